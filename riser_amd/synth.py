@@ -1,0 +1,187 @@
+"""Deterministic synthetic weights and squiggle signals (host side, numpy only).
+
+Nothing here is on the compute path: it only manufactures inputs for tests, the
+golden-vector generator (tools/make_golden.py) and bench.py, because the reference's
+trained weights are not distributed (/root/reference/.MISSING_LARGE_BLOBS:1-6) and
+there is no network for datasets.  Every value is a pure function of integer
+(seed, stream, index) counters pushed through a 64-bit mixing hash, so the same
+arrays are rebuilt bit-for-bit on the GPU box without shipping 41.8 MB per model and
+without depending on the numpy / torch RNG streams.
+
+Shapes follow the reference network (riser/nets/cnn.py:13-33, channel list at
+riser/model/mRNA_config_RNA004_RP4.yaml:7-12) and its state_dict keys
+(`layers.{i}.0.weight|bias`, `classifier.2.weight|bias`).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+CHANNELS = (20, 30, 45, 67, 100, 150, 225, 337, 505, 757, 1135, 1702)
+KERNELS = (3,) * 12
+N_CLASSES = 2
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on uint64 arrays (wrap-around arithmetic)."""
+    x = x.astype(np.uint64, copy=True)
+    with np.errstate(over="ignore"):
+        x += np.uint64(0x9E3779B97F4A7C15)
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return x
+
+
+def _key(seed: int, stream: int) -> np.uint64:
+    k = _mix64(np.array([seed & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))
+    with np.errstate(over="ignore"):
+        k = _mix64(k ^ (np.uint64(stream) * np.uint64(0xD6E8FEB86659FD93)))
+    return k[0]
+
+
+def hash_u64(seed: int, stream: int, n: int, start: int = 0) -> np.ndarray:
+    """n hashed uint64 for counters start..start+n-1 of (seed, stream)."""
+    idx = np.arange(start, start + n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return _mix64(idx * np.uint64(0x2545F4914F6CDD1D) ^ _key(seed, stream))
+
+
+def uniform_pm1(seed: int, stream: int, n: int) -> np.ndarray:
+    """float32 uniform in [-1, 1) with 24 random bits (exact in fp32)."""
+    h = hash_u64(seed, stream, n)
+    u = (h >> np.uint64(40)).astype(np.int64) - (1 << 23)          # [-2^23, 2^23)
+    return (u.astype(np.float32) * np.float32(2.0 ** -23)).astype(np.float32)
+
+
+class CnnConfig:
+    """Duck-type of the `config.cnn` namespace the reference ConvNet reads
+    (riser/nets/cnn.py:13-21)."""
+
+    def __init__(self, channels=CHANNELS, kernels=KERNELS, n_classes=N_CLASSES,
+                 classifier="gap_fc", depth=1):
+        self.n_layers = len(channels)
+        self.depth = depth
+        self.channels = list(channels)
+        self.kernels = list(kernels)
+        self.n_classes = n_classes
+        self.classifier = classifier
+
+
+class Config:
+    def __init__(self, cnn=None):
+        self.cnn = cnn or CnnConfig()
+
+
+# Calibration constants (see tools/make_golden.py --calibrate): conv weights are
+# uniform(-a, a) with a = GAIN * sqrt(6 / fan_in) (He-uniform would be GAIN = 1);
+# biases uniform(-0.05, 0.05); the FC layer is scaled so that logit differences
+# spread over roughly +-4 and some probabilities land near the 0.9 threshold
+# (torch default init gives a constant 0.494/0.506,
+# naive He init saturates to exactly 0/1).
+CONV_GAIN = 0.92
+BIAS_AMP = 0.05
+FC_AMP = 0.055
+# Per-seed (fc_scale, logit-difference offset), measured once over 64 synthetic
+# 16000-sample reads so that p_on has spread on both sides of 0.5 / 0.9 for the three
+# stand-in models (seeds 1/2/3 = mRNA/mtRNA/globin).  Other seeds use the default.
+FC_CAL = {1: (18.0, 8.69), 2: (7.5, 1.98), 3: (10.0, 12.4), 4: (2.6, -6.68)}
+FC_CAL_DEFAULT = (8.0, 0.0)
+
+
+def make_state_dict(seed: int, channels=CHANNELS, n_classes=N_CLASSES) -> dict:
+    """Reference-compatible state dict of float32 numpy arrays."""
+    sd = {}
+    c_in = 1
+    for i, c_out in enumerate(channels):
+        fan_in = c_in * 3
+        a = np.float32(CONV_GAIN * np.sqrt(6.0 / fan_in))
+        w = uniform_pm1(seed, 2 * i, c_out * c_in * 3) * a
+        b = uniform_pm1(seed, 2 * i + 1, c_out) * np.float32(BIAS_AMP)
+        sd[f"layers.{i}.0.weight"] = w.reshape(c_out, c_in, 3).astype(np.float32)
+        sd[f"layers.{i}.0.bias"] = b.astype(np.float32)
+        c_in = c_out
+    fc_scale, fc_off = FC_CAL.get(seed, FC_CAL_DEFAULT)
+    fw = uniform_pm1(seed, 1000, n_classes * c_in) * np.float32(FC_AMP * fc_scale)
+    fb = uniform_pm1(seed, 1001, n_classes) * np.float32(0.1)
+    fb[n_classes - 1] += np.float32(fc_off)
+    sd["classifier.2.weight"] = fw.reshape(n_classes, c_in).astype(np.float32)
+    sd["classifier.2.bias"] = fb.astype(np.float32)
+    return sd
+
+
+def make_signals(seed: int, n_reads: int, length: int, first_read: int = 0,
+                 spikes: bool = True) -> np.ndarray:
+    """int16 [n_reads, length] ADC-like squiggles, integer arithmetic only.
+
+    Each read is a piecewise-constant level sequence (events of 6..37 samples whose
+    level is drawn per event, with a per-read level spread so reads differ in texture)
+    plus approximately normal noise (sum of four 16-bit uniforms), centred near 500 ADC
+    counts; dwell scale (x1/2/4) and noise sigma (~7/15/30) are drawn per read.  0.5 % of samples are replaced by +-(400..1500) spikes, and one read in 16
+    gets forced runs of 2..4 consecutive spikes, to exercise the outlier smoothing of
+    riser/preprocess.py:127-139.  Values are clipped to [0, 4095].
+    """
+    out = np.empty((n_reads, length), dtype=np.int16)
+    n_ev_max = length // 6 + 2
+    for r in range(n_reads):
+        rid = first_read + r
+        # --- events -----------------------------------------------------------
+        he = hash_u64(seed, 3 * rid, n_ev_max)
+        hr = int(hash_u64(seed, 3 * rid + 1, 1, start=1 << 40)[0])
+        dwell = (6 + (he & np.uint64(31)).astype(np.int64)) << ((hr >> 8) % 3)   # 6..37, x1/2/4
+        spread = 20 + hr % 90
+        nmul = (13, 26, 52)[(hr >> 16) % 3]                               # noise sigma ~ 7/15/30
+        lev = ((he >> np.uint64(8)) & np.uint64(0xFFFF)).astype(np.int64) - 32768
+        lev = (lev * spread) >> 15                                        # +-spread
+        ends = np.cumsum(dwell)
+        ev = np.searchsorted(ends, np.arange(length, dtype=np.int64), side="right")
+        base = 500 + lev[ev]
+        # --- noise: Irwin-Hall(4) ~ N(0,1) after scaling ------------------------
+        hn = hash_u64(seed, 3 * rid + 1, length)
+        s = ((hn & np.uint64(0xFFFF)) + ((hn >> np.uint64(16)) & np.uint64(0xFFFF))
+             + ((hn >> np.uint64(32)) & np.uint64(0xFFFF)) + (hn >> np.uint64(48))).astype(np.int64)
+        noise = ((s - 131070) * nmul) >> 16
+        x = base + noise
+        if spikes:
+            hs = hash_u64(seed, 3 * rid + 2, length)
+            is_spk = (hs % np.uint64(200)) == 0
+            if rid % 16 == 0:                                             # forced runs
+                starts = np.nonzero((hs % np.uint64(4000)) == 1)[0]
+                for s0 in starts:
+                    run = 2 + int(hs[s0] >> np.uint64(60)) % 3
+                    is_spk[s0:s0 + run] = True
+            mag = 400 + ((hs >> np.uint64(20)) % np.uint64(1101)).astype(np.int64)
+            sign = np.where(((hs >> np.uint64(12)) & np.uint64(1)) == 1, 1, -1)
+            x = np.where(is_spk, 500 + sign * mag, x)
+        out[r] = np.clip(x, 0, 4095).astype(np.int16)
+    return out
+
+
+def make_raw_read(seed: int, rid: int, total_len: int, polya: bool = True) -> np.ndarray:
+    """int16 [total_len] raw read as MinKNOW would stream it: sequencing adapter, then
+    (optionally) a quiet, elevated poly(A) plateau, then the RNA squiggle.  Built so the
+    window rule of riser/preprocess.py:49-72 fires (plateau mean > 1.2 x the preceding
+    1000 samples with window MAD <= 20) when `polya` is set and cannot fire otherwise.
+    """
+    hr = int(hash_u64(seed, 5 * rid + 4, 1, start=1 << 41)[0])
+    a_len = 1200 + hr % 1400
+    p_len = (1500 + (hr >> 16) % 3000) if polya else 0
+    a_len = min(a_len, total_len)
+    p_len = min(p_len, total_len - a_len)
+    r_len = total_len - a_len - p_len
+    parts = []
+    # adapter: textured, mean ~470
+    ad = make_signals(seed ^ 0xA5A5, 1, max(a_len, 1), first_read=rid, spikes=False)[0, :a_len].astype(np.int64)
+    parts.append(ad - 30)
+    if p_len:
+        hn = hash_u64(seed, 5 * rid + 3, p_len)
+        s = ((hn & np.uint64(0xFFFF)) + ((hn >> np.uint64(16)) & np.uint64(0xFFFF))
+             + ((hn >> np.uint64(32)) & np.uint64(0xFFFF)) + (hn >> np.uint64(48))).astype(np.int64)
+        parts.append(760 + (((s - 131070) * 10) >> 16))                    # sigma ~ 6
+    if r_len:
+        parts.append(make_signals(seed, 1, r_len, first_read=rid)[0].astype(np.int64))
+    x = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+    return np.clip(x, 0, 4095).astype(np.int16)

@@ -1,0 +1,162 @@
+"""Pin the CPU oracle (oracle/) to outputs of the reference itself.
+
+The fixtures in tests/golden/ were produced by tools/make_golden.py, which imports
+/root/reference and records what its own SignalProcessor / Model / SequencerControl
+returned.  These tests run without a GPU and without the reference.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import riser_oracle as ro
+from oracle import torch_path
+from riser_amd import synth
+from riser_amd.fake_client import FakeClient, FakeRead
+
+
+@pytest.fixture(scope="module")
+def norm(golden_dir):
+    return np.load(os.path.join(golden_dir, "normalise.npz"))
+
+
+def test_normalise_bit_exact(norm):
+    names = [str(n) for n in norm["names"]]
+    assert len(names) >= 20
+    for name in names:
+        sig, want, stats = norm[f"{name}.sig"], norm[f"{name}.out"], norm[f"{name}.stats"]
+        med, mad = ro.median_mad(sig)
+        assert med == stats[0] and mad == stats[1], name
+        got = ro.mad_normalise(sig)
+        assert got.dtype == want.dtype, name                      # int64 zeros when mad == 0
+        assert np.array_equal(got, want), name                    # bit-exact float64
+
+
+def test_normalise_empty_raises():
+    with pytest.raises(ValueError):
+        ro.mad_normalise(np.zeros(0, dtype=np.int16))
+
+
+def test_kit_constants():
+    # SURVEY 8(a) A1 [probe values from the reference]
+    assert ro.kit_max_length("RNA002") == 12048 and ro.kit_max_length("RNA004") == 8615
+    assert ro.kit_fixed_trim_length("RNA002") == 6480 and ro.kit_fixed_trim_length("RNA004") == 4633
+
+
+def test_polya_end(golden_dir):
+    cases = np.load(os.path.join(golden_dir, "polya.npz"))["cases"]
+    found = 0
+    for seed, rid, n, polya, want in cases:
+        got = ro.polya_end(synth.make_raw_read(int(seed), int(rid), int(n), bool(polya)))
+        assert (-1 if got is None else got) == want
+        found += want >= 0
+    assert found >= 20
+
+
+@pytest.fixture(scope="module")
+def net(golden_dir):
+    return np.load(os.path.join(golden_dir, "network.npz"))
+
+
+def _signals(net, seed, L, B, first):
+    sigs = synth.make_signals(int(net["sig_seed"][0]), B, L, first_read=first)
+    crc = net[f"s{seed}_L{L}_B{B}_r{first}.sig_crc"]
+    s = sigs.astype(np.int64)
+    assert int(s.sum()) == crc[0] and int((s ** 2).sum()) == crc[1], "synthetic signal generator drifted"
+    return sigs
+
+
+def test_network_numpy_oracle(net):
+    """numpy fp32 oracle vs reference Model.classify: probs within 2e-5, labels equal."""
+    for seed, L, B, first in net["cases"]:
+        if B > 8:
+            continue
+        tag = f"s{seed}_L{L}_B{B}_r{first}"
+        sigs = _signals(net, seed, L, B, first)
+        sd = synth.make_state_dict(int(seed))
+        probs = ro.classify_reads(sd, sigs)
+        want = net[f"{tag}.probs"]
+        assert np.abs(probs - want).max() < 2e-5, tag
+        assert np.array_equal(probs[:, 1] > 0.9, want[:, 1] > 0.9), tag
+        # per-layer statistics of read 0
+        _, layers = ro.convnet_forward(sd, ro.mad_normalise(sigs[0]).astype(np.float32)[None], return_layers=True)
+        st = net[f"{tag}.layer_stats"]
+        for i, h in enumerate(layers):
+            assert h.shape[1] == st[i, 4] and h.shape[2] == st[i, 5]
+            assert abs(float(h.astype(np.float64).sum()) - st[i, 0]) <= 1e-4 * max(1.0, st[i, 1]), (tag, i)
+
+
+def test_network_torch_port(net):
+    """the torch-CPU port used as bench.py's cpu_baseline reproduces the reference."""
+    for seed, L, B, first in net["cases"]:
+        if B < 32:
+            continue
+        tag = f"s{seed}_L{L}_B{B}_r{first}"
+        sigs = _signals(net, seed, L, B, first)
+        m = torch_path.TorchCpuModel(synth.make_state_dict(int(seed)))
+        probs = torch_path.classify_per_read(m, sigs)
+        want = net[f"{tag}.probs"]
+        assert np.abs(probs - want).max() < 1e-5, tag
+        assert np.array_equal(probs[:, 1] > 0.9, want[:, 1] > 0.9), tag
+
+
+def test_probs_are_discriminating(net):
+    """guard against degenerate fixtures (SURVEY 8(c) last row)."""
+    p = net["s1_L16000_B32_r1000.probs"][:, 1]
+    assert (p > 0.9).sum() >= 2 and (p < 0.2).sum() >= 2 and ((p > 0.3) & (p < 0.7)).sum() >= 2
+
+
+def test_control_loop_oracle(golden_dir):
+    """oracle normalise + polyA + classify + decide replays the reference control loop
+    (riser/control.py:31-97) row for row."""
+    with open(os.path.join(golden_dir, "control.json")) as f:
+        g = json.load(f)
+    max_len = ro.kit_max_length(g["kit"])
+    fixed = ro.kit_fixed_trim_length(g["kit"])
+    models = {}
+    for run in g["runs"]:
+        if run["mode"] != "enrich":
+            continue                                   # same probabilities; decisions covered below
+        for s in run["seeds"]:
+            models.setdefault(s, torch_path.TorchCpuModel(synth.make_state_dict(s)))
+    prob_cache = {}
+    for run in g["runs"]:
+        rows = []
+        cache = {}
+        for batch in g["script"]:
+            for ch, read_id, rid, n, polya, number in batch:
+                sig = synth.make_raw_read(g["raw_seed"], rid, n, bool(polya))
+                sig, trimmed = ro.trim_polya(sig, read_id, cache)
+                if not trimmed:
+                    if len(sig) > fixed + max_len:
+                        sig = sig[fixed:][:max_len]
+                    else:
+                        continue
+                else:
+                    if len(sig) < ro.MIN_INPUT_SIGNALS:
+                        continue
+                    sig = sig[:max_len]
+                key = (read_id, n)
+                p_on, p_off = [], []
+                for s in run["seeds"]:
+                    if (key, s) not in prob_cache:
+                        prob_cache[(key, s)] = models[s].classify(ro.mad_normalise(sig)).numpy()
+                    p = prob_cache[(key, s)]
+                    p_off.append(p[0]); p_on.append(p[1])
+                rows.append((read_id, ch, len(sig), [float(p) for p in p_on],
+                             ro.decide(p_on, p_off, run["threshold"], run["mode"], len(sig), max_len)))
+        assert len(rows) == len(run["rows"])
+        for got, want in zip(rows, run["rows"]):
+            assert got[0] == want["read_id"] and got[1] == want["channel"] and got[2] == want["sig_length"]
+            assert np.allclose(got[3], want["prob_targets"], atol=1e-5)
+            assert got[4] == want["decision"], (run["mode"], run["seeds"], run["threshold"], want)
+
+
+def test_fake_client_contract():
+    c = FakeClient([[(1, FakeRead("a", np.arange(10, dtype=np.int16), number=3))], []])
+    assert c.is_running()
+    (ch, rd), = c.get_read_batch()
+    assert ch == 1 and rd.id == "a" and rd.number == 3 and np.array_equal(c.get_raw_signal(rd), np.arange(10))
+    c.get_read_batch()
+    assert not c.is_running()

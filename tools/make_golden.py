@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (it imports /root/reference, which does not exist on
+the GPU box and must never be copied).  The committed outputs are data: inputs (or the
+integer seeds that rebuild them through riser_amd.synth) and the values the reference's
+own code returned for them.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+
+Reference entry points exercised:
+  F1  SignalProcessor.mad_normalise          riser/preprocess.py:108-147
+  F2  Model.classify / ConvNet.forward        riser/model.py:22-28, riser/nets/cnn.py:43-65
+  F3  SequencerControl.target                 riser/control.py:11-124 (fake client)
+  F4  SignalProcessor.get_polyA_end           riser/preprocess.py:42-79
+"""
+import json
+import logging
+import os
+import sys
+import tempfile
+import types
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# riser/nets/cnn.py:2 imports torchinfo (unused, not installed): stub it.
+sys.modules.setdefault("torchinfo", types.SimpleNamespace(summary=None))
+sys.path.insert(0, "/root/reference/riser")
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+from model import Model                              # noqa: E402  (reference)
+from preprocess import Kit, SignalProcessor          # noqa: E402  (reference)
+from control import SequencerControl                 # noqa: E402  (reference)
+
+from riser_amd import synth                          # noqa: E402
+from riser_amd.fake_client import FakeClient, FakeRead   # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SIG_SEED = 20260103
+LOG = logging.getLogger("golden")
+LOG.addHandler(logging.NullHandler())
+
+
+def ref_model(seed, target="mRNA"):
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(seed).items()}
+    with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as f:
+        torch.save(sd, f.name)
+        path = f.name
+    try:
+        return Model(path, synth.Config(), LOG, target)
+    finally:
+        os.unlink(path)
+
+
+# --------------------------------------------------------------------------------------
+def f1_normalise():
+    proc = SignalProcessor(Kit.create_from_version("RNA004"))
+    cases = {}
+    for L in (4096, 4097, 6024, 8615, 12048, 16000):
+        cases[f"synth_{L}"] = synth.make_signals(SIG_SEED, 1, L, first_read=L % 97)[0]
+    cases["synth_runs_16000"] = synth.make_signals(SIG_SEED, 1, 16000, first_read=16)[0]   # rid%16==0: forced runs
+    base = synth.make_signals(SIG_SEED, 1, 5000, first_read=3, spikes=False)[0]
+
+    def with_spikes(pos_val, src=base):
+        s = src.copy()
+        for p, v in pos_val:
+            s[p] = v
+        return s
+
+    cases["out_first"] = with_spikes([(0, 2500)])
+    cases["out_first_two"] = with_spikes([(0, 2500), (1, 2400)])
+    cases["out_first_three_neg"] = with_spikes([(0, 0), (1, 5), (2, 2)])
+    cases["out_last"] = with_spikes([(4999, 2500)])
+    cases["out_last_two"] = with_spikes([(4998, 30), (4999, 2500)])
+    cases["run3"] = with_spikes([(100, 1900), (101, 2000), (102, 1800)])
+    cases["run4_mixed_sign"] = with_spikes([(200, 1900), (201, 10), (202, 1800), (203, 5)])
+    cases["run5_then_gap_run2"] = with_spikes([(300 + k, 1500 + 37 * k) for k in range(5)] + [(306, 1700), (307, 20)])
+    cases["long_run_64"] = with_spikes([(1000 + k, 1200 + (k * 53) % 700) for k in range(64)])
+    cases["alternating"] = with_spikes([(2000 + 2 * k, 2000) for k in range(40)])
+    cases["mad0_constant"] = np.full(4096, 512, dtype=np.int16)
+    m = synth.make_signals(SIG_SEED, 1, 4100, first_read=5)[0]
+    m[:2500] = 500
+    cases["mad0_majority"] = m
+    cases["even_half_median"] = np.array([1, 2, 3, 4, 5, 6, 7, 8, 100, -50] * 410, dtype=np.int16)
+    cases["odd_len"] = np.array([3, -2, 7, 7, 1, 0, 9, 11, -30000, 30000, 4] * 373, dtype=np.int16)
+    cases["negative_adc"] = (synth.make_signals(SIG_SEED, 1, 4500, first_read=9)[0].astype(np.int32) - 2600).astype(np.int16)
+    cases["two_level"] = np.array(([100] * 7 + [900] * 6) * 400, dtype=np.int16)
+    cases["tiny_len5"] = np.array([5, 1, 9, 3, 400], dtype=np.int16)
+    cases["tiny_len2"] = np.array([5, 9], dtype=np.int16)
+
+    out = {}
+    names = []
+    for name, sig in cases.items():
+        y = proc.mad_normalise(sig.copy())
+        med = np.median(sig)
+        mad = np.median(np.abs(sig - med))
+        names.append(name)
+        out[f"{name}.sig"] = sig
+        out[f"{name}.out"] = np.asarray(y)
+        out[f"{name}.stats"] = np.array([med, mad], dtype=np.float64)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "normalise.npz"), **out)
+    print("F1:", len(names), "cases")
+
+
+# --------------------------------------------------------------------------------------
+def f2_network():
+    proc = SignalProcessor(Kit.create_from_version("RNA004"))
+    out = {}
+    cases = []
+    plan = [(1, L, 3, 100 + i) for i, L in enumerate((4096, 4097, 5000, 6024, 8000, 8615, 12000, 12048, 16000))]
+    plan += [(2, 6024, 64, 0)]                       # BASELINE config 1 (RNA002 2 s, 64 chunks)
+    plan += [(s, 16000, 8, 0) for s in (1, 2, 3)]    # ensemble stand-ins, RNA004 4 s
+    plan += [(1, 16000, 32, 1000)]
+    for seed, L, B, first in plan:
+        tag = f"s{seed}_L{L}_B{B}_r{first}"
+        m = ref_model(seed)
+        sigs = synth.make_signals(SIG_SEED, B, L, first_read=first)
+        probs = np.zeros((B, 2), np.float32)
+        logits = np.zeros((B, 2), np.float32)
+        for b in range(B):
+            x = proc.mad_normalise(sigs[b].copy())
+            probs[b] = m.classify(x).numpy()
+            with torch.no_grad():
+                logits[b] = m.model(torch.from_numpy(x).unsqueeze(0).float())[0].numpy()
+        # per-layer statistics of read 0 for bisecting
+        with torch.no_grad():
+            h = torch.from_numpy(proc.mad_normalise(sigs[0].copy())).float()[None, None, :]
+            stats = []
+            for layer in m.model.layers:
+                h = layer(h)
+                flat = h.flatten().double()
+                stats.append([float(flat.sum()), float(flat.abs().sum()), float(h[0, 0, 0]), float(h[0, -1, -1]),
+                              float(h.shape[1]), float(h.shape[2])])
+        out[f"{tag}.probs"] = probs
+        out[f"{tag}.logits"] = logits
+        out[f"{tag}.layer_stats"] = np.array(stats, dtype=np.float64)
+        out[f"{tag}.sig_crc"] = np.array([int(sigs.astype(np.int64).sum()), int((sigs.astype(np.int64) ** 2).sum())], dtype=np.int64)
+        cases.append([seed, L, B, first])
+        print("F2:", tag, "p_on", np.round(probs[:4, 1], 4))
+    out["cases"] = np.array(cases, dtype=np.int64)
+    out["sig_seed"] = np.array([SIG_SEED], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "network.npz"), **out)
+
+
+# --------------------------------------------------------------------------------------
+def control_script():
+    """(channel, read_id, rid, total_len, polya, number) per batch; RNA004 kit:
+    max 8615, fixed trim 4633, fixed-trim trigger > 13248 (riser/preprocess.py:36-37,81-85)."""
+    b0 = [
+        (1, "r-polya-short", 0, 7000, True, None),       # trimmed but < 4096 left -> skipped (or not found)
+        (2, "r-polya-mid", 1, 12000, True, None),        # trimmed, 4096 <= len < max
+        (3, "r-polya-long", 2, 20000, True, 17),         # trimmed, > max -> cut to 8615
+        (4, "r-nopolya-short", 3, 9000, False, None),    # not found, too short for fixed trim -> skipped
+        (5, "r-nopolya-long", 4, 14000, False, None),    # not found, fixed trim + cut to max
+        (6, "r-polya-mid2", 5, 11000, True, 23),
+        (7, "r-polya-mid3", 6, 12500, True, None),
+        (8, "r-nopolya-long2", 7, 15000, False, 99),
+    ]
+    b1 = [
+        (1, "r-polya-short", 0, 11500, True, None),      # same read, more signal: cache hit, now assessable
+        (2, "r-polya-mid", 1, 14000, True, None),
+        (9, "r-polya-new", 8, 13000, True, None),
+        (4, "r-nopolya-short", 3, 13249, False, None),   # just over the fixed-trim trigger
+        (10, "r-edge-13248", 9, 13248, False, None),     # exactly at the trigger: not trimmed (strict >)
+    ]
+    b2 = [(11 + k, f"r-bulk-{k}", 20 + k, 10000 + 411 * k, k % 3 != 0, None) for k in range(12)]
+    return [b0, b1, b2]
+
+
+def build_batches(script, seed=77):
+    batches = []
+    for b in script:
+        reads = []
+        for ch, rid_s, rid, n, polya, number in b:
+            reads.append((ch, FakeRead(rid_s, synth.make_raw_read(seed, rid, n, polya), number)))
+        batches.append(reads)
+    return batches
+
+
+def f3_control():
+    script = control_script()
+    results = {"script": script, "raw_seed": 77, "kit": "RNA004", "runs": []}
+    for mode in ("enrich", "deplete"):
+        for seeds, thr in (((1,), 0.9), ((1,), 0.6), ((1,), 0.999), ((2,), 0.9), ((1, 2, 3), 0.9),
+                           ((2, 3), 0.9), ((2, 3), 0.6)):
+            if True:
+                models = [ref_model(s, t) for s, t in zip(seeds, ("mRNA", "mtRNA", "globin"))]
+                proc = SignalProcessor(Kit.create_from_version("RNA004"))
+                client = FakeClient(build_batches(script))
+                with tempfile.TemporaryDirectory() as d:
+                    ctl = SequencerControl(client, models, proc, LOG, os.path.join(d, "out"))
+                    ctl.start()
+                    ctl.target(mode, 1.0, thr)
+                    ctl.finish()
+                    with open(os.path.join(d, "out.csv")) as f:
+                        lines = f.read().strip().split("\n")
+                rows = []
+                for ln in lines[1:]:
+                    p = ln.split(",")
+                    rows.append({"read_id": p[1], "channel": int(p[2]), "sig_length": int(p[3]), "models": p[4],
+                                 "prob_targets": [float(v) for v in p[5].split(";")], "threshold": float(p[6]),
+                                 "mode": p[7], "decision": p[8]})
+                results["runs"].append({"mode": mode, "seeds": list(seeds), "threshold": thr, "header": lines[0],
+                                        "rows": rows, "rejected": client.rejected, "finished": client.finished,
+                                        "warnings": client.warnings, "unblock": client.unblock_durations})
+                print("F3:", mode, seeds, thr, [r["decision"] for r in rows])
+    with open(os.path.join(OUT, "control.json"), "w") as f:
+        json.dump(results, f, indent=1)
+
+
+# --------------------------------------------------------------------------------------
+def f4_polya():
+    proc = SignalProcessor(Kit.create_from_version("RNA004"))
+    cases = []
+    for rid in range(40):
+        n = 6000 + 523 * rid
+        polya = rid % 4 != 3
+        sig = synth.make_raw_read(91, rid, n, polya)
+        end = proc.get_polyA_end(sig)
+        cases.append([91, rid, n, int(polya), -1 if end is None else int(end)])
+    # hand-made: plateau that never ends (no later noisy window) and a too-short read
+    np.savez_compressed(os.path.join(OUT, "polya.npz"), cases=np.array(cases, dtype=np.int64))
+    print("F4:", [c[4] for c in cases])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4"]
+    if "f1" in which:
+        f1_normalise()
+    if "f4" in which:
+        f4_polya()
+    if "f2" in which:
+        f2_network()
+    if "f3" in which:
+        f3_control()
