@@ -1,0 +1,175 @@
+/*
+ * riser_amd.h -- C ABI of the MI355X (gfx950) squiggle-classification hot path.
+ *
+ * This is the drop-in boundary for the path
+ *     SignalProcessor.mad_normalise -> Model.classify -> ConvNet.forward -> softmax
+ * of comprna/riser.  The reference has no native code and therefore no FFI of its own;
+ * each entry point below names the reference Python interface it replaces
+ * (file:line under /root/reference).  INTEGRATION.md shows the ctypes stub a RISER
+ * maintainer would add to riser/model.py and riser/preprocess.py.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every function returns RS_OK (0) or a
+ *     negative rs_status and records a message readable with rs_last_error()
+ *     (thread-local).
+ *   - all `d_` pointers are DEVICE pointers owned by the caller (e.g. torch tensors'
+ *     data_ptr()); the library owns only the packed weight copies made by
+ *     rs_model_create and frees them in rs_model_destroy.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all launches
+ *     are asynchronous on it, nothing here synchronises the device.
+ *   - raw signal samples are int16 ADC counts, as delivered by
+ *     riser/client.py:47 (np.frombuffer(read.raw_data, signal_dtype)).
+ *   - a batch is B reads; read b is the `d_len[b]` samples starting at element
+ *     `d_off[b]` of `d_sig` (so a trim is just an offset: riser/preprocess.py:100,105).
+ *   - reads shorter than 2^n_layers samples (4096 for the shipped 12-layer net,
+ *     riser/preprocess.py:8) cannot be classified: RS_ERR_LENGTH, matching the
+ *     RuntimeError torch raises in max_pool1d for the reference.
+ */
+#ifndef RISER_AMD_H
+#define RISER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rs_status {
+    RS_OK = 0,
+    RS_ERR_ARG = -1,        /* null pointer, bad size, unsupported configuration */
+    RS_ERR_HIP = -2,        /* a HIP runtime call failed; message has hipGetErrorString */
+    RS_ERR_LENGTH = -3,     /* a read is empty / shorter than the network minimum / too long */
+    RS_ERR_OOM = -4,        /* device or host allocation failed */
+    RS_ERR_WORKSPACE = -5   /* caller's workspace is smaller than rs_workspace_bytes() */
+} rs_status;
+
+/* arithmetic type of the conv stack (accumulation is always fp32) */
+typedef enum rs_dtype {
+    RS_F32 = 0,             /* f32-input MFMA (v_mfma_f32_16x16x4_f32): exact fmaf chains */
+    RS_BF16 = 1             /* bf16 activations/weights, v_mfma_f32_16x16x32_bf16, fp32 accumulate */
+} rs_dtype;
+
+/* decisions of riser/control.py:75-82, as written into rs_decide's output */
+typedef enum rs_decision {
+    RS_TRY_AGAIN = 0,
+    RS_ACCEPT = 1,
+    RS_REJECT = 2,
+    RS_NO_DECISION = 3
+} rs_decision;
+
+typedef enum rs_mode { RS_ENRICH = 0, RS_DEPLETE = 1 } rs_mode;
+
+typedef struct rs_model rs_model;
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* rs_last_error(void);
+
+/* ABI version of this header: (major << 16) | minor. */
+int rs_version(void);
+
+/* Number of HIP devices visible (0 if none / no driver).  Does not select a device. */
+int rs_device_count(void);
+
+/*
+ * Build a model on `device` from a reference-format ConvNet state dict.
+ * Replaces Model.__init__ (riser/model.py:7-20) + ConvNet.__init__ (riser/nets/cnn.py:8-41)
+ * for the shipped configuration: depth 1, kernel 3, classifier `gap_fc`.
+ *   n_layers            number of conv blocks (config.cnn.n_layers, 12 in every shipped yaml)
+ *   channels[n_layers]  config.cnn.channels
+ *   conv_w[i]           HOST fp32 [channels[i], channels[i-1] (1 for i==0), 3]  = layers.{i}.0.weight
+ *   conv_b[i]           HOST fp32 [channels[i]]                                   = layers.{i}.0.bias
+ *   fc_w                HOST fp32 [n_classes, channels[n_layers-1]]               = classifier.2.weight
+ *   fc_b                HOST fp32 [n_classes]                                     = classifier.2.bias
+ *   n_classes           must be 2 (riser/control.py:69 unpacks exactly two probabilities)
+ * Host pointers need only live for the duration of the call.
+ */
+int rs_model_create(int n_layers, const int32_t* channels, int n_classes,
+                    const float* const* conv_w, const float* const* conv_b,
+                    const float* fc_w, const float* fc_b,
+                    int dtype /* rs_dtype */, int device, rs_model** out);
+
+int rs_model_destroy(rs_model* m);
+
+/* Bytes of device workspace rs_forward / rs_classify need for a batch of B reads of at
+ * most Lmax samples (0 on bad arguments). */
+size_t rs_workspace_bytes(const rs_model* m, int B, int Lmax);
+
+/*
+ * MAD normalisation + outlier smoothing of B reads.
+ * Replaces SignalProcessor.mad_normalise (riser/preprocess.py:108-147), bit-exact in
+ * float64: exact integer median / MAD, y = (x - med) / (1.4826 * mad), then the
+ * sequential in-place smoothing of |y| > 3.5 (order-dependent recurrence, un-clipped
+ * ends).  mad == 0 gives zeros (the reference returns an int64 zero array).
+ *   d_out32  fp32 [B, ld32] or NULL: (float)y, i.e. the cast of riser/model.py:25;
+ *            elements [len, pad_to) of each row are zero-filled (pad_to <= ld32)
+ *   d_out64  fp64 [B, ld64] or NULL: y exactly as the reference returns it
+ *   d_stats  fp64 [B, 2] or NULL: (median, mad)
+ * Lmax is the host-known maximum of d_len (sizes the LDS staging buffer); every read
+ * must have 1 <= len <= Lmax <= 65536.
+ */
+int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
+                 float* d_out32, int64_t ld32, int32_t pad_to,
+                 double* d_out64, int64_t ld64, double* d_stats, void* stream);
+
+/*
+ * Forward pass + softmax on already normalised fp32 signals.
+ * Replaces Model.classify (riser/model.py:22-28) -> ConvNet.forward
+ * (riser/nets/cnn.py:43-65) for a batch: B independent reads of individual length.
+ *   d_x       fp32 [B, ldx]; row b holds d_len[b] samples followed by zeros up to
+ *             the padded pitch returned by rs_padded_length(m, Lmax) (<= ldx)
+ *   d_probs   fp32 [B, 2] = (p_off_target, p_on_target), the order of riser/control.py:69
+ *   d_logits  fp32 [B, 2] or NULL
+ */
+int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmax,
+               void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream);
+
+/* Row pitch (in samples) the conv stack uses for reads of at most Lmax samples:
+ * the smallest multiple of 2^n_layers that is >= Lmax + 1.  rs_normalise's pad_to. */
+int rs_padded_length(const rs_model* m, int Lmax);
+
+/*
+ * Fused path: raw int16 reads -> normalise -> forward -> probabilities.
+ * Equivalent to the pair of calls at riser/control.py:63 and :69 for every read of the
+ * batch; the normalised signals live in the workspace.
+ */
+int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len,
+                int B, int Lmax, void* d_ws, size_t ws_bytes,
+                float* d_probs, float* d_logits, void* stream);
+
+/*
+ * Ensemble decision of riser/control.py:75-82 for B reads and n_models models.
+ *   d_probs   fp32 [n_models, B, 2]
+ *   max_len   SignalProcessor.get_max_length() (riser/preprocess.py:36-40)
+ *   d_out     uint8 [B], rs_decision values
+ * Comparisons are strict `>` in fp32, as torch does for `tensor > python_float`.
+ */
+int rs_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len,
+              float threshold, int mode /* rs_mode */, uint8_t* d_out, void* stream);
+
+/*
+ * poly(A) end detector on raw reads.
+ * Replaces SignalProcessor.get_polyA_end (riser/preprocess.py:42-79): 500-sample
+ * windows, start when the window mean rose > 20 % over the previous 1000 samples with
+ * window MAD <= 20, end at the first later window with MAD > 20.
+ *   d_end     int32 [B]: the end index (a multiple of 500) or -1 where the reference
+ *             returns None
+ */
+int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B,
+                 int32_t* d_end, void* stream);
+
+/* Introspection used by bench.py for roofline accounting: per conv layer i (0-based),
+ * fills the padded GEMM shape the kernels execute.  Returns RS_ERR_ARG if out of range. */
+typedef struct rs_layer_info {
+    int32_t c_in, c_out;        /* logical channels */
+    int32_t cp_in, cp_out;      /* padded row widths of the activation buffers */
+    int32_t k_pad;              /* padded reduction length (3 * padded input channels) */
+    int32_t n_pad;              /* padded output channels the MFMA tiles cover */
+    int32_t bm, bn, kc;         /* workgroup tile (rows x couts) and channel chunk of the last launch (0 if never run) */
+} rs_layer_info;
+int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RISER_AMD_H */

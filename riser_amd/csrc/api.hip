@@ -1,0 +1,394 @@
+// C ABI of libriser_amd (see include/riser_amd.h): model construction / weight packing,
+// workspace layout, tile planning and the launch sequence of one forward pass.
+#include "common.hpp"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+namespace rs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return RS_ERR_HIP;
+}
+
+size_t conv_f32_lds_bytes(int mt, int nt, int kc, int nch);
+
+}  // namespace rs
+
+using namespace rs;
+
+struct rs_model {
+    int device = 0;
+    int dtype = RS_F32;
+    int n_layers = 0;
+    int n_classes = 2;
+    int channels[kMaxLayers] = {0};
+    int cp[kMaxLayers] = {0};             // padded row width of layer i's OUTPUT buffer
+    float* d_w0 = nullptr;                // layer 0: [cp[0]][4] = (w0, w1, w2, bias)
+    ConvLayerDev layers[kMaxLayers];      // i >= 1
+    float* d_fcw = nullptr;               // [2][c_last]
+    float* d_fcb = nullptr;
+    int last_bm[kMaxLayers] = {0};
+    int last_bn[kMaxLayers] = {0};
+};
+
+namespace {
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+int esize(const rs_model* m) { return m->dtype == RS_BF16 ? 2 : 4; }
+
+// ---- static part of the tile plan: nt (couts per wave tile / 16) and the K chunking ---------
+// nt minimises the padded cout count (ties -> larger tile); kc minimises
+// nch * (3*kc/4 + 3) k-steps (3 steps ~ the per-chunk sync + staging bubble) under the
+// 80 KB LDS budget that keeps two workgroups per CU at the largest row tile.
+ConvPlan plan_static_f32(int cp_in, int c_out) {
+    ConvPlan p{};
+    const int n16 = round_up(c_out, 16) / 16;
+    int best_nt = 2, best_pad = 1 << 30;
+    for (int nt = 2; nt <= 8; ++nt) {
+        const int pad = round_up(n16, nt);
+        if (pad < best_pad || (pad == best_pad && nt > best_nt)) {
+            best_pad = pad;
+            best_nt = nt;
+        }
+    }
+    p.nt = best_nt;
+    p.n_pad = best_pad * 16;
+    p.mt = 4;
+    int best_kc = 4, best_nch = (cp_in + 3) / 4;
+    long best_cost = -1;
+    for (int kc = 4; kc <= 64; kc += 4) {
+        if (conv_f32_lds_bytes(4, p.nt, kc, 2) > 80 * 1024) break;
+        const int nch = (cp_in + kc - 1) / kc;
+        const long cost = (long)nch * (3 * kc / 4 + 3);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && kc > best_kc)) {
+            best_cost = cost;
+            best_kc = kc;
+            best_nch = nch;
+        }
+    }
+    p.kc = best_kc;
+    p.nch = best_nch;
+    return p;
+}
+
+// ---- run-time part: rows per workgroup (64 * mt) from the batch's row count ------------------
+int plan_mt(const ConvPlan& p, int64_t rows) {
+    int best = 4;
+    double best_cost = 1e300;
+    const int ntiles = p.n_pad / (16 * p.nt);
+    for (int mt : {4, 2, 1}) {
+        const int64_t nwg = (rows + 64 * mt - 1) / (64 * mt) * ntiles;
+        const int64_t rounds = (nwg + 511) / 512;                  // 256 CUs x 2 workgroups
+        const double cost = (double)rounds * mt * (1.0 + 0.03 * (4 / mt - 1));   // small tiles re-read weights
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = mt;
+        }
+    }
+    return best;
+}
+
+struct WsLayout {
+    size_t xnorm_off, bufa_off, bufb_off, total;
+    int P0;
+};
+
+WsLayout ws_layout(const rs_model* m, int B, int Lmax) {
+    WsLayout w{};
+    const int unit = 1 << m->n_layers;
+    w.P0 = round_up(Lmax + 1, unit);
+    size_t buf = 0;
+    for (int i = 0; i < m->n_layers; ++i) {
+        const size_t rows = (size_t)B * (w.P0 >> (i + 1));
+        buf = std::max(buf, rows * m->cp[i] * esize(m));
+    }
+    buf = align_up(buf + kAlign);
+    w.xnorm_off = 0;
+    w.bufa_off = align_up((size_t)B * w.P0 * sizeof(float));
+    w.bufb_off = w.bufa_off + buf;
+    w.total = w.bufb_off + buf;
+    return w;
+}
+
+template <class T>
+int upload(T** dptr, const std::vector<T>& h) {
+    RS_HIP(hipMalloc(reinterpret_cast<void**>(dptr), std::max<size_t>(h.size(), 1) * sizeof(T)));
+    RS_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rs_last_error(void) { return g_err; }
+
+int rs_version(void) { return (1 << 16) | 0; }
+
+int rs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const float* const* conv_w,
+                    const float* const* conv_b, const float* fc_w, const float* fc_b, int dtype, int device,
+                    rs_model** out) {
+    if (!out || !channels || !conv_w || !conv_b || !fc_w || !fc_b) {
+        set_error("rs_model_create: null argument");
+        return RS_ERR_ARG;
+    }
+    *out = nullptr;
+    if (n_layers < 2 || n_layers > kMaxLayers) {
+        set_error("rs_model_create: n_layers %d outside [2, %d]", n_layers, kMaxLayers);
+        return RS_ERR_ARG;
+    }
+    if (n_classes != 2) {
+        set_error("rs_model_create: n_classes must be 2 (got %d)", n_classes);
+        return RS_ERR_ARG;
+    }
+    if (dtype != RS_F32) {
+        set_error("rs_model_create: dtype %d not available in this build", dtype);
+        return RS_ERR_ARG;
+    }
+    for (int i = 0; i < n_layers; ++i)
+        if (channels[i] < 1 || !conv_w[i] || !conv_b[i]) {
+            set_error("rs_model_create: bad layer %d", i);
+            return RS_ERR_ARG;
+        }
+    RS_HIP(hipSetDevice(device));
+    rs_model* m = new (std::nothrow) rs_model();
+    if (!m) {
+        set_error("rs_model_create: out of host memory");
+        return RS_ERR_OOM;
+    }
+    m->device = device;
+    m->dtype = dtype;
+    m->n_layers = n_layers;
+    for (int i = 0; i < n_layers; ++i) {
+        m->channels[i] = channels[i];
+        m->cp[i] = round_up(channels[i], 4);
+    }
+    int rc = RS_OK;
+    {   // layer 0: (w0, w1, w2, bias) per output channel
+        std::vector<float> w4((size_t)m->cp[0] * 4, 0.0f);
+        for (int c = 0; c < channels[0]; ++c) {
+            w4[c * 4 + 0] = conv_w[0][c * 3 + 0];
+            w4[c * 4 + 1] = conv_w[0][c * 3 + 1];
+            w4[c * 4 + 2] = conv_w[0][c * 3 + 2];
+            w4[c * 4 + 3] = conv_b[0][c];
+        }
+        rc = upload(&m->d_w0, w4);
+    }
+    for (int i = 1; i < n_layers && rc == RS_OK; ++i) {
+        ConvLayerDev& L = m->layers[i];
+        L.c_in = channels[i - 1];
+        L.c_out = channels[i];
+        L.cp_in = m->cp[i - 1];
+        L.cp_out = m->cp[i];
+        L.plan = plan_static_f32(L.cp_in, L.c_out);
+        const ConvPlan& p = L.plan;
+        std::vector<float> wp((size_t)p.n_pad * p.nch * 3 * p.kc, 0.0f);
+        for (int n = 0; n < L.c_out; ++n)
+            for (int ci = 0; ci < L.c_in; ++ci) {
+                const int c = ci / p.kc, cc = ci - c * p.kc;
+                for (int kw = 0; kw < 3; ++kw)
+                    wp[(((size_t)n * p.nch + c) * 3 + kw) * p.kc + cc] = conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw];
+            }
+        std::vector<float> bp((size_t)p.n_pad, 0.0f);
+        for (int n = 0; n < L.c_out; ++n) bp[n] = conv_b[i][n];
+        float* dw = nullptr;
+        rc = upload(&dw, wp);
+        L.d_w = dw;
+        if (rc == RS_OK) rc = upload(&L.d_bias, bp);
+    }
+    if (rc == RS_OK) {
+        const int cl = channels[n_layers - 1];
+        rc = upload(&m->d_fcw, std::vector<float>(fc_w, fc_w + 2 * (size_t)cl));
+        if (rc == RS_OK) rc = upload(&m->d_fcb, std::vector<float>(fc_b, fc_b + 2));
+    }
+    if (rc != RS_OK) {
+        char keep[512];
+        strncpy(keep, g_err, sizeof(keep));
+        keep[sizeof(keep) - 1] = 0;
+        rs_model_destroy(m);
+        set_error("%s", keep);
+        return rc;
+    }
+    *out = m;
+    return RS_OK;
+}
+
+int rs_model_destroy(rs_model* m) {
+    if (!m) return RS_OK;
+    (void)hipSetDevice(m->device);
+    if (m->d_w0) (void)hipFree(m->d_w0);
+    for (int i = 1; i < m->n_layers; ++i) {
+        if (m->layers[i].d_w) (void)hipFree(m->layers[i].d_w);
+        if (m->layers[i].d_bias) (void)hipFree(m->layers[i].d_bias);
+    }
+    if (m->d_fcw) (void)hipFree(m->d_fcw);
+    if (m->d_fcb) (void)hipFree(m->d_fcb);
+    delete m;
+    return RS_OK;
+}
+
+int rs_padded_length(const rs_model* m, int Lmax) {
+    if (!m || Lmax < 1) return 0;
+    return round_up(Lmax + 1, 1 << m->n_layers);
+}
+
+size_t rs_workspace_bytes(const rs_model* m, int B, int Lmax) {
+    if (!m || B < 1 || Lmax < 1) return 0;
+    return ws_layout(m, B, Lmax).total;
+}
+
+int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax, float* d_out32,
+                 int64_t ld32, int32_t pad_to, double* d_out64, int64_t ld64, double* d_stats, void* stream) {
+    if (B < 0 || (B > 0 && (!d_sig || !d_off || !d_len))) {
+        set_error("rs_normalise: null argument");
+        return RS_ERR_ARG;
+    }
+    if (!d_out32 && !d_out64 && !d_stats) {
+        set_error("rs_normalise: no output requested");
+        return RS_ERR_ARG;
+    }
+    if ((d_out32 && (ld32 < Lmax || pad_to > ld32)) || (d_out64 && ld64 < Lmax)) {
+        set_error("rs_normalise: output pitch smaller than Lmax / pad_to");
+        return RS_ERR_ARG;
+    }
+    return launch_normalise(d_sig, d_off, d_len, B, Lmax, d_out32, ld32, pad_to, d_out64, ld64, d_stats,
+                            static_cast<hipStream_t>(stream));
+}
+
+int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmax, void* d_ws,
+               size_t ws_bytes, float* d_probs, float* d_logits, void* stream) {
+    if (!m || !d_x || !d_len || !d_ws || !d_probs || B < 1) {
+        set_error("rs_forward: null argument or empty batch");
+        return RS_ERR_ARG;
+    }
+    if (Lmax < (1 << m->n_layers)) {
+        set_error("rs_forward: Lmax %d shorter than the network minimum %d", Lmax, 1 << m->n_layers);
+        return RS_ERR_LENGTH;
+    }
+    if (ldx < Lmax) {
+        set_error("rs_forward: ldx %lld < Lmax %d", (long long)ldx, Lmax);
+        return RS_ERR_ARG;
+    }
+    const WsLayout w = ws_layout(m, B, Lmax);
+    if (ws_bytes < w.total) {
+        set_error("rs_forward: workspace %zu < required %zu", ws_bytes, w.total);
+        return RS_ERR_WORKSPACE;
+    }
+    if ((int64_t)B * w.P0 / 2 > 0x7fffffffLL) {
+        set_error("rs_forward: batch too large, split it (B * pitch = %lld)", (long long)B * w.P0);
+        return RS_ERR_ARG;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(d_ws);
+    void* buf[2] = {ws + w.bufa_off, ws + w.bufb_off};
+    const bool bf16 = m->dtype == RS_BF16;
+
+    int rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], bf16, st);
+    if (rc != RS_OK) return rc;
+    int cur = 0;
+    for (int i = 1; i < m->n_layers; ++i) {
+        ConvLayerDev& L = m->layers[i];
+        const int P_in = w.P0 >> i;
+        L.plan.mt = plan_mt(L.plan, (int64_t)B * P_in);
+        rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len, B,
+                             P_in, i, st, &m->last_bm[i], &m->last_bn[i]);
+        if (rc != RS_OK) return rc;
+        cur ^= 1;
+    }
+    return launch_head(buf[cur], bf16, m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
+                       w.P0 >> m->n_layers, m->n_layers, d_len, B, m->d_fcw, m->d_fcb, d_probs, d_logits, st);
+}
+
+int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
+                void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream) {
+    if (!m || !d_sig || !d_off || !d_len || !d_ws || !d_probs || B < 1) {
+        set_error("rs_classify: null argument or empty batch");
+        return RS_ERR_ARG;
+    }
+    if (Lmax < (1 << m->n_layers) || Lmax > kMaxNormLen) {
+        set_error("rs_classify: Lmax %d outside [%d, %d]", Lmax, 1 << m->n_layers, kMaxNormLen);
+        return RS_ERR_LENGTH;
+    }
+    const WsLayout w = ws_layout(m, B, Lmax);
+    if (ws_bytes < w.total) {
+        set_error("rs_classify: workspace %zu < required %zu", ws_bytes, w.total);
+        return RS_ERR_WORKSPACE;
+    }
+    float* xn = reinterpret_cast<float*>(static_cast<char*>(d_ws) + w.xnorm_off);
+    int rc = launch_normalise(d_sig, d_off, d_len, B, Lmax, xn, w.P0, w.P0, nullptr, 0, nullptr,
+                              static_cast<hipStream_t>(stream));
+    if (rc != RS_OK) return rc;
+    return rs_forward(m, xn, w.P0, d_len, B, Lmax, d_ws, ws_bytes, d_probs, d_logits, stream);
+}
+
+int rs_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len, float threshold,
+              int mode, uint8_t* d_out, void* stream) {
+    if (B < 0 || n_models < 1 || (B > 0 && (!d_probs || !d_len || !d_out)) ||
+        (mode != RS_ENRICH && mode != RS_DEPLETE)) {
+        set_error("rs_decide: bad argument");
+        return RS_ERR_ARG;
+    }
+    return launch_decide(d_probs, n_models, B, d_len, max_len, threshold, mode, d_out,
+                         static_cast<hipStream_t>(stream));
+}
+
+int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int32_t* d_end,
+                 void* stream) {
+    if (B < 0 || (B > 0 && (!d_sig || !d_off || !d_len || !d_end))) {
+        set_error("rs_polya_end: null argument");
+        return RS_ERR_ARG;
+    }
+    return launch_polya(d_sig, d_off, d_len, B, d_end, static_cast<hipStream_t>(stream));
+}
+
+int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out) {
+    if (!m || !out || layer < 0 || layer >= m->n_layers) {
+        set_error("rs_model_layer_info: bad argument");
+        return RS_ERR_ARG;
+    }
+    memset(out, 0, sizeof(*out));
+    out->c_out = m->channels[layer];
+    out->cp_out = m->cp[layer];
+    if (layer == 0) {
+        out->c_in = 1;
+        out->cp_in = 1;
+        out->k_pad = 3;
+        out->n_pad = m->cp[0];
+        return RS_OK;
+    }
+    const ConvLayerDev& L = m->layers[layer];
+    out->c_in = L.c_in;
+    out->cp_in = L.cp_in;
+    out->k_pad = 3 * L.plan.kc * L.plan.nch;
+    out->n_pad = L.plan.n_pad;
+    out->bm = m->last_bm[layer];
+    out->bn = m->last_bn[layer];
+    out->kc = L.plan.kc;
+    return RS_OK;
+}
+
+}  // extern "C"

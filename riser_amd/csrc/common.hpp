@@ -1,0 +1,63 @@
+// Shared host/device declarations for libriser_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/riser_amd.h"
+
+namespace rs {
+
+// thread-local error text behind rs_last_error()
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define RS_HIP(call)                                                   \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) return rs::hip_fail(e__, #call);        \
+    } while (0)
+
+constexpr int kMaxLayers = 16;
+constexpr int kMaxNormLen = 65536;
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- kernel launchers (each returns RS_OK or records an error) -------------------------
+int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
+                     float* d_out32, int64_t ld32, int32_t pad_to, double* d_out64, int64_t ld64,
+                     double* d_stats, hipStream_t st);
+
+// layer 0: x fp32 [B, ldx] -> y [B*P1, cp_out] (fp32 or bf16 rows), fused bias+ReLU+maxpool
+int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int P0,
+                 const float* d_w4 /* [cp_out][4] = w0,w1,w2,bias */, int cp_out,
+                 void* d_y, bool bf16_out, hipStream_t st);
+
+struct ConvPlan {
+    int mt, nt;       // wave tile = 16*mt rows x 16*nt couts; workgroup = 4 waves stacked along rows
+    int kc;           // channels per K chunk (multiple of 4 for f32, 32 for bf16)
+    int nch;          // number of chunks
+    int n_pad;        // padded couts covered by the grid (multiple of 16*nt)
+};
+
+struct ConvLayerDev {
+    int c_in, c_out, cp_in, cp_out;
+    ConvPlan plan;            // packing of d_w follows plan.kc / plan.nch / plan.n_pad
+    void* d_w;                // packed weights [n_pad][nch][3][kc] (f32 or bf16)
+    float* d_bias;            // [n_pad] fp32, zero padded
+};
+
+int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len,
+                    int B, int P_in, int layer_index, hipStream_t st, int* bm_out, int* bn_out);
+
+int launch_head(const void* d_y, bool bf16_in, int cp, int c, int P_last, int n_layers,
+                const int32_t* d_len, int B, const float* d_fcw, const float* d_fcb,
+                float* d_probs, float* d_logits, hipStream_t st);
+
+int launch_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len,
+                  float thr, int mode, uint8_t* d_out, hipStream_t st);
+
+int launch_polya(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B,
+                 int32_t* d_end, hipStream_t st);
+
+}  // namespace rs

@@ -1,0 +1,267 @@
+// K1: MAD normalisation + outlier smoothing, one 512-thread workgroup per read.
+//
+// Restates SignalProcessor.mad_normalise (riser/preprocess.py:108-147) so that the
+// float64 result is bit-identical to the reference's numpy path:
+//   * median and MAD are exact ORDER STATISTICS of integers (np.median on an even-length
+//     array is the mean of the two middle values), found with a range-adaptive LDS
+//     histogram select instead of a sort;
+//   * y = (x - med) / (1.4826 * mad) is evaluated in fp64 with IEEE division;
+//   * the outlier set {|y| > 3.5} is fixed before any update (:129) and rewritten in
+//     ascending order in place (:130-138): the head lane of each run of consecutive
+//     outliers walks its run sequentially (left neighbour = already smoothed value,
+//     right neighbour = original value), so any run length is handled exactly.
+// HBM-bound integer/byte work: the read is staged once into LDS (2 B/sample) and every
+// later pass (two selects, the threshold test, the division pass) runs out of LDS.
+#include "common.hpp"
+
+namespace rs {
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kBins = 4096;            // 8 bins per thread
+constexpr int kSubBins = 32;           // refinement pass: keys < 2^17 -> shift <= 5
+
+struct Scratch {
+    int wave_tot[kWaves];
+    int red_a[kWaves];
+    int red_b[kWaves];
+    int sel_bin[2];
+    int sel_rank[2];
+    int result[2];
+    unsigned sub[2][kSubBins];
+    int dthr;
+    int pad_;
+    double denom;
+};
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive prefix of v over the workgroup (thread order)
+__device__ __forceinline__ int block_excl_scan(int v, int* wave_tot, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    const int incl = wave_incl_scan(v, lane);
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += wave_tot[i];
+    __syncthreads();
+    return base + incl - v;
+}
+
+// Order statistics k_lo <= k_hi (0-based) of the n integer keys key(i) in [0, R].
+// One histogram pass over (key >> shift) with shift chosen so that at most kBins bins are
+// used; when shift > 0 (value range wider than 4096) a second pass resolves the low bits
+// inside the (at most two) selected bins.
+template <class KeyFn>
+__device__ void block_select2(KeyFn key, int n, int R, int k_lo, int k_hi, unsigned* hist, Scratch* sc,
+                              int tid, int& out_lo, int& out_hi) {
+    const int bits = 32 - __clz(R | 1);
+    const int shift = bits > 12 ? bits - 12 : 0;
+    for (int i = tid; i < kBins; i += kThreads) hist[i] = 0u;
+    if (tid < 2 * kSubBins) (&sc->sub[0][0])[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += kThreads) atomicAdd(&hist[key(i) >> shift], 1u);
+    __syncthreads();
+    int loc[8];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        loc[j] = (int)hist[tid * 8 + j];
+        s += loc[j];
+    }
+    const int excl = block_excl_scan(s, sc->wave_tot, tid);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const int k = which ? k_hi : k_lo;
+        if (excl <= k && k < excl + s) {
+            int c = excl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (k >= c && k < c + loc[j]) {
+                    sc->sel_bin[which] = tid * 8 + j;
+                    sc->sel_rank[which] = k - c;
+                }
+                c += loc[j];
+            }
+        }
+    }
+    __syncthreads();
+    const int bin_lo = sc->sel_bin[0], bin_hi = sc->sel_bin[1];
+    if (shift == 0) {
+        out_lo = bin_lo;
+        out_hi = bin_hi;
+        return;
+    }
+    const int mask = (1 << shift) - 1;
+    for (int i = tid; i < n; i += kThreads) {
+        const int kk = key(i);
+        const int hb = kk >> shift;
+        if (hb == bin_lo) atomicAdd(&sc->sub[0][kk & mask], 1u);
+        if (hb == bin_hi) atomicAdd(&sc->sub[1][kk & mask], 1u);
+    }
+    __syncthreads();
+    if (tid < 2) {
+        const int rank = sc->sel_rank[tid];
+        int c = 0, res = 0;
+        for (int j = 0; j <= mask; ++j) {
+            const int h = (int)sc->sub[tid][j];
+            if (rank >= c && rank < c + h) res = j;
+            c += h;
+        }
+        sc->result[tid] = ((tid ? bin_hi : bin_lo) << shift) | res;
+    }
+    __syncthreads();
+    out_lo = sc->result[0];
+    out_hi = sc->result[1];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void normalise_kernel(
+    const int16_t* __restrict__ sig, const int64_t* __restrict__ off, const int32_t* __restrict__ len,
+    float* __restrict__ out32, int64_t ld32, int32_t pad_to, double* __restrict__ out64, int64_t ld64,
+    double* __restrict__ stats, int lmax) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* hist = reinterpret_cast<unsigned*>(smem);
+    Scratch* sc = reinterpret_cast<Scratch*>(smem + kBins * 4);
+    int16_t* sx = reinterpret_cast<int16_t*>(smem + kBins * 4 + 512);
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int n = min(len[b], lmax);                  // len > Lmax violates the contract; never overrun LDS
+    const int16_t* src = sig + off[b];
+    float* o32 = out32 ? out32 + (int64_t)b * ld32 : nullptr;
+    double* o64 = out64 ? out64 + (int64_t)b * ld64 : nullptr;
+
+    // ---- stage the read into LDS, min / max on the way ------------------------------------
+    int mn = 32767, mx = -32768;
+    for (int i = tid; i < n; i += kThreads) {
+        const int v = src[i];
+        sx[i] = (int16_t)v;
+        mn = min(mn, v);
+        mx = max(mx, v);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mn = min(mn, __shfl_xor(mn, d, 64));
+        mx = max(mx, __shfl_xor(mx, d, 64));
+    }
+    if (lane == 0) {
+        sc->red_a[w] = mn;
+        sc->red_b[w] = mx;
+    }
+    __syncthreads();
+    mn = sc->red_a[0];
+    mx = sc->red_b[0];
+#pragma unroll
+    for (int i = 1; i < kWaves; ++i) {
+        mn = min(mn, sc->red_a[i]);
+        mx = max(mx, sc->red_b[i]);
+    }
+    __syncthreads();
+
+    // ---- median: the two middle order statistics -------------------------------------------
+    const int k_lo = (n - 1) >> 1, k_hi = n >> 1;
+    int m_lo, m_hi;
+    block_select2([&](int i) { return (int)sx[i] - mn; }, n, mx - mn, k_lo, k_hi, hist, sc, tid, m_lo, m_hi);
+    const int sum2 = m_lo + m_hi + 2 * mn;                       // 2 * median, exact
+
+    // ---- MAD: middle order statistics of |2x - 2 med| (integers < 2^17) --------------------
+    const int rd = max(abs(2 * mn - sum2), abs(2 * mx - sum2));
+    int d_lo, d_hi;
+    block_select2([&](int i) { return abs(2 * (int)sx[i] - sum2); }, n, rd, k_lo, k_hi, hist, sc, tid, d_lo, d_hi);
+    const int mad4 = d_lo + d_hi;                                // 4 * mad, exact
+
+    if (stats && tid == 0) {
+        stats[2 * b + 0] = (double)sum2 * 0.5;
+        stats[2 * b + 1] = (double)mad4 * 0.25;
+    }
+
+    if (mad4 == 0) {                                             // riser/preprocess.py:123-124
+        for (int i = tid; i < n; i += kThreads) {
+            if (o32) o32[i] = 0.0f;
+            if (o64) o64[i] = 0.0;
+        }
+    } else {
+        // smallest integer deviation d (in half counts) with fp64((d/2)/denom) > 3.5: the
+        // outlier predicate of :129 becomes an integer compare (IEEE division by a positive
+        // constant is monotonic and sign-symmetric).
+        if (tid == 0) {
+            const double denom = 1.4826 * ((double)mad4 * 0.25);
+            long long d = (long long)floor(7.0 * denom);
+            if (d < 0) d = 0;
+            while (d > 0 && ((double)(d - 1) * 0.5) / denom > 3.5) --d;
+            while (!(((double)d * 0.5) / denom > 3.5)) ++d;
+            sc->denom = denom;
+            sc->dthr = (int)(d > 0x7fffffffLL ? 0x7fffffffLL : d);
+        }
+        __syncthreads();
+        const double denom = sc->denom;
+        const int dthr = sc->dthr;
+        auto dev2 = [&](int j) { return 2 * (int)sx[j] - sum2; };
+        auto yv = [&](int j) { return ((double)dev2(j) * 0.5) / denom; };
+        auto put = [&](int j, double v) {
+            if (o32) o32[j] = (float)v;
+            if (o64) o64[j] = v;
+        };
+        for (int i = tid; i < n; i += kThreads) {
+            const int t = dev2(i);
+            if (abs(t) < dthr) {
+                put(i, ((double)t * 0.5) / denom);
+                continue;
+            }
+            if (i > 0 && abs(dev2(i - 1)) >= dthr) continue;     // inside a run: its head writes it
+            double prev = i > 0 ? yv(i - 1) : 0.0;
+            int j = i;
+            do {
+                double nv;
+                if (j == 0) {
+                    nv = yv(1);                                  // :132 (not clipped)
+                } else if (j == n - 1) {
+                    nv = prev;                                   // :134 (not clipped)
+                } else {
+                    nv = (prev + yv(j + 1)) * 0.5;               // :136
+                    nv = nv > 3.5 ? 3.5 : (nv < -3.5 ? -3.5 : nv);   // :141-147
+                }
+                put(j, nv);
+                prev = nv;
+                ++j;
+            } while (j < n && abs(dev2(j)) >= dthr);
+        }
+    }
+    if (o32)
+        for (int i = n + tid; i < pad_to; i += kThreads) o32[i] = 0.0f;
+}
+
+}  // namespace
+
+int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
+                     float* d_out32, int64_t ld32, int32_t pad_to, double* d_out64, int64_t ld64,
+                     double* d_stats, hipStream_t st) {
+    if (B <= 0) return RS_OK;
+    if (Lmax < 1 || Lmax > kMaxNormLen) {
+        set_error("rs_normalise: read length %d outside [1, %d]", Lmax, kMaxNormLen);
+        return RS_ERR_LENGTH;
+    }
+    const size_t lds = (size_t)kBins * 4 + 512 + (size_t)round_up(Lmax, 8) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(normalise_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(normalise_kernel, dim3(B), dim3(kThreads), lds, st, d_sig, d_off, d_len, d_out32, ld32,
+                       pad_to, d_out64, ld64, d_stats, Lmax);
+    RS_HIP(hipGetLastError());
+    return RS_OK;
+}
+
+}  // namespace rs

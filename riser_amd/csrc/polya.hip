@@ -1,0 +1,107 @@
+// poly(A) end detector (riser/preprocess.py:42-79) for a batch of raw reads.
+// One 256-thread workgroup per read.  Each wave takes every 4th 500-sample window, sorts
+// it (bitonic, 512 int keys in LDS, padded with +inf) to get the exact median, sorts the
+// integer deviations |2x - 2med| to get the exact MAD, and records the window sum; one
+// lane then replays the reference's sequential start/end rule over the window table in
+// fp64 with the reference's operation order.
+#include "common.hpp"
+
+namespace rs {
+namespace {
+
+constexpr int kWin = 500;                          // _TRIM_RESOLUTION
+constexpr int kMaxWin = kMaxNormLen / kWin + 1;
+constexpr int kPad = 0x7fffffff;
+
+__device__ __forceinline__ void bitonic512(int* keys, int lane) {
+    for (int k = 2; k <= 512; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = lane + 64 * u;
+                const int i = 2 * p - (p & (j - 1));
+                const int q = i + j;
+                const int a = keys[i], b = keys[q];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    keys[i] = b;
+                    keys[q] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void polya_kernel(const int16_t* __restrict__ sig, const int64_t* __restrict__ off,
+                                                    const int32_t* __restrict__ len, int32_t* __restrict__ out) {
+    __shared__ int keys[4][512];
+    __shared__ int wsum[kMaxWin];
+    __shared__ int wmad4[kMaxWin];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(len[b], kMaxNormLen);
+    const int16_t* src = sig + off[b];
+    const int nw = n / kWin;
+    int* K = keys[wave];
+    for (int w0 = 0; w0 < nw; w0 += 4) {
+        const int w = w0 + wave;
+        const bool act = w < nw;
+        int s = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = lane + 64 * u;
+            int v = kPad;
+            if (act && i < kWin) {
+                v = src[w * kWin + i];
+                s += v;
+            }
+            K[i] = v;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        __syncthreads();
+        bitonic512(K, lane);
+        const int sum2 = K[kWin / 2 - 1] + K[kWin / 2];            // 2 * median
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = lane + 64 * u;
+            const int v = K[i];
+            K[i] = (v == kPad) ? kPad : abs(2 * v - sum2);
+        }
+        __syncthreads();
+        bitonic512(K, lane);
+        if (act && lane == 0) {
+            wsum[w] = s;
+            wmad4[w] = K[kWin / 2 - 1] + K[kWin / 2];              // 4 * MAD
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int start = -1, end = -1;
+        for (int w = 0; w < nw; ++w) {
+            const int i = w * kWin;
+            const double mad = (double)wmad4[w] * 0.25;
+            const double mean = (double)wsum[w] / 500.0;
+            double rolling = mean;
+            if (i > 2 * kWin) rolling = (double)(wsum[w - 2] + wsum[w - 1]) / 1000.0;
+            const double change = (mean - rolling) / rolling * 100.0;
+            // `not polyA_start` is also true for index 0 (riser/preprocess.py:62)
+            if (start <= 0 && change > 20.0 && mad <= 20.0) start = i;
+            if (start > 0 && end <= 0 && mad > 20.0) end = i;
+        }
+        out[b] = end > 0 ? end : -1;
+    }
+}
+
+}  // namespace
+
+int launch_polya(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int32_t* d_end,
+                 hipStream_t st) {
+    if (B <= 0) return RS_OK;
+    hipLaunchKernelGGL(polya_kernel, dim3(B), dim3(256), 0, st, d_sig, d_off, d_len, d_end);
+    RS_HIP(hipGetLastError());
+    return RS_OK;
+}
+
+}  // namespace rs

@@ -1,0 +1,192 @@
+"""Model: drop-in for riser/model.py:6-32 on MI355X, plus the batched entry points.
+
+`Model(state, config, logger, target)` and `classify(signal) -> Tensor[2]` keep the
+reference's signature and meaning (probabilities in the order (p_off_target, p_on_target),
+riser/control.py:69).  The forward pass itself is the HIP library (riser_amd/csrc) reached
+through the C ABI; torch is used only for device memory and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nv
+
+_DTYPES = {"f32": nv.RS_F32, "fp32": nv.RS_F32, "float32": nv.RS_F32,
+           "bf16": nv.RS_BF16, "bfloat16": nv.RS_BF16}
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Workspace:
+    """Grow-only device scratch owned by the caller side of the ABI."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes: int) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = None
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+class Model:
+    def __init__(self, state, config, logger, target, dtype: str = "f32", device=None):
+        self.target = target
+        self.logger = logger
+        self.device = self._get_device(device)
+        if logger is not None:
+            logger.info('Using %s device', self.device)
+        cnn = config.cnn
+        if getattr(cnn, "classifier", "gap_fc") != "gap_fc" or int(getattr(cnn, "depth", 1)) != 1 \
+                or any(int(k) != 3 for k in cnn.kernels):
+            raise ValueError("riser_amd supports the shipped ConvNet configuration only: "
+                             "depth 1, kernel 3, classifier gap_fc (riser/model/*.yaml)")
+        if isinstance(state, dict):
+            sd = state
+        else:
+            sd = torch.load(state, map_location="cpu")              # riser/model.py:19
+        sd = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
+        self.channels = [int(c) for c in cnn.channels][: int(cnn.n_layers)]
+        self.n_layers = len(self.channels)
+        self.min_length = 1 << self.n_layers
+        self.dtype = dtype
+        self._keep = []
+        conv_w, conv_b = [], []
+        c_in = 1
+        for i, c_out in enumerate(self.channels):
+            w = np.ascontiguousarray(sd[f"layers.{i}.0.weight"], dtype=np.float32)
+            b = np.ascontiguousarray(sd[f"layers.{i}.0.bias"], dtype=np.float32)
+            if w.shape != (c_out, c_in, 3) or b.shape != (c_out,):
+                raise ValueError(f"layers.{i}.0: state dict shape {w.shape} does not match config")
+            conv_w.append(w)
+            conv_b.append(b)
+            c_in = c_out
+        fc_w = np.ascontiguousarray(sd["classifier.2.weight"], dtype=np.float32)
+        fc_b = np.ascontiguousarray(sd["classifier.2.bias"], dtype=np.float32)
+        if fc_w.shape != (int(cnn.n_classes), c_in):
+            raise ValueError("classifier.2.weight shape does not match config")
+        L = nv.lib()
+        wp = (C.c_void_p * self.n_layers)(*[w.ctypes.data for w in conv_w])
+        bp = (C.c_void_p * self.n_layers)(*[b.ctypes.data for b in conv_b])
+        ch = (C.c_int32 * self.n_layers)(*self.channels)
+        h = C.c_void_p()
+        nv.check(L.rs_model_create(self.n_layers, ch, int(cnn.n_classes), wp, bp, fc_w.ctypes.data,
+                                   fc_b.ctypes.data, _DTYPES[dtype], self.device.index, C.byref(h)),
+                 "rs_model_create")
+        self._h = h
+        self._ws = Workspace(self.device)
+        self.model = self            # the reference exposes the nn.Module here; kept as an alias
+
+    # ------------------------------------------------------------------------------------
+    def _get_device(self, device=None):
+        nv.require_gpu()
+        if not torch.cuda.is_available():
+            raise nv.NativeError("torch sees no ROCm device")
+        if device is None:
+            return torch.device("cuda", torch.cuda.current_device())
+        d = torch.device(device)
+        return torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            nv.lib().rs_model_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def padded_length(self, lmax: int) -> int:
+        return nv.lib().rs_padded_length(self._h, int(lmax))
+
+    def layer_info(self):
+        out = []
+        for i in range(self.n_layers):
+            li = nv.LayerInfo()
+            nv.check(nv.lib().rs_model_layer_info(self._h, i, C.byref(li)), "rs_model_layer_info")
+            out.append({n: getattr(li, n) for n, _ in nv.LayerInfo._fields_})
+        return out
+
+    def _check_lengths(self, lens_host: np.ndarray):
+        if lens_host.size == 0:
+            raise ValueError("empty batch")
+        if int(lens_host.min()) < self.min_length:
+            # torch raises "max_pool1d() Invalid computed output size: 0" in the reference
+            raise ValueError(f"signal of {int(lens_host.min())} samples is shorter than the network "
+                             f"minimum {self.min_length}")
+
+    # ------------------------------------------------------------------------------------
+    def classify(self, signal):
+        """riser/model.py:22-28: normalised signal [L] -> fp32 Tensor[2] on the device."""
+        x = torch.from_numpy(np.ascontiguousarray(signal)).unsqueeze(0)
+        x = x.to(self.device, dtype=torch.float)
+        lens = np.array([x.shape[1]], dtype=np.int32)
+        return self.forward_batch(x, lens)[0]
+
+    def classify_batch(self, signals, lengths=None, return_logits: bool = False):
+        """Batched classify of already-normalised signals.
+        signals: list of 1-D arrays (any float dtype / the int64 zeros of mad == 0), or a
+        2-D array / tensor [B, Lmax] with `lengths`.  Returns fp32 [B, 2] on the device."""
+        if isinstance(signals, (list, tuple)):
+            lens = np.array([len(s) for s in signals], dtype=np.int32)
+            self._check_lengths(lens)
+            host = np.zeros((len(signals), int(lens.max())), dtype=np.float32)
+            for i, s in enumerate(signals):
+                host[i, : lens[i]] = np.asarray(s, dtype=np.float32)
+            x = torch.from_numpy(host).to(self.device)
+        else:
+            x = torch.as_tensor(signals).to(self.device, dtype=torch.float)
+            if x.dim() != 2:
+                raise ValueError("signals must be [B, L]")
+            lens = (np.full(x.shape[0], x.shape[1], dtype=np.int32) if lengths is None
+                    else np.asarray(lengths, dtype=np.int32))
+        return self.forward_batch(x, lens, return_logits=return_logits)
+
+    def forward_batch(self, x: torch.Tensor, lens_host: np.ndarray, lens_dev: torch.Tensor = None,
+                      return_logits: bool = False, out: torch.Tensor = None):
+        """x: fp32 device tensor [B, ldx] (row b valid for lens[b] samples)."""
+        self._check_lengths(lens_host)
+        B, ldx = x.shape
+        if not x.is_contiguous() or x.dtype != torch.float32 or x.device != self.device:
+            raise ValueError("x must be a contiguous fp32 tensor on the model's device")
+        lmax = int(lens_host.max())
+        if lmax > ldx:
+            raise ValueError("a length exceeds the row pitch")
+        if lens_dev is None:
+            lens_dev = torch.from_numpy(np.ascontiguousarray(lens_host, dtype=np.int32)).to(self.device)
+        L = nv.lib()
+        need = L.rs_workspace_bytes(self._h, B, lmax)
+        ws = self._ws.get(need)
+        probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
+        logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
+        nv.check(L.rs_forward(self._h, x.data_ptr(), ldx, lens_dev.data_ptr(), B, lmax, ws.data_ptr(),
+                              ws.numel(), probs.data_ptr(), logits.data_ptr() if return_logits else None,
+                              _stream_ptr(self.device)), "rs_forward")
+        return (probs, logits) if return_logits else probs
+
+    def classify_raw(self, sig_dev: torch.Tensor, off_dev: torch.Tensor, len_dev: torch.Tensor,
+                     lens_host: np.ndarray, out: torch.Tensor = None, return_logits: bool = False):
+        """Fused normalise + forward on raw int16 reads already resident on the device:
+        read b = sig_dev[off[b] : off[b] + len[b]].  Returns fp32 [B, 2] on the device."""
+        self._check_lengths(lens_host)
+        B = int(lens_host.shape[0])
+        lmax = int(lens_host.max())
+        L = nv.lib()
+        need = L.rs_workspace_bytes(self._h, B, lmax)
+        ws = self._ws.get(need)
+        probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
+        logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
+        nv.check(L.rs_classify(self._h, sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), B, lmax,
+                               ws.data_ptr(), ws.numel(), probs.data_ptr(),
+                               logits.data_ptr() if return_logits else None, _stream_ptr(self.device)),
+                 "rs_classify")
+        return (probs, logits) if return_logits else probs

@@ -1,0 +1,168 @@
+"""Kit / SignalProcessor: drop-in for riser/preprocess.py:15-147 with the arithmetic on the GPU.
+
+Same constructor, same nine methods, same argument meaning and error behaviour
+(`mad_normalise` raises ValueError on an empty signal, riser/preprocess.py:109-110).
+The median / MAD selection, the normalisation, the outlier smoothing and the poly(A)
+window scan run in HIP kernels (riser_amd/csrc/normalise.hip, polya.hip) through the C
+ABI; results are bit-identical to the reference's float64 numpy path.  Batched variants
+(`mad_normalise_batch`, `get_polyA_end_batch`) are what the batched control loop uses.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _native as nv
+
+_OUTLIER_LIMIT = 3.5
+_SCALING_FACTOR = 1.4826
+_MIN_INPUT_SIGNALS = 4096        # constrained by the 12 max-pools of the CNN (riser/preprocess.py:8)
+_MAX_INPUT_NT = 280
+_TRIM_RESOLUTION = 500
+_TRIM_MAD_THRESHOLD = 20
+_TRIM_FIXED_LENGTH_NT = 150.6
+MAX_SIGNAL = 65536               # LDS staging limit of the normalise kernel
+
+
+class Kit():
+    def __init__(self, sampling_hz, transloc_rate):
+        self.sampling_hz = sampling_hz
+        self.transloc_rate = transloc_rate
+
+    @classmethod
+    def create_from_version(cls, version):
+        if version == "RNA002":
+            return cls(3012, 70)
+        elif version == "RNA004":
+            return cls(4000, 130)
+        else:
+            raise Exception(f"Invalid kit version {version}")
+
+
+def _as_int16(signal) -> np.ndarray:
+    a = np.asarray(signal)
+    if a.dtype == np.int16:
+        return np.ascontiguousarray(a)
+    if np.issubdtype(a.dtype, np.integer):
+        if a.size and (a.min() < -32768 or a.max() > 32767):
+            raise TypeError("raw signal does not fit int16 ADC counts")
+        return np.ascontiguousarray(a.astype(np.int16))
+    raise TypeError("riser_amd normalises raw int16 ADC signals (riser/client.py:47); "
+                    f"got dtype {a.dtype}")
+
+
+def pack_reads(signals, device):
+    """Concatenate int16 reads into one device buffer -> (sig, off, len tensors, lens_host)."""
+    sigs = [_as_int16(s) for s in signals]
+    lens = np.array([s.shape[0] for s in sigs], dtype=np.int32)
+    offs = np.zeros(len(sigs), dtype=np.int64)
+    if len(sigs) > 1:
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+    flat = np.concatenate(sigs) if sigs else np.zeros(0, dtype=np.int16)
+    if flat.size == 0:
+        flat = np.zeros(1, dtype=np.int16)
+    return (torch.from_numpy(flat).to(device), torch.from_numpy(offs).to(device),
+            torch.from_numpy(lens).to(device), lens)
+
+
+class SignalProcessor():
+    def __init__(self, kit, device=None):
+        self.kit = kit
+        nv.require_gpu()
+        if not torch.cuda.is_available():
+            raise nv.NativeError("torch sees no ROCm device")
+        d = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+
+    # ---- constants (riser/preprocess.py:33-40,81-85) --------------------------------------
+    def get_min_length(self):
+        return _MIN_INPUT_SIGNALS
+
+    def get_max_length(self):
+        return int(_MAX_INPUT_NT / self.kit.transloc_rate * self.kit.sampling_hz)
+
+    def is_max_length(self, signal):
+        return len(signal) >= self.get_max_length()
+
+    def get_fixed_trim_length(self):
+        return int(_TRIM_FIXED_LENGTH_NT / self.kit.transloc_rate * self.kit.sampling_hz)
+
+    def should_trim_fixed_length(self, signal):
+        return len(signal) > self.get_fixed_trim_length() + self.get_max_length()
+
+    def trim_polyA_fixed_length(self, signal):
+        trim = self.get_fixed_trim_length()
+        return signal[trim:]
+
+    # ---- poly(A) (riser/preprocess.py:42-79,87-102) ---------------------------------------
+    def get_polyA_end(self, signal):
+        end = self.get_polyA_end_batch([signal])[0]
+        return None if end < 0 else int(end)
+
+    def get_polyA_end_batch(self, signals) -> np.ndarray:
+        """int32 [B]: end index or -1 where the reference returns None."""
+        if len(signals) == 0:
+            return np.zeros(0, dtype=np.int32)
+        sig, off, ln, lens = pack_reads(signals, self.device)
+        if int(lens.max()) > MAX_SIGNAL:
+            raise ValueError(f"raw read longer than {MAX_SIGNAL} samples")
+        return self.polyA_end_device(sig, off, ln, len(signals)).cpu().numpy()
+
+    def polyA_end_device(self, sig, off, ln, B) -> torch.Tensor:
+        out = torch.empty(B, dtype=torch.int32, device=self.device)
+        nv.check(nv.lib().rs_polya_end(sig.data_ptr(), off.data_ptr(), ln.data_ptr(), B, out.data_ptr(),
+                                       torch.cuda.current_stream(self.device).cuda_stream), "rs_polya_end")
+        return out
+
+    def trim_polyA(self, signal, read_id, cache):
+        """If the polyA end can be found, trim polyA + sequencing adapter from the start of
+        the signal (riser/preprocess.py:87-102; found ends are cached per read id)."""
+        trimmed = False
+        if read_id in cache:
+            polyA_end = cache[read_id]
+        else:
+            polyA_end = self.get_polyA_end(signal)
+            if polyA_end:
+                cache[read_id] = polyA_end
+        if polyA_end:
+            signal = signal[polyA_end+1:]
+            trimmed = True
+        return signal, trimmed
+
+    # ---- normalisation (riser/preprocess.py:108-147) --------------------------------------
+    def mad_normalise(self, signal):
+        if np.asarray(signal).shape[0] == 0:
+            raise ValueError("Signal must not be empty")
+        out, stats = self.mad_normalise_batch([signal], return_stats=True)
+        if stats[0, 1] == 0:
+            # np.vectorize over Python ints yields an int64 zero array (riser/preprocess.py:122-125)
+            return np.zeros(out[0].shape[0], dtype=np.int64)
+        return out[0]
+
+    def mad_normalise_batch(self, signals, return_stats: bool = False):
+        """List of raw int16 reads -> list of float64 arrays (bit-exact with the reference),
+        optionally with the [B, 2] (median, mad) table."""
+        if any(np.asarray(s).shape[0] == 0 for s in signals):
+            raise ValueError("Signal must not be empty")
+        sig, off, ln, lens = pack_reads(signals, self.device)
+        B, lmax = len(signals), int(lens.max())
+        if lmax > MAX_SIGNAL:
+            raise ValueError(f"signal longer than {MAX_SIGNAL} samples")
+        out64 = torch.empty((B, lmax), dtype=torch.float64, device=self.device)
+        stats = torch.empty((B, 2), dtype=torch.float64, device=self.device)
+        nv.check(nv.lib().rs_normalise(sig.data_ptr(), off.data_ptr(), ln.data_ptr(), B, lmax, None, 0, 0,
+                                       out64.data_ptr(), lmax, stats.data_ptr(),
+                                       torch.cuda.current_stream(self.device).cuda_stream), "rs_normalise")
+        host = out64.cpu().numpy()
+        res = [host[i, : lens[i]].copy() for i in range(B)]
+        return (res, stats.cpu().numpy()) if return_stats else res
+
+    def normalise_device(self, sig, off, ln, B, lmax, pad_to=None) -> torch.Tensor:
+        """Raw reads already on the device -> fp32 [B, pad_to] normalised signals (zero
+        padded), i.e. what Model.classify would receive after its fp32 cast."""
+        pad_to = int(pad_to or lmax)
+        out = torch.empty((B, pad_to), dtype=torch.float32, device=self.device)
+        nv.check(nv.lib().rs_normalise(sig.data_ptr(), off.data_ptr(), ln.data_ptr(), B, int(lmax),
+                                       out.data_ptr(), pad_to, pad_to, None, 0, None,
+                                       torch.cuda.current_stream(self.device).cuda_stream), "rs_normalise")
+        return out
