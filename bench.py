@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py - chunks/s of the squiggle-classification hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32]
+
+One "step" = one pass of the hot path over one batch of 512 synthetic RNA004 4 s chunks
+(512 x 16000 int16 samples, BASELINE.json configs[1]) already resident in HBM:
+MAD-normalise + 12-layer ConvNet forward + softmax, through the C ABI.  With N > 1 (launched
+by torch.distributed.run, one rank per GPU) every rank steps its own 512-read shard - reads
+are independent, there is no data-path collective - and the printed value is the whole-job
+aggregate over the max-over-ranks time ("scaling": "weak").
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline      conv stack (layers 1..11, the MFMA kernel family) achieved TFLOP/s from HIP
+                events recorded on the launch stream during the timed steps
+  cpu_baseline  the oracle's torch-CPU port (reference structure: one read at a time) timed
+                on this box's host cores over a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from riser_amd import dist as rdist          # noqa: E402
+from riser_amd import synth                  # noqa: E402
+
+BATCH = 512
+CHUNK = 16000
+SIG_SEED = 20260103
+PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md:42
+PEAK_BF16_MFMA_TF = 2500.0    # :43
+PEAK_HBM_GBS = 8000.0         # :36
+
+
+def conv_flops_per_chunk(channels, L0):
+    """Un-padded algorithmic FLOPs per chunk of each conv layer."""
+    out = []
+    c_in, L = 1, L0
+    for c in channels:
+        out.append(2.0 * c_in * c * 3 * L)
+        c_in, L = c, L // 2
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--chunk", type=int, default=CHUNK)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank, local_rank, world = rdist.env_world()
+    if world != max(args.gpus, 1) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    device = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(device)
+    rdist.init(device=device)
+
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+
+    B, L = args.batch, args.chunk
+    model = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=args.dtype, device=device)
+    # each rank owns a different shard of the synthetic read population
+    sigs = synth.make_signals(SIG_SEED, B, L, first_read=rank * B)
+    sig, off, ln, lens = pack_reads(list(sigs), device)
+    probs = torch.empty((B, 2), dtype=torch.float32, device=device)
+
+    def step():
+        model.classify_raw(sig, off, ln, lens, out=probs)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+
+    # ---- timed region: exactly K steps, barrier + sync on both sides ---------------------------
+    model.profile(True)
+    rdist.barrier(device)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    rdist.barrier(device)
+    elapsed = time.perf_counter() - t0
+    stage_ms, calls = model.profile_read()
+    model.profile(False)
+    elapsed = rdist.reduce_scalar(elapsed, "max", device)
+    total_chunks = rdist.reduce_scalar(B * args.steps, "sum", device)
+
+    # ---- per-batch latency incl. H2D of the int16 batch and D2H of the probabilities -----------
+    host_sig = torch.from_numpy(np.ascontiguousarray(sigs.reshape(-1))).pin_memory()
+    host_probs = torch.empty((B, 2), dtype=torch.float32).pin_memory()
+    lat = []
+    n_lat = max(30, min(200, args.steps * 5))
+    for i in range(n_lat + 5):
+        t1 = time.perf_counter()
+        sig.copy_(host_sig, non_blocking=True)
+        step()
+        host_probs.copy_(probs, non_blocking=True)
+        torch.cuda.synchronize(device)
+        if i >= 5:
+            lat.append(time.perf_counter() - t1)
+    lat_ms = np.asarray(lat) * 1e3
+    p50, p99 = float(np.percentile(lat_ms, 50)), float(np.percentile(lat_ms, 99))
+    p99 = rdist.reduce_scalar(p99, "max", device)
+
+    if rank != 0:
+        rdist.finalize()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_chunks / elapsed
+
+    # ---- roofline of the conv stack (the MFMA kernel family, layers 1..n-1) --------------------
+    flops = conv_flops_per_chunk(model.channels, L)
+    conv_ms = float(stage_ms[2:2 + model.n_layers - 1].sum()) / max(calls, 1)      # per step, all conv launches
+    conv_flop = sum(flops[1:]) * B
+    achieved_tf = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    peak = PEAK_F32_MFMA_TF if args.dtype == "f32" else PEAK_BF16_MFMA_TF
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            with open(pmc_path) as f:
+                traffic = json.load(f).get(args.dtype, {}).get("conv_stack_hbm_bytes_per_step")
+        except Exception:
+            traffic = None
+    info = model.layer_info()
+    per_layer = []
+    for i in range(1, model.n_layers):
+        ms = float(stage_ms[1 + i]) / max(calls, 1)
+        per_layer.append({"layer": i, "ms": round(ms, 4),
+                          "tflops": round(flops[i] * B / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+                          "tile": [info[i]["bm"], info[i]["bn"], info[i]["kc"]]})
+    roofline = {"bound": "mfma", "kernel": "conv_%s_kernel (11 launches/step, layers 1-11)" % args.dtype,
+                "achieved": round(achieved_tf, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved_tf / peak, 4), "traffic": traffic,
+                "avg_launch_ms": round(conv_ms / (model.n_layers - 1), 4),
+                "stage_ms": {"normalise": round(float(stage_ms[0]) / max(calls, 1), 4),
+                             "conv0": round(float(stage_ms[1]) / max(calls, 1), 4),
+                             "conv1_11": round(conv_ms, 4),
+                             "head": round(float(stage_ms[model.n_layers + 1]) / max(calls, 1), 4)},
+                "layers": per_layer}
+
+    out = {
+        "metric": "signal chunks classified/sec (RNA004 4 s chunks, batch=512)",
+        "value": round(value, 1), "unit": "chunks/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"mRNA RNA004 model, batch={B} x {L}-sample (4 s) int16 chunks resident in HBM, "
+                               f"MAD-normalise + 12-layer ConvNet forward + softmax, {args.dtype}",
+                   "batch_per_gpu": B, "chunk_samples": L, "sharding": "reads by id across GPUs, no collectives"},
+        "p50_batch_latency_ms": round(p50, 3), "p99_batch_latency_ms": round(p99, 3),
+        "latency_note": "host wall time per 512-read batch incl. H2D of int16 signals from pinned memory and D2H of probabilities",
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline (rank 0, N = 1 only): oracle port timed on this box's host cores ---------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_path
+        cpu_model = torch_path.TorchCpuModel(synth.make_state_dict(1))
+        torch_path.classify_per_read(cpu_model, sigs[:2])                    # warm-up
+        n_done, t1 = 0, time.perf_counter()
+        while n_done < B and time.perf_counter() - t1 < args.cpu_seconds:
+            torch_path.classify_per_read(cpu_model, sigs[n_done:n_done + 8])
+            n_done += 8
+        dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(n_done / dt, 2), "unit": "chunks/s",
+                               "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"first {n_done} of the step's {B} chunks ({L} samples each), one read at a "
+                                         f"time: numpy MAD-normalise + torch-CPU conv stack at batch 1 "
+                                         f"(structure of riser/control.py:63-69), {dt:.1f} s; host has {os.cpu_count()} logical CPUs"}
+    print(json.dumps(out), flush=True)
+    rdist.finalize()
+
+
+if __name__ == "__main__":
+    main()

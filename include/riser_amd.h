@@ -169,6 +169,19 @@ typedef struct rs_layer_info {
 } rs_layer_info;
 int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out);
 
+/*
+ * Stage timing with HIP events on the launch stream (used by bench.py's roofline leg).
+ * While enabled, rs_forward / rs_classify record one event before their first launch and
+ * one after every kernel launch, on the caller's stream; no synchronisation is added.
+ * rs_profile_read synchronises on the last recorded event and ADDS the elapsed
+ * milliseconds per stage into stage_ms[0 .. n_layers + 1]:
+ *   stage 0 = normalise, stage 1 = layer-0 conv, stage 1 + i = conv layer i (i >= 1),
+ *   stage n_layers + 1 = GAP/FC/softmax head;
+ * *calls receives the number of profiled forward calls.  Recorded events are consumed.
+ */
+int rs_profile_enable(rs_model* m, int on);
+int rs_profile_read(rs_model* m, float* stage_ms, int32_t* calls);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ DECISION_NAMES = ("try_again", "accept", "reject", "no_decision")
 SYMBOLS = (
     "rs_last_error", "rs_version", "rs_device_count", "rs_model_create", "rs_model_destroy",
     "rs_workspace_bytes", "rs_normalise", "rs_forward", "rs_padded_length", "rs_classify",
-    "rs_decide", "rs_polya_end", "rs_model_layer_info",
+    "rs_decide", "rs_polya_end", "rs_model_layer_info", "rs_profile_enable", "rs_profile_read",
 )
 
 
@@ -72,6 +72,10 @@ def lib():
     L.rs_polya_end.argtypes = [vp, vp, vp, i32, vp, vp]
     L.rs_model_layer_info.restype = i32
     L.rs_model_layer_info.argtypes = [vp, i32, C.POINTER(LayerInfo)]
+    L.rs_profile_enable.restype = i32
+    L.rs_profile_enable.argtypes = [vp, i32]
+    L.rs_profile_read.restype = i32
+    L.rs_profile_read.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     _lib = L
     return L
 

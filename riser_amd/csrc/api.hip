@@ -45,6 +45,12 @@ struct rs_model {
     float* d_fcb = nullptr;
     int last_bm[kMaxLayers] = {0};
     int last_bn[kMaxLayers] = {0};
+    // stage profiling (rs_profile_*): events recorded on the launch stream
+    bool prof_on = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_stage;            // stage of event k (-1 = start of a call)
+    size_t ev_used = 0;
+    int prof_calls = 0;
 };
 
 namespace {
@@ -126,6 +132,21 @@ WsLayout ws_layout(const rs_model* m, int B, int Lmax) {
     w.bufb_off = w.bufa_off + buf;
     w.total = w.bufb_off + buf;
     return w;
+}
+
+// record an event tagged `stage` (-1 opens a call) on the stream, if profiling is on
+void prof_mark(rs_model* m, int stage, hipStream_t st) {
+    if (!m->prof_on) return;
+    if (m->ev_used == m->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        m->ev_pool.push_back(e);
+        m->ev_stage.push_back(0);
+    }
+    m->ev_stage[m->ev_used] = stage;
+    (void)hipEventRecord(m->ev_pool[m->ev_used], st);
+    ++m->ev_used;
+    if (stage < 0) ++m->prof_calls;
 }
 
 template <class T>
@@ -247,6 +268,7 @@ int rs_model_destroy(rs_model* m) {
     }
     if (m->d_fcw) (void)hipFree(m->d_fcw);
     if (m->d_fcb) (void)hipFree(m->d_fcb);
+    for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
     return RS_OK;
 }
@@ -307,8 +329,10 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
     void* buf[2] = {ws + w.bufa_off, ws + w.bufb_off};
     const bool bf16 = m->dtype == RS_BF16;
 
+    if (!m->prof_on || m->ev_used == 0 || m->ev_stage[m->ev_used - 1] != 0) prof_mark(m, -1, st);
     int rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], bf16, st);
     if (rc != RS_OK) return rc;
+    prof_mark(m, 1, st);
     int cur = 0;
     for (int i = 1; i < m->n_layers; ++i) {
         ConvLayerDev& L = m->layers[i];
@@ -317,10 +341,13 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
         rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len, B,
                              P_in, i, st, &m->last_bm[i], &m->last_bn[i]);
         if (rc != RS_OK) return rc;
+        prof_mark(m, 1 + i, st);
         cur ^= 1;
     }
-    return launch_head(buf[cur], bf16, m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
-                       w.P0 >> m->n_layers, m->n_layers, d_len, B, m->d_fcw, m->d_fcb, d_probs, d_logits, st);
+    rc = launch_head(buf[cur], bf16, m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
+                     w.P0 >> m->n_layers, m->n_layers, d_len, B, m->d_fcw, m->d_fcb, d_probs, d_logits, st);
+    if (rc == RS_OK) prof_mark(m, m->n_layers + 1, st);
+    return rc;
 }
 
 int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
@@ -339,9 +366,11 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
         return RS_ERR_WORKSPACE;
     }
     float* xn = reinterpret_cast<float*>(static_cast<char*>(d_ws) + w.xnorm_off);
+    prof_mark(m, -1, static_cast<hipStream_t>(stream));
     int rc = launch_normalise(d_sig, d_off, d_len, B, Lmax, xn, w.P0, w.P0, nullptr, 0, nullptr,
                               static_cast<hipStream_t>(stream));
     if (rc != RS_OK) return rc;
+    prof_mark(m, 0, static_cast<hipStream_t>(stream));
     return rs_forward(m, xn, w.P0, d_len, B, Lmax, d_ws, ws_bytes, d_probs, d_logits, stream);
 }
 
@@ -363,6 +392,38 @@ int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
         return RS_ERR_ARG;
     }
     return launch_polya(d_sig, d_off, d_len, B, d_end, static_cast<hipStream_t>(stream));
+}
+
+int rs_profile_enable(rs_model* m, int on) {
+    if (!m) {
+        set_error("rs_profile_enable: null model");
+        return RS_ERR_ARG;
+    }
+    m->prof_on = on != 0;
+    if (!on) {
+        m->ev_used = 0;
+        m->prof_calls = 0;
+    }
+    return RS_OK;
+}
+
+int rs_profile_read(rs_model* m, float* stage_ms, int32_t* calls) {
+    if (!m || !stage_ms) {
+        set_error("rs_profile_read: null argument");
+        return RS_ERR_ARG;
+    }
+    if (m->ev_used) RS_HIP(hipEventSynchronize(m->ev_pool[m->ev_used - 1]));
+    for (size_t k = 1; k < m->ev_used; ++k) {
+        const int stage = m->ev_stage[k];
+        if (stage < 0) continue;
+        float ms = 0.f;
+        RS_HIP(hipEventElapsedTime(&ms, m->ev_pool[k - 1], m->ev_pool[k]));
+        stage_ms[stage] += ms;
+    }
+    if (calls) *calls = m->prof_calls;
+    m->ev_used = 0;
+    m->prof_calls = 0;
+    return RS_OK;
 }
 
 int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out) {

@@ -116,6 +116,16 @@ class Model:
             out.append({n: getattr(li, n) for n, _ in nv.LayerInfo._fields_})
         return out
 
+    def profile(self, on: bool):
+        nv.check(nv.lib().rs_profile_enable(self._h, 1 if on else 0), "rs_profile_enable")
+
+    def profile_read(self):
+        """-> (stage_ms float32 [n_layers + 2], calls); see rs_profile_read."""
+        ms = np.zeros(self.n_layers + 2, dtype=np.float32)
+        calls = C.c_int32(0)
+        nv.check(nv.lib().rs_profile_read(self._h, ms.ctypes.data, C.byref(calls)), "rs_profile_read")
+        return ms, calls.value
+
     def _check_lengths(self, lens_host: np.ndarray):
         if lens_host.size == 0:
             raise ValueError("empty batch")

@@ -1,0 +1,97 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol the
+header declares, argument validation works without a GPU, and the host package fails
+loudly (no CPU fallback) when no device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from riser_amd import _native as nv
+from riser_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from riser_amd import build
+    build.build()
+    return nv.lib()
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "riser_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    declared = _header_functions()
+    assert len(declared) >= 13
+    assert sorted(nv.SYMBOLS) == declared, "riser_amd/_native.py SYMBOLS out of sync with include/riser_amd.h"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported by libriser_amd.so"
+
+
+def test_version_and_error_string(lib):
+    assert lib.rs_version() >> 16 == 1
+    assert isinstance(lib.rs_last_error(), bytes)
+
+
+def test_argument_validation_without_gpu(lib):
+    h = C.c_void_p()
+    ch = (C.c_int32 * 2)(4, 4)
+    # null weight tables
+    assert lib.rs_model_create(2, ch, 2, None, None, None, None, 0, 0, C.byref(h)) == -1
+    assert b"null" in lib.rs_last_error()
+    assert lib.rs_workspace_bytes(None, 1, 4096) == 0
+    assert lib.rs_padded_length(None, 4096) == 0
+    assert lib.rs_decide(None, 0, 4, None, 1, 0.9, 0, None, None) == -1
+    assert lib.rs_forward(None, None, 0, None, 1, 4096, None, 0, None, None, None) == -1
+    assert lib.rs_model_destroy(None) == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu(lib):
+    from riser_amd.model import Model
+    from riser_amd.preprocess import Kit, SignalProcessor
+    assert lib.rs_device_count() == 0
+    with pytest.raises(nv.NativeError):
+        Model(synth.make_state_dict(1), synth.Config(), None, "mRNA")
+    with pytest.raises(nv.NativeError):
+        SignalProcessor(Kit.create_from_version("RNA004"))
+
+
+def test_product_never_imports_oracle():
+    """the shipped package must not reach into oracle/ (no CPU fallback)."""
+    pkg = os.path.join(ROOT, "riser_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_pack_reads_and_kit():
+    from riser_amd.preprocess import Kit, _as_int16
+    k = Kit.create_from_version("RNA002")
+    assert (k.sampling_hz, k.transloc_rate) == (3012, 70)
+    with pytest.raises(Exception):
+        Kit.create_from_version("RNA999")
+    with pytest.raises(TypeError):
+        _as_int16(np.zeros(4, dtype=np.float64))
+    with pytest.raises(TypeError):
+        _as_int16(np.array([70000]))
+    assert _as_int16(np.array([1, -2, 3], dtype=np.int64)).dtype == np.int16
+
+
+def test_synth_state_dict_matches_reference_keys():
+    sd = synth.make_state_dict(3)
+    assert sum(v.size for v in sd.values()) == 10_447_564
+    assert sd["layers.0.0.weight"].shape == (20, 1, 3) and sd["layers.11.0.weight"].shape == (1702, 1135, 3)
+    assert sd["classifier.2.weight"].shape == (2, 1702)
+    sd2 = synth.make_state_dict(3)
+    assert all(np.array_equal(sd[k], sd2[k]) for k in sd)

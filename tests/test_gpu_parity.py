@@ -1,0 +1,331 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden fixtures
+recorded from the reference.  Bars: normalise / polyA / decisions bit-exact; probabilities
+within 1e-3 of the reference's fp32 torch-CPU path (north_star), labels identical at 0.9."""
+import ctypes as C
+import json
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import riser_oracle as ro
+from riser_amd import _native as nv
+from riser_amd import synth
+from riser_amd.fake_client import FakeClient, FakeRead
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-3          # north_star: class probabilities within 1e-3 (fp32)
+SIG_SEED = 20260103
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def proc(dev):
+    from riser_amd.preprocess import Kit, SignalProcessor
+    return SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+
+
+_models = {}
+
+
+def get_model(seed, dev, target="mRNA"):
+    from riser_amd.model import Model
+    if seed not in _models:
+        _models[seed] = Model(synth.make_state_dict(seed), synth.Config(), logging.getLogger("t"), target, device=dev)
+    return _models[seed]
+
+
+# ------------------------------------------------------------------------------------------
+# normalise
+# ------------------------------------------------------------------------------------------
+def test_normalise_golden_bit_exact(proc, golden_dir):
+    g = np.load(os.path.join(golden_dir, "normalise.npz"))
+    names = [str(n) for n in g["names"]]
+    sigs = [g[f"{n}.sig"] for n in names]
+    outs, stats = proc.mad_normalise_batch(sigs, return_stats=True)
+    for i, n in enumerate(names):
+        want = g[f"{n}.out"]
+        assert np.array_equal(stats[i], g[f"{n}.stats"]), n
+        if want.dtype == np.int64:                         # mad == 0 -> zeros
+            assert not outs[i].any(), n
+        else:
+            assert np.array_equal(outs[i], want), n
+        one = proc.mad_normalise(sigs[i])                  # the reference's single-read surface
+        assert one.dtype == want.dtype and np.array_equal(one, want), n
+
+
+def test_normalise_random_vs_oracle(proc):
+    rng = np.random.default_rng(5)
+    sigs = []
+    for i in range(40):
+        n = int(rng.integers(2, 20000))
+        kind = i % 4
+        if kind == 0:        # full int16 range: exercises the two-pass (shift > 0) select
+            s = rng.integers(-32768, 32768, n)
+        elif kind == 1:      # narrow, many ties
+            s = rng.integers(480, 520, n)
+        elif kind == 2:      # heavy tails
+            s = (500 + 40 * rng.standard_t(2, n)).clip(-32768, 32767)
+        else:
+            s = synth.make_signals(SIG_SEED + i, 1, n)[0]
+        sigs.append(np.asarray(s, dtype=np.int16))
+    sigs.append(np.array([7], dtype=np.int16))
+    sigs.append(np.array([-32768, 32767, 0, 0, 1], dtype=np.int16))
+    outs = proc.mad_normalise_batch(sigs)
+    for s, o in zip(sigs, outs):
+        w = ro.mad_normalise(s)
+        assert np.array_equal(o, w.astype(np.float64)), (len(s), s[:8])
+
+
+def test_normalise_max_length_and_errors(proc):
+    s = synth.make_signals(3, 1, 65536)[0]
+    assert np.array_equal(proc.mad_normalise(s), ro.mad_normalise(s))
+    with pytest.raises(ValueError):
+        proc.mad_normalise(np.zeros(0, dtype=np.int16))
+    with pytest.raises(ValueError):
+        proc.mad_normalise(np.zeros(65537, dtype=np.int16))
+    with pytest.raises(TypeError):
+        proc.mad_normalise(np.zeros(10, dtype=np.float32))
+
+
+def test_normalise_fp32_device_output(proc, dev):
+    from riser_amd.preprocess import pack_reads
+    sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=i)[0] for i, n in enumerate((4096, 5001, 9000))]
+    sig, off, ln, lens = pack_reads(sigs, dev)
+    x = proc.normalise_device(sig, off, ln, 3, 9000, pad_to=12288).cpu().numpy()
+    for i, s in enumerate(sigs):
+        w = ro.mad_normalise(s).astype(np.float32)
+        assert np.array_equal(x[i, :len(s)], w) and not x[i, len(s):].any()
+
+
+# ------------------------------------------------------------------------------------------
+# polyA
+# ------------------------------------------------------------------------------------------
+def test_polya_golden(proc, golden_dir):
+    cases = np.load(os.path.join(golden_dir, "polya.npz"))["cases"]
+    sigs = [synth.make_raw_read(int(s), int(r), int(n), bool(p)) for s, r, n, p, _ in cases]
+    got = proc.get_polyA_end_batch(sigs)
+    assert np.array_equal(got, cases[:, 4])
+    assert proc.get_polyA_end(sigs[3]) is None and proc.get_polyA_end(sigs[0]) == cases[0, 4]
+    assert proc.get_polyA_end(np.zeros(100, dtype=np.int16)) is None          # shorter than one window
+    cache = {}
+    trimmed, ok = proc.trim_polyA(sigs[0], "r0", cache)
+    assert ok and cache == {"r0": int(cases[0, 4])} and len(trimmed) == len(sigs[0]) - cases[0, 4] - 1
+
+
+def test_polya_random_vs_oracle(proc):
+    rng = np.random.default_rng(11)
+    sigs = [synth.make_raw_read(1234, i, int(rng.integers(600, 30000)), bool(i % 3)) for i in range(48)]
+    got = proc.get_polyA_end_batch(sigs)
+    for s, e in zip(sigs, got):
+        w = ro.polya_end(s)
+        assert e == (-1 if w is None else w)
+
+
+# ------------------------------------------------------------------------------------------
+# network
+# ------------------------------------------------------------------------------------------
+def test_forward_golden(dev, golden_dir):
+    net = np.load(os.path.join(golden_dir, "network.npz"))
+    worst = 0.0
+    for seed, L, B, first in net["cases"]:
+        tag = f"s{seed}_L{L}_B{B}_r{first}"
+        sigs = synth.make_signals(int(net["sig_seed"][0]), int(B), int(L), first_read=int(first))
+        m = get_model(int(seed), dev)
+        xs = [ro.mad_normalise(s) for s in sigs]
+        probs, logits = m.classify_batch(xs, return_logits=True)
+        probs, logits = probs.cpu().numpy(), logits.cpu().numpy()
+        want = net[f"{tag}.probs"]
+        err = float(np.abs(probs - want).max())
+        worst = max(worst, err)
+        assert err < PROB_TOL, (tag, err)
+        assert np.array_equal(probs[:, 1] > 0.9, want[:, 1] > 0.9), tag
+        assert np.allclose(logits, net[f"{tag}.logits"], atol=2e-3), tag
+    print("worst |dp| vs reference:", worst)
+
+
+def test_classify_single_read_surface(dev):
+    """Model.classify(signal) keeps riser/model.py:22-28: Tensor[2] on the device, (p_off, p_on)."""
+    m = get_model(1, dev)
+    s = synth.make_signals(SIG_SEED, 1, 8615, first_read=3)[0]
+    x = ro.mad_normalise(s)
+    p = m.classify(x)
+    assert isinstance(p, torch.Tensor) and p.shape == (2,) and p.dtype == torch.float32 and p.is_cuda
+    p_off, p_on = p
+    want = ro.classify(synth.make_state_dict(1), x)
+    assert abs(p_on.item() - want[1]) < PROB_TOL and abs(p_off.item() + p_on.item() - 1) < 1e-6
+    assert bool(p_on > 0.9) == bool(want[1] > 0.9)
+    z = m.classify(np.zeros(4096, dtype=np.int64))          # the mad == 0 array of the reference
+    assert abs(z[1].item() - ro.classify(synth.make_state_dict(1), np.zeros(4096, dtype=np.int64))[1]) < PROB_TOL
+
+
+def test_mixed_lengths_batch_and_permutation(dev):
+    m = get_model(2, dev)
+    lens = [4096, 4097, 4099, 5000, 6023, 6024, 8191, 8192, 8193, 8615, 11999, 12048, 15999, 16000, 16383, 16384, 20001]
+    sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=50 + i)[0] for i, n in enumerate(lens)]
+    xs = [ro.mad_normalise(s) for s in sigs]
+    sd = synth.make_state_dict(2)
+    want = np.stack([ro.classify(sd, x) for x in xs])
+    got = m.classify_batch(xs).cpu().numpy()
+    assert np.abs(got - want).max() < PROB_TOL
+    perm = np.random.default_rng(0).permutation(len(xs))
+    got_p = m.classify_batch([xs[i] for i in perm]).cpu().numpy()
+    assert np.array_equal(got_p, got[perm]), "per-read result must not depend on batch position"
+    for i in (0, 9, 16):
+        assert np.array_equal(m.classify_batch([xs[i]]).cpu().numpy()[0], got[i]), "batch of 1 == batched"
+
+
+def test_fused_raw_path_vs_oracle(dev):
+    from riser_amd.preprocess import pack_reads
+    m = get_model(3, dev)
+    sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=200 + i)[0] for i, n in enumerate((16000, 4096, 12000, 8000, 9999))]
+    sig, off, ln, lens = pack_reads(sigs, dev)
+    got = m.classify_raw(sig, off, ln, lens).cpu().numpy()
+    want = ro.classify_reads(synth.make_state_dict(3), sigs)
+    assert np.abs(got - want).max() < PROB_TOL
+    # a trim is an offset: classify sigs[0][1234:1234+8000] in place
+    off2 = torch.tensor([1234], dtype=torch.int64, device=dev)
+    ln2 = torch.tensor([8000], dtype=torch.int32, device=dev)
+    got2 = m.classify_raw(sig, off2, ln2, np.array([8000], dtype=np.int32)).cpu().numpy()
+    want2 = ro.classify_reads(synth.make_state_dict(3), [sigs[0][1234:9234]])
+    assert np.abs(got2 - want2).max() < PROB_TOL
+
+
+def test_too_short_and_bad_args(dev):
+    m = get_model(1, dev)
+    with pytest.raises(ValueError):
+        m.classify(np.zeros(4095))                           # torch raises in max_pool1d for the reference
+    with pytest.raises(ValueError):
+        m.classify_batch([])
+    L = nv.lib()
+    x = torch.zeros((1, 4096), device=dev)
+    ln = torch.tensor([4096], dtype=torch.int32, device=dev)
+    out = torch.zeros((1, 2), device=dev)
+    ws = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    rc = L.rs_forward(m._h, x.data_ptr(), 4096, ln.data_ptr(), 1, 4096, ws.data_ptr(), ws.numel(), out.data_ptr(), None, None)
+    assert rc == -5 and b"workspace" in L.rs_last_error()
+    h = C.c_void_p()
+    ch = (C.c_int32 * 2)(4, 4)
+    w = np.zeros(64, dtype=np.float32)
+    wp = (C.c_void_p * 2)(w.ctypes.data, w.ctypes.data)
+    assert L.rs_model_create(2, ch, 3, wp, wp, w.ctypes.data, w.ctypes.data, 0, 0, C.byref(h)) == -1     # n_classes != 2
+
+
+def test_small_custom_network(dev):
+    """the kernels are generic over the channel list (config.cnn.channels), not only the shipped one."""
+    from riser_amd.model import Model
+    rng = np.random.default_rng(3)
+    channels = [8, 13, 21, 40, 70, 17]
+    sd, c_in = {}, 1
+    for i, c in enumerate(channels):
+        sd[f"layers.{i}.0.weight"] = (rng.standard_normal((c, c_in, 3)) * np.sqrt(2.0 / (3 * c_in))).astype(np.float32)
+        sd[f"layers.{i}.0.bias"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        c_in = c
+    sd["classifier.2.weight"] = rng.standard_normal((2, c_in)).astype(np.float32)
+    sd["classifier.2.bias"] = rng.standard_normal(2).astype(np.float32)
+    cfg = synth.Config(synth.CnnConfig(channels=channels, kernels=[3] * 6))
+    m = Model(sd, cfg, None, "x", device=dev)
+    xs = [rng.standard_normal(n).astype(np.float64) for n in (64, 65, 100, 777, 2048)]
+    got = m.classify_batch(xs).cpu().numpy()
+    want = np.stack([ro.classify(sd, x) for x in xs])
+    assert np.abs(got - want).max() < 1e-4
+    m.close()
+
+
+# ------------------------------------------------------------------------------------------
+# decision + control loop
+# ------------------------------------------------------------------------------------------
+def test_decide_matches_reference_rule(dev):
+    rng = np.random.default_rng(9)
+    B, nm = 257, 3
+    p_on = rng.random((nm, B)).astype(np.float32)
+    p_on[:, :40] = np.float32(0.9)                           # exactly at the threshold: strict >
+    probs = np.stack([1 - p_on, p_on], axis=2).astype(np.float32)
+    lens = rng.choice([5000, 8614, 8615, 9000], B).astype(np.int32)
+    for mode in ("enrich", "deplete"):
+        for thr in (0.9, 0.5):
+            out = torch.empty(B, dtype=torch.uint8, device=dev)
+            pt = torch.from_numpy(probs).to(dev)
+            lt = torch.from_numpy(lens).to(dev)
+            nv.check(nv.lib().rs_decide(pt.data_ptr(), nm, B, lt.data_ptr(), 8615, thr,
+                                        nv.RS_ENRICH if mode == "enrich" else nv.RS_DEPLETE, out.data_ptr(), None), "d")
+            got = out.cpu().numpy()
+            for b in range(B):
+                t32 = torch.tensor(thr)                      # torch compares fp32 tensor > python float
+                want = ro.decide([p for p in probs[:, b, 1]], [p for p in probs[:, b, 0]], float(np.float32(thr)), mode, int(lens[b]), 8615)
+                assert nv.DECISION_NAMES[got[b]] == want, (mode, thr, b)
+
+
+def _build_batches(script, seed):
+    return [[(ch, FakeRead(rid_s, synth.make_raw_read(seed, rid, n, bool(polya)), number))
+             for ch, rid_s, rid, n, polya, number in b] for b in script]
+
+
+def test_control_loop_golden(dev, proc, golden_dir, tmp_path):
+    """replay the scripted ReadUntil batches through the batched SequencerControl and compare
+    with what the reference's per-read loop wrote / sent (riser/control.py:11-124)."""
+    from riser_amd.control import SequencerControl
+    with open(os.path.join(golden_dir, "control.json")) as f:
+        g = json.load(f)
+    log = logging.getLogger("ctl")
+    for k, run in enumerate(g["runs"]):
+        models = [get_model(s, dev) for s in run["seeds"]]
+        for mdl, t in zip(models, ("mRNA", "mtRNA", "globin")):
+            mdl.target = t
+        client = FakeClient(_build_batches(g["script"], g["raw_seed"]))
+        out = str(tmp_path / f"run{k}")
+        ctl = SequencerControl(client, models, proc, log, out)
+        ctl.start()
+        ctl.target(run["mode"], 1.0, run["threshold"])
+        ctl.finish()
+        assert client.started and client.was_reset and client.warnings == run["warnings"]
+        lines = open(out + ".csv").read().strip().split("\n")
+        assert lines[0] == run["header"] and len(lines) - 1 == len(run["rows"])
+        for ln, want in zip(lines[1:], run["rows"]):
+            p = ln.split(",")
+            assert (p[1], int(p[2]), int(p[3]), p[4]) == (want["read_id"], want["channel"], want["sig_length"], want["models"])
+            got_p = [float(v) for v in p[5].split(";")]
+            assert np.allclose(got_p, want["prob_targets"], atol=PROB_TOL)
+            assert float(p[6]) == want["threshold"] and p[7] == want["mode"]
+            assert p[8] == want["decision"], (run["mode"], run["seeds"], run["threshold"], want, got_p)
+        assert [[list(x) for x in b] for b in client.rejected] == run["rejected"]
+        assert [[list(x) for x in b] for b in client.finished] == run["finished"]
+        assert client.unblock_durations == run["unblock"]
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE-size properties (512 x 16000): no oracle at this size, so size-independent checks
+# ------------------------------------------------------------------------------------------
+def test_full_size_batch_properties(dev):
+    from riser_amd.preprocess import pack_reads
+    m = get_model(1, dev)
+    B, L = 512, 16000
+    sigs = synth.make_signals(SIG_SEED, B, L)
+    sig, off, ln, lens = pack_reads(list(sigs), dev)
+    full = m.classify_raw(sig, off, ln, lens).cpu().numpy()
+    assert np.isfinite(full).all() and np.allclose(full.sum(1), 1.0, atol=1e-6)
+    # (a) idempotence: same call, same bits
+    assert np.array_equal(full, m.classify_raw(sig, off, ln, lens).cpu().numpy())
+    # (b) sub-batch consistency: reads 100..163 classified alone give the same bits
+    idx = torch.arange(100, 164, device=dev)
+    part = m.classify_raw(sig, off[idx].contiguous(), ln[idx].contiguous(), lens[100:164]).cpu().numpy()
+    assert np.array_equal(part, full[100:164])
+    # (c) reversed read order
+    ridx = torch.arange(B - 1, -1, -1, device=dev)
+    rev = m.classify_raw(sig, off[ridx].contiguous(), ln[ridx].contiguous(), lens[::-1].copy()).cpu().numpy()
+    assert np.array_equal(rev[::-1], full)
+    # (d) a sample against the oracle
+    pick = [0, 17, 255, 511]
+    want = ro.classify_reads(synth.make_state_dict(1), sigs[pick])
+    assert np.abs(full[pick] - want).max() < PROB_TOL
+    assert np.array_equal(full[pick, 1] > 0.9, want[:, 1] > 0.9)
+    # the population must be discriminating, or the checks above prove little
+    assert (full[:, 1] > 0.9).sum() > 10 and (full[:, 1] < 0.1).sum() > 10
