@@ -26,8 +26,6 @@ int hip_fail(hipError_t e, const char* what) {
     return RS_ERR_HIP;
 }
 
-size_t conv_f32_lds_bytes(int mt, int nt, int kc, int nch);
-
 }  // namespace rs
 
 using namespace rs;
@@ -43,6 +41,7 @@ struct rs_model {
     ConvLayerDev layers[kMaxLayers];      // i >= 1
     float* d_fcw = nullptr;               // [2][c_last]
     float* d_fcb = nullptr;
+    int num_cu = 256;
     int last_bm[kMaxLayers] = {0};
     int last_bn[kMaxLayers] = {0};
     // stage profiling (rs_profile_*): events recorded on the launch stream
@@ -60,56 +59,23 @@ inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 int esize(const rs_model* m) { return m->dtype == RS_BF16 ? 2 : 4; }
 
-// ---- static part of the tile plan: nt (couts per wave tile / 16) and the K chunking ---------
-// nt minimises the padded cout count (ties -> larger tile); kc minimises
-// nch * (3*kc/4 + 3) k-steps (3 steps ~ the per-chunk sync + staging bubble) under the
-// 80 KB LDS budget that keeps two workgroups per CU at the largest row tile.
+// ---- static part of the plan: the K chunking (fixes the weight packing) -------------------------
+// kc minimises nch * (3*kc/4 + 0.75) k-steps (0.75 step ~ the per-item barrier + LDS write);
+// the tile shape is chosen per launch from the batch's row count (conv_f32.hip).
 ConvPlan plan_static_f32(int cp_in, int c_out) {
     ConvPlan p{};
-    const int n16 = round_up(c_out, 16) / 16;
-    int best_nt = 2, best_pad = 1 << 30;
-    for (int nt = 2; nt <= 8; ++nt) {
-        const int pad = round_up(n16, nt);
-        if (pad < best_pad || (pad == best_pad && nt > best_nt)) {
-            best_pad = pad;
-            best_nt = nt;
-        }
-    }
-    p.nt = best_nt;
-    p.n_pad = best_pad * 16;
-    p.mt = 4;
-    int best_kc = 4, best_nch = (cp_in + 3) / 4;
-    long best_cost = -1;
-    for (int kc = 4; kc <= 64; kc += 4) {
-        if (conv_f32_lds_bytes(4, p.nt, kc, 2) > 80 * 1024) break;
+    double best_cost = -1;
+    for (int kc = 4; kc <= conv_f32_kc_max(); kc += 4) {
         const int nch = (cp_in + kc - 1) / kc;
-        const long cost = (long)nch * (3 * kc / 4 + 3);
-        if (best_cost < 0 || cost < best_cost || (cost == best_cost && kc > best_kc)) {
+        const double cost = nch * (3.0 * kc / 4.0 + 0.75);
+        if (best_cost < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && kc > p.kc)) {
             best_cost = cost;
-            best_kc = kc;
-            best_nch = nch;
+            p.kc = kc;
+            p.nch = nch;
         }
     }
-    p.kc = best_kc;
-    p.nch = best_nch;
+    p.n_alloc = round_up(c_out, 16) + conv_f32_max_bn();
     return p;
-}
-
-// ---- run-time part: rows per workgroup (64 * mt) from the batch's row count ------------------
-int plan_mt(const ConvPlan& p, int64_t rows) {
-    int best = 4;
-    double best_cost = 1e300;
-    const int ntiles = p.n_pad / (16 * p.nt);
-    for (int mt : {4, 2, 1}) {
-        const int64_t nwg = (rows + 64 * mt - 1) / (64 * mt) * ntiles;
-        const int64_t rounds = (nwg + 511) / 512;                  // 256 CUs x 2 workgroups
-        const double cost = (double)rounds * mt * (1.0 + 0.03 * (4 / mt - 1));   // small tiles re-read weights
-        if (cost < best_cost - 1e-9) {
-            best_cost = cost;
-            best = mt;
-        }
-    }
-    return best;
 }
 
 struct WsLayout {
@@ -202,6 +168,11 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         return RS_ERR_OOM;
     }
     m->device = device;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            m->num_cu = cus;
+    }
     m->dtype = dtype;
     m->n_layers = n_layers;
     for (int i = 0; i < n_layers; ++i) {
@@ -227,14 +198,14 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         L.cp_out = m->cp[i];
         L.plan = plan_static_f32(L.cp_in, L.c_out);
         const ConvPlan& p = L.plan;
-        std::vector<float> wp((size_t)p.n_pad * p.nch * 3 * p.kc, 0.0f);
+        std::vector<float> wp((size_t)p.n_alloc * p.nch * 3 * p.kc, 0.0f);
         for (int n = 0; n < L.c_out; ++n)
             for (int ci = 0; ci < L.c_in; ++ci) {
                 const int c = ci / p.kc, cc = ci - c * p.kc;
                 for (int kw = 0; kw < 3; ++kw)
                     wp[(((size_t)n * p.nch + c) * 3 + kw) * p.kc + cc] = conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw];
             }
-        std::vector<float> bp((size_t)p.n_pad, 0.0f);
+        std::vector<float> bp((size_t)p.n_alloc, 0.0f);
         for (int n = 0; n < L.c_out; ++n) bp[n] = conv_b[i][n];
         float* dw = nullptr;
         rc = upload(&dw, wp);
@@ -337,9 +308,8 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
     for (int i = 1; i < m->n_layers; ++i) {
         ConvLayerDev& L = m->layers[i];
         const int P_in = w.P0 >> i;
-        L.plan.mt = plan_mt(L.plan, (int64_t)B * P_in);
         rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len, B,
-                             P_in, i, st, &m->last_bm[i], &m->last_bn[i]);
+                             P_in, i, m->num_cu, st, &m->last_bm[i], &m->last_bn[i]);
         if (rc != RS_OK) return rc;
         prof_mark(m, 1 + i, st);
         cur ^= 1;
@@ -445,7 +415,7 @@ int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out) {
     out->c_in = L.c_in;
     out->cp_in = L.cp_in;
     out->k_pad = 3 * L.plan.kc * L.plan.nch;
-    out->n_pad = L.plan.n_pad;
+    out->n_pad = m->last_bn[layer] ? round_up(round_up(L.c_out, 16), m->last_bn[layer]) : round_up(L.c_out, 16);
     out->bm = m->last_bm[layer];
     out->bn = m->last_bn[layer];
     out->kc = L.plan.kc;

@@ -34,21 +34,22 @@ int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int
                  void* d_y, bool bf16_out, hipStream_t st);
 
 struct ConvPlan {
-    int mt, nt;       // wave tile = 16*mt rows x 16*nt couts; workgroup = 4 waves stacked along rows
-    int kc;           // channels per K chunk (multiple of 4 for f32, 32 for bf16)
-    int nch;          // number of chunks
-    int n_pad;        // padded couts covered by the grid (multiple of 16*nt)
+    int kc;           // input channels per K chunk (multiple of 4)
+    int nch;          // number of chunks: kc * nch >= cp_in
+    int n_alloc;      // rows of the packed weight / bias tables (couts + zero rows for any tile width)
 };
 
 struct ConvLayerDev {
     int c_in, c_out, cp_in, cp_out;
     ConvPlan plan;            // packing of d_w follows plan.kc / plan.nch / plan.n_pad
-    void* d_w;                // packed weights [n_pad][nch][3][kc] (f32 or bf16)
-    float* d_bias;            // [n_pad] fp32, zero padded
+    void* d_w;                // packed weights [n_alloc][nch][3][kc] (f32 or bf16)
+    float* d_bias;            // [n_alloc] fp32, zero padded
 };
 
 int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len,
-                    int B, int P_in, int layer_index, hipStream_t st, int* bm_out, int* bn_out);
+                    int B, int P_in, int layer_index, int num_cu, hipStream_t st, int* bm_out, int* bn_out);
+int conv_f32_max_bn();
+int conv_f32_kc_max();
 
 int launch_head(const void* d_y, bool bf16_in, int cp, int c, int P_last, int n_layers,
                 const int32_t* d_len, int B, const float* d_fcw, const float* d_fcb,

@@ -16,24 +16,32 @@
 // bias + ReLU + MaxPool run in registers and the pooled row is stored straight into the next
 // layer's buffer at row/2 (P_out = P/2), masked to zero beyond len >> (i+1).
 //
-// Workgroup = 4 waves stacked along M; wave tile = (16*MT) x (16*NT); K is processed in
-// chunks of KC input channels: per chunk the workgroup stages a (BM+2) x KC slab of X (the
-// +2 halo rows serve all three taps from ONE copy) and a BN x 3 x KC slab of packed weights
-// through registers into LDS (single buffer of <= 80 KB, so two workgroups share a CU and one
-// stages while the other computes), then issues 3*KC/4 k-steps of v_mfma_f32_16x16x4_f32 per
-// (mt, nt) tile.  LDS rows are KC+2 floats (= 2 mod 4) so that
-// the 16 rows x 2 k-groups a 32-lane half reads with ds_read_b32 hit 32 distinct banks.
+// Schedule: PERSISTENT workgroups (one per CU, 8 waves = 2 per SIMD) walk the tile list in an
+// XCD-aware order; a tile is BM x BN = (WM*16*MT) x (WN*16*NT) with the 8 waves arranged
+// WM x WN.  K is cut into chunks of KC input channels; a work item = (tile, chunk).  Per item
+// the workgroup needs a (BM+2) x KC slab of X (the +2 halo rows serve all three taps from ONE
+// copy) and a BN x 3 x KC slab of packed weights in LDS.  Items are software-pipelined across
+// tile boundaries: the global loads of item k+1 are issued into registers BEFORE the MFMAs of
+// item k and written to the other LDS buffer after them (one barrier per item), so HBM/L2
+// latency, the epilogue's stores and the next tile's prologue all hide under MFMA issue.
+// LDS rows are KC+2 floats (= 2 mod 4): the 16 rows x 2 k-groups that a 32-lane half reads
+// with ds_read_b32 then fall in 32 distinct banks.
 #include "common.hpp"
+
+#include <algorithm>
 
 namespace rs {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kThreads = 512;
+constexpr int kKcMax = 24;                  // bounds the per-thread staging registers
+
 struct ConvArgs {
     const float* x;
-    const float* w;        // packed [n_pad][nch][3][kc]
-    const float* bias;     // [n_pad]
+    const float* w;        // packed [n_alloc][nch][3][kc], zero rows beyond c_out
+    const float* bias;     // [n_alloc]
     float* y;
     const int32_t* len;
     int rows_in;           // B * P_in
@@ -44,70 +52,96 @@ struct ConvArgs {
     int n_mtiles, n_ntiles;
 };
 
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
-    constexpr int BM = 64 * MT;
-    constexpr int BN = 16 * NT;
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a) {
+    static_assert(WM * WN == 8, "8 waves per workgroup");
+    constexpr int BM = WM * 16 * MT;
+    constexpr int BN = WN * 16 * NT;
+    constexpr int A_PER = ((BM + 2) * (kKcMax / 4) + kThreads - 1) / kThreads;
+    constexpr int B_PER = (BN * 3 * (kKcMax / 4) + kThreads - 1) / kThreads;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
     const int r = lane & 15, kq = lane >> 4;
-
-    // XCD-aware tile order: the 8 XCDs each take a contiguous range of an n-tile-major order,
-    // so workgroups sharing an L2 stream the same weight slab (bijective remap).
-    const int nwg = a.n_mtiles * a.n_ntiles;
-    int o;
-    {
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
-        o = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    }
-    const int ntile = o / a.n_mtiles;
-    const int mtile = o - ntile * a.n_mtiles;
-    const int m0 = mtile * BM;
-    const int n0 = ntile * BN;
 
     const int KC = a.kc;
     const int S = KC + 2;
     const int kc4 = KC >> 2;
     const int a_elems = (BM + 2) * S;
+    const int buf_elems = a_elems + BN * 3 * S;
 
-    // ---- staging: global -> registers -> LDS in float4 units ----------------------------------
-    // Single LDS buffer; two workgroups are co-resident per CU (LDS <= 80 KB each) so one
-    // stages while the other issues MFMAs.
-    const int a_units = (BM + 2) * kc4;
-    const int b_row_units = 3 * kc4;
-    const int b_units = BN * b_row_units;
-    float* const Abuf = lds;
-    float* const Bbuf = lds + a_elems;
-
-    auto stage = [&](int c) {
-        const int cbase = c * KC;
-#pragma unroll 4
-        for (int f = tid; f < a_units; f += 256) {
+    // ---- per-thread staging map (computed once; the kernel is persistent) ---------------------
+    int a_lds[A_PER], a_key[A_PER];            // key = row * 8 + c4, or -1 if the unit is unused
+    int b_lds[B_PER], b_g[B_PER];              // b_g < 0 if unused
+    {
+        const int a_units = (BM + 2) * kc4;
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u) {
+            const int f = tid + u * kThreads;
             const int row = f / kc4, c4 = f - row * kc4;
-            const int gr = m0 - 1 + row;
-            const int ch = cbase + 4 * c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gr >= 0 && gr < a.rows_in && ch < a.cp_in)
-                v = *reinterpret_cast<const float4*>(a.x + (int64_t)gr * a.cp_in + ch);
-            float2* d = reinterpret_cast<float2*>(Abuf + row * S + 4 * c4);
-            d[0] = make_float2(v.x, v.y);
-            d[1] = make_float2(v.z, v.w);
+            a_lds[u] = row * S + 4 * c4;
+            a_key[u] = f < a_units ? row * 8 + c4 : -1;
         }
-#pragma unroll 4
-        for (int f = tid; f < b_units; f += 256) {
+        const int b_row_units = 3 * kc4;
+        const int b_units = BN * b_row_units;
+#pragma unroll
+        for (int u = 0; u < B_PER; ++u) {
+            const int f = tid + u * kThreads;
             const int n = f / b_row_units, rem = f - n * b_row_units;
             const int kw = rem / kc4, c4 = rem - kw * kc4;
-            const float4 v =
-                *reinterpret_cast<const float4*>(a.w + ((int64_t)(n0 + n) * a.nch + c) * (3 * KC) + 4 * rem);
-            float2* d = reinterpret_cast<float2*>(Bbuf + (n * 3 + kw) * S + 4 * c4);
-            d[0] = make_float2(v.x, v.y);
-            d[1] = make_float2(v.z, v.w);
+            b_lds[u] = a_elems + (n * 3 + kw) * S + 4 * c4;
+            b_g[u] = f < b_units ? n * a.nch * 3 * KC + 4 * rem : -1;
+        }
+    }
+
+    float4 ra[A_PER], rb[B_PER];
+    auto load_item = [&](int m0, int n0, int c) {
+        const int cbase = c * KC;
+        const float* xb = a.x + (int64_t)(m0 - 1) * a.cp_in + cbase;
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int key = a_key[u];
+            const int row = key >> 3, c4 = key & 7;
+            const int gr = m0 - 1 + row;
+            if (key >= 0 && gr >= 0 && gr < a.rows_in && cbase + 4 * c4 < a.cp_in)
+                v = *reinterpret_cast<const float4*>(xb + (int64_t)row * a.cp_in + 4 * c4);
+            ra[u] = v;
+        }
+        const float* wb = a.w + ((int64_t)n0 * a.nch + c) * (3 * KC);
+#pragma unroll
+        for (int u = 0; u < B_PER; ++u) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_g[u] >= 0) v = *reinterpret_cast<const float4*>(wb + b_g[u]);
+            rb[u] = v;
         }
     };
+    auto store_item = [&](float* buf) {
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u)
+            if (a_key[u] >= 0) {
+                float2* d = reinterpret_cast<float2*>(buf + a_lds[u]);
+                d[0] = make_float2(ra[u].x, ra[u].y);
+                d[1] = make_float2(ra[u].z, ra[u].w);
+            }
+#pragma unroll
+        for (int u = 0; u < B_PER; ++u)
+            if (b_g[u] >= 0) {
+                float2* d = reinterpret_cast<float2*>(buf + b_lds[u]);
+                d[0] = make_float2(rb[u].x, rb[u].y);
+                d[1] = make_float2(rb[u].z, rb[u].w);
+            }
+    };
+
+    // ---- tile walk: round k gives XCD x (= blockIdx % 8) a contiguous block of the n-major tile
+    // order, so the workgroups sharing an L2 stream the same weight slab at the same time -------
+    const int tiles = a.n_mtiles * a.n_ntiles;
+    const int nwg = gridDim.x;
+    int o = (nwg & 7) == 0 ? (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    if (o >= tiles) return;
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -115,18 +149,40 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* As = Abuf + (wave * 16 * MT + r) * S + kq;       // + mt*16*S + kw*S + c0
-    const float* Bs = Bbuf + r * 3 * S + kq;                      // + nt*48*S + kw*S + c0
+    int c = 0;
+    int ntile = o / a.n_mtiles;
+    int m0 = (o - ntile * a.n_mtiles) * BM, n0 = ntile * BN;
+    load_item(m0, n0, 0);
+    store_item(lds);
+    __syncthreads();
+    int buf = 0;
 
-    for (int c = 0; c < a.nch; ++c) {
-        if (c) __syncthreads();                                   // everyone done reading the previous chunk
-        stage(c);
-        __syncthreads();
+    const int a_rd = (wm * 16 * MT + r) * S + kq;              // + i*16*S + kw*S + c0
+    const int b_rd = a_elems + (wn * 16 * NT + r) * 3 * S + kq;   // + j*48*S + kw*S + c0
+
+    while (true) {
+        int nc = c + 1, no = o;
+        if (nc == a.nch) {
+            nc = 0;
+            no = o + nwg;
+        }
+        const bool has_next = no < tiles;
+        int nm0 = m0, nn0 = n0;
+        if (has_next) {
+            if (nc == 0) {
+                const int nt_ = no / a.n_mtiles;
+                nm0 = (no - nt_ * a.n_mtiles) * BM;
+                nn0 = nt_ * BN;
+            }
+            load_item(nm0, nn0, nc);                            // in flight under the MFMAs below
+        }
+
+        const float* cur = lds + buf * buf_elems;
 #pragma unroll 1
         for (int kw = 0; kw < 3; ++kw) {
-            const float* Ak = As + kw * S;
-            const float* Bk = Bs + kw * S;
-#pragma unroll 2
+            const float* Ak = cur + a_rd + kw * S;
+            const float* Bk = cur + b_rd + kw * S;
+#pragma unroll 1
             for (int c0 = 0; c0 < KC; c0 += 4) {
                 float af[MT], bf[NT];
 #pragma unroll
@@ -140,64 +196,116 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-    }
 
-    // ---- epilogue: bias + ReLU + MaxPool(2,2) in registers, masked store ---------------------
-    float bias[NT];
+        if (c == a.nch - 1) {
+            // ---- epilogue: bias + ReLU + MaxPool(2,2) in registers, masked store -----------------
+            float bias[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bias[j] = a.bias[n0 + j * 16 + r];
+            for (int j = 0; j < NT; ++j) bias[j] = a.bias[n0 + (wn * NT + j) * 16 + r];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int row = m0 + wave * 16 * MT + i * 16 + 4 * kq;   // even; rows row..row+3 in regs 0..3
+            for (int i = 0; i < MT; ++i) {
+                const int row = m0 + (wm * MT + i) * 16 + 4 * kq;   // even; rows row..row+3 = regs 0..3
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int prow = (row >> 1) + h;                      // pooled output row
-            if (2 * prow >= a.rows_in) continue;
-            const int b = prow / a.P_out;
-            const int p = prow - b * a.P_out;
-            const bool valid = p < (a.len[b] >> a.shift_out);
+                for (int h = 0; h < 2; ++h) {
+                    const int prow = (row >> 1) + h;                // pooled output row
+                    if (2 * prow < a.rows_in) {
+                        const int b = prow / a.P_out;
+                        const int p = prow - b * a.P_out;
+                        const bool valid = p < (a.len[b] >> a.shift_out);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int col = n0 + j * 16 + r;
-                if (col < a.cp_out) {
-                    const float v = fmaxf(fmaxf(acc[i][j][2 * h], acc[i][j][2 * h + 1]) + bias[j], 0.0f);
-                    a.y[(int64_t)prow * a.cp_out + col] = valid ? v : 0.0f;
+                        for (int j = 0; j < NT; ++j) {
+                            const int col = n0 + (wn * NT + j) * 16 + r;
+                            if (col < a.cp_out) {
+                                const float v =
+                                    fmaxf(fmaxf(acc[i][j][2 * h], acc[i][j][2 * h + 1]) + bias[j], 0.0f);
+                                a.y[(int64_t)prow * a.cp_out + col] = valid ? v : 0.0f;
+                            }
+                        }
+                    }
                 }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
+        if (!has_next) break;
+        store_item(lds + (buf ^ 1) * buf_elems);
+        __syncthreads();
+        buf ^= 1;
+        o = no;
+        c = nc;
+        m0 = nm0;
+        n0 = nn0;
     }
 }
 
 using KernelFn = void (*)(const ConvArgs);
 
-template <int MT, int NT>
-KernelFn get_kernel() {
-    return conv_f32_kernel<MT, NT>;
+struct Shape {
+    int wm, wn, mt, nt;
+    KernelFn fn;
+};
+
+#define RS_SHAPE(WM, WN, MT, NT) {WM, WN, MT, NT, conv_f32_kernel<WM, WN, MT, NT>}
+const Shape kShapes[] = {
+    // narrow outputs: all 8 waves stacked along rows
+    RS_SHAPE(8, 1, 2, 2), RS_SHAPE(8, 1, 4, 2), RS_SHAPE(8, 1, 2, 3), RS_SHAPE(8, 1, 4, 3),
+    RS_SHAPE(8, 1, 2, 5), RS_SHAPE(8, 1, 4, 5), RS_SHAPE(8, 1, 2, 7), RS_SHAPE(8, 1, 4, 7),
+    // wide outputs: 4 x 2 waves
+    RS_SHAPE(4, 2, 2, 2), RS_SHAPE(4, 2, 4, 2), RS_SHAPE(4, 2, 2, 3), RS_SHAPE(4, 2, 4, 3),
+    RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 4, 4), RS_SHAPE(4, 2, 2, 5), RS_SHAPE(4, 2, 4, 5),
+    RS_SHAPE(4, 2, 2, 6), RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 2, 7), RS_SHAPE(4, 2, 4, 7),
+    RS_SHAPE(4, 2, 2, 8),
+    // short batches (few rows): 2 x 4 waves
+    RS_SHAPE(2, 4, 2, 2), RS_SHAPE(2, 4, 2, 4), RS_SHAPE(2, 4, 1, 4),
+};
+#undef RS_SHAPE
+constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
+
+size_t lds_bytes(const Shape& s, int kc) {
+    const int bm = s.wm * 16 * s.mt, bn = s.wn * 16 * s.nt;
+    return 2 * (size_t)((bm + 2) + 3 * bn) * (kc + 2) * sizeof(float);
 }
 
-KernelFn lookup_kernel(int mt, int nt) {
-#define RS_CASE(M, N) \
-    if (mt == M && nt == N) return get_kernel<M, N>();
-    RS_CASE(1, 2) RS_CASE(1, 3) RS_CASE(1, 4) RS_CASE(1, 5) RS_CASE(1, 6) RS_CASE(1, 7) RS_CASE(1, 8)
-    RS_CASE(2, 2) RS_CASE(2, 3) RS_CASE(2, 4) RS_CASE(2, 5) RS_CASE(2, 6) RS_CASE(2, 7) RS_CASE(2, 8)
-    RS_CASE(4, 2) RS_CASE(4, 3) RS_CASE(4, 4) RS_CASE(4, 5) RS_CASE(4, 6) RS_CASE(4, 7) RS_CASE(4, 8)
-#undef RS_CASE
-    return nullptr;
+// Pick the tile shape for a layer launch.  Model: one persistent workgroup per CU; time =
+// rounds x (MFMA issue of a tile + per-item and per-tile overheads), in SIMD cycles.
+const Shape* choose_shape(int64_t rows, int n16 /* couts / 16 */, int kc, int nch, int num_cu, double* cost_out) {
+    const Shape* best = nullptr;
+    double best_cost = 1e300;
+    for (int k = 0; k < kNumShapes; ++k) {
+        const Shape& s = kShapes[k];
+        if (lds_bytes(s, kc) > 160 * 1024) continue;
+        const int bm = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
+        const int64_t mtiles = (rows + bm - 1) / bm;
+        const int64_t ntiles = (n16 + bnt - 1) / bnt;
+        const int64_t tiles = mtiles * ntiles;
+        const int64_t rounds = (tiles + num_cu - 1) / num_cu;
+        const double steps = 3.0 * kc / 4.0;
+        // two waves share a SIMD: a k-step issues 2 * mt * nt MFMAs of 32 cycles on it; the
+        // (mt + nt) LDS reads per step and the barrier per item are partly exposed
+        const double item = steps * (2.0 * s.mt * s.nt * 32.0 + 6.0 * (s.mt + s.nt)) + 900.0;
+        const double tile = nch * item + 1500.0 + 40.0 * s.mt * s.nt;
+        const double cost = (double)rounds * tile;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = &s;
+        }
+    }
+    if (cost_out) *cost_out = best_cost;
+    return best;
 }
 
 }  // namespace
 
-size_t conv_f32_lds_bytes(int mt, int nt, int kc, int nch) {
-    (void)nch;
-    return (size_t)((64 * mt + 2) + 48 * nt) * (kc + 2) * sizeof(float);
-}
+// largest BN any shape uses: weight / bias tables are padded by this many zero rows so that
+// every shape can be chosen at run time without bounds checks on the weight loads
+int conv_f32_max_bn() { return 256; }
+int conv_f32_kc_max() { return kKcMax; }
 
 int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
-                    int layer_index, hipStream_t st, int* bm_out, int* bn_out) {
+                    int layer_index, int num_cu, hipStream_t st, int* bm_out, int* bn_out) {
     const ConvPlan& p = L.plan;
-    KernelFn fn = lookup_kernel(p.mt, p.nt);
-    if (!fn || p.kc < 4 || (p.kc & 3)) {
-        set_error("conv_f32: no kernel for tile mt=%d nt=%d kc=%d", p.mt, p.nt, p.kc);
+    if (p.kc < 4 || p.kc > kKcMax || (p.kc & 3)) {
+        set_error("conv_f32: unsupported channel chunk %d", p.kc);
         return RS_ERR_ARG;
     }
     const int64_t rows64 = (int64_t)B * P_in;
@@ -205,6 +313,13 @@ int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const i
         set_error("conv_f32: batch too large (%lld rows)", (long long)rows64);
         return RS_ERR_ARG;
     }
+    const int n16 = round_up(L.c_out, 16) / 16;
+    const Shape* s = choose_shape(rows64, n16, p.kc, p.nch, num_cu, nullptr);
+    if (!s) {
+        set_error("conv_f32: no tile shape fits (kc=%d)", p.kc);
+        return RS_ERR_ARG;
+    }
+    const int BM = s->wm * 16 * s->mt, BN = s->wn * 16 * s->nt;
     ConvArgs a;
     a.x = d_x;
     a.w = static_cast<const float*>(L.d_w);
@@ -218,18 +333,14 @@ int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const i
     a.kc = p.kc;
     a.nch = p.nch;
     a.shift_out = layer_index + 1;
-    const int BM = 64 * p.mt, BN = 16 * p.nt;
     a.n_mtiles = (a.rows_in + BM - 1) / BM;
-    a.n_ntiles = p.n_pad / BN;
-    const size_t lds = conv_f32_lds_bytes(p.mt, p.nt, p.kc, p.nch);
-    if (lds > 160 * 1024) {
-        set_error("conv_f32: LDS %zu too large", lds);
-        return RS_ERR_ARG;
-    }
-    RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+    a.n_ntiles = (n16 * 16 + BN - 1) / BN;
+    const size_t lds = lds_bytes(*s, p.kc);
+    RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s->fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
-    const unsigned grid = (unsigned)(a.n_mtiles * a.n_ntiles);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, a);
+    const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+    hipLaunchKernelGGL(s->fn, dim3(grid), dim3(kThreads), lds, st, a);
     RS_HIP(hipGetLastError());
     if (bm_out) *bm_out = BM;
     if (bn_out) *bn_out = BN;
