@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=CHUNK)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-latency", action="store_true", help="skip the per-batch latency loop (profiling runs)")
     args = ap.parse_args()
 
     rank, local_rank, world = rdist.env_world()
@@ -107,8 +108,8 @@ def main():
     host_sig = torch.from_numpy(np.ascontiguousarray(sigs.reshape(-1))).pin_memory()
     host_probs = torch.empty((B, 2), dtype=torch.float32).pin_memory()
     lat = []
-    n_lat = max(30, min(200, args.steps * 5))
-    for i in range(n_lat + 5):
+    n_lat = 0 if args.no_latency else max(30, min(200, args.steps * 5))
+    for i in range(n_lat + 5 if n_lat else 0):
         t1 = time.perf_counter()
         sig.copy_(host_sig, non_blocking=True)
         step()
@@ -116,7 +117,7 @@ def main():
         torch.cuda.synchronize(device)
         if i >= 5:
             lat.append(time.perf_counter() - t1)
-    lat_ms = np.asarray(lat) * 1e3
+    lat_ms = np.asarray(lat if lat else [0.0]) * 1e3
     p50, p99 = float(np.percentile(lat_ms, 50)), float(np.percentile(lat_ms, 99))
     p99 = rdist.reduce_scalar(p99, "max", device)
 

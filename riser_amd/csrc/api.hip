@@ -41,6 +41,7 @@ struct rs_model {
     ConvLayerDev layers[kMaxLayers];      // i >= 1
     float* d_fcw = nullptr;               // [2][c_last]
     float* d_fcb = nullptr;
+    float* d_zero = nullptr;              // 256 zero bytes: target of masked-off staging loads
     int num_cu = 256;
     int last_bm[kMaxLayers] = {0};
     int last_bn[kMaxLayers] = {0};
@@ -66,6 +67,9 @@ ConvPlan plan_static_f32(int cp_in, int c_out) {
     ConvPlan p{};
     double best_cost = -1;
     for (int kc = 4; kc <= conv_f32_kc_max(); kc += 4) {
+        // chunks of 16 / 20 / 24 channels have fully unrolled kernels (immediate LDS offsets);
+        // other sizes run the generic kernel and are only worth it for very narrow layers
+        if (cp_in >= 16 && kc != 16 && kc != 20 && kc != 24) continue;
         const int nch = (cp_in + kc - 1) / kc;
         const double cost = nch * (3.0 * kc / 4.0 + 0.75);
         if (best_cost < 0 || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && kc > p.kc)) {
@@ -212,6 +216,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         L.d_w = dw;
         if (rc == RS_OK) rc = upload(&L.d_bias, bp);
     }
+    if (rc == RS_OK) rc = upload(&m->d_zero, std::vector<float>(64, 0.0f));
     if (rc == RS_OK) {
         const int cl = channels[n_layers - 1];
         rc = upload(&m->d_fcw, std::vector<float>(fc_w, fc_w + 2 * (size_t)cl));
@@ -239,6 +244,7 @@ int rs_model_destroy(rs_model* m) {
     }
     if (m->d_fcw) (void)hipFree(m->d_fcw);
     if (m->d_fcb) (void)hipFree(m->d_fcb);
+    if (m->d_zero) (void)hipFree(m->d_zero);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
     return RS_OK;
@@ -309,7 +315,7 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
         ConvLayerDev& L = m->layers[i];
         const int P_in = w.P0 >> i;
         rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len, B,
-                             P_in, i, m->num_cu, st, &m->last_bm[i], &m->last_bn[i]);
+                             P_in, i, m->num_cu, m->d_zero, st, &m->last_bm[i], &m->last_bn[i]);
         if (rc != RS_OK) return rc;
         prof_mark(m, 1 + i, st);
         cur ^= 1;

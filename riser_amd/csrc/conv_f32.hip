@@ -44,21 +44,27 @@ struct ConvArgs {
     const float* bias;     // [n_alloc]
     float* y;
     const int32_t* len;
+    const float* zero;     // >= 16 bytes of zeros (target of masked-off staging loads)
     int rows_in;           // B * P_in
     int P_out;             // P_in / 2
+    float inv_P_out;
     int cp_in, cp_out;
     int kc, nch;
     int shift_out;         // valid output rows of read b: len[b] >> shift_out
     int n_mtiles, n_ntiles;
 };
 
-template <int WM, int WN, int MT, int NT>
+// KCT > 0: the channel chunk is a compile-time constant, so every LDS fragment address in the
+// MFMA loop is "per-item base register + immediate" and the loop is fully unrolled (no address
+// VALU between MFMAs).  KCT == 0: generic fallback with the chunk taken from ConvArgs.
+template <int WM, int WN, int MT, int NT, int KCT>
 __global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a) {
     static_assert(WM * WN == 8, "8 waves per workgroup");
     constexpr int BM = WM * 16 * MT;
     constexpr int BN = WN * 16 * NT;
-    constexpr int A_PER = ((BM + 2) * (kKcMax / 4) + kThreads - 1) / kThreads;
-    constexpr int B_PER = (BN * 3 * (kKcMax / 4) + kThreads - 1) / kThreads;
+    constexpr int KCB = KCT ? KCT : kKcMax;                    // bound for the staging registers
+    constexpr int A_PER = ((BM + 2) * (KCB / 4) + kThreads - 1) / kThreads;
+    constexpr int B_PER = (BN * 3 * (KCB / 4) + kThreads - 1) / kThreads;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a)
     const int wm = wave % WM, wn = wave / WM;
     const int r = lane & 15, kq = lane >> 4;
 
-    const int KC = a.kc;
+    const int KC = KCT ? KCT : a.kc;
     const int S = KC + 2;
     const int kc4 = KC >> 2;
     const int a_elems = (BM + 2) * S;
@@ -98,25 +104,26 @@ __global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a)
     }
 
     float4 ra[A_PER], rb[B_PER];
-    auto load_item = [&](int m0, int n0, int c) {
+    auto load_item = [&](int m0, int n0, int c, bool live) {
         const int cbase = c * KC;
         const float* xb = a.x + (int64_t)(m0 - 1) * a.cp_in + cbase;
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            // UNCONDITIONAL load: out-of-range units read a 16-byte zero page instead of being
+            // branched around (a conditional load makes hipcc drain vmcnt(0) before the MFMA
+            // block, which serialises the prefetch with the compute)
             const int key = a_key[u];
             const int row = key >> 3, c4 = key & 7;
             const int gr = m0 - 1 + row;
-            if (key >= 0 && gr >= 0 && gr < a.rows_in && cbase + 4 * c4 < a.cp_in)
-                v = *reinterpret_cast<const float4*>(xb + (int64_t)row * a.cp_in + 4 * c4);
-            ra[u] = v;
+            const bool ok = live && key >= 0 && gr >= 0 && gr < a.rows_in && cbase + 4 * c4 < a.cp_in;
+            const float* src = ok ? xb + (int64_t)row * a.cp_in + 4 * c4 : a.zero;
+            ra[u] = *reinterpret_cast<const float4*>(src);
         }
         const float* wb = a.w + ((int64_t)n0 * a.nch + c) * (3 * KC);
 #pragma unroll
         for (int u = 0; u < B_PER; ++u) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b_g[u] >= 0) v = *reinterpret_cast<const float4*>(wb + b_g[u]);
-            rb[u] = v;
+            const float* src = (live && b_g[u] >= 0) ? wb + b_g[u] : a.zero;
+            rb[u] = *reinterpret_cast<const float4*>(src);
         }
     };
     auto store_item = [&](float* buf) {
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a)
     int c = 0;
     int ntile = o / a.n_mtiles;
     int m0 = (o - ntile * a.n_mtiles) * BM, n0 = ntile * BN;
-    load_item(m0, n0, 0);
+    load_item(m0, n0, 0, true);
     store_item(lds);
     __syncthreads();
     int buf = 0;
@@ -168,32 +175,53 @@ __global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a)
         }
         const bool has_next = no < tiles;
         int nm0 = m0, nn0 = n0;
-        if (has_next) {
-            if (nc == 0) {
-                const int nt_ = no / a.n_mtiles;
-                nm0 = (no - nt_ * a.n_mtiles) * BM;
-                nn0 = nt_ * BN;
-            }
-            load_item(nm0, nn0, nc);                            // in flight under the MFMAs below
+        if (has_next && nc == 0) {
+            const int nt_ = no / a.n_mtiles;
+            nm0 = (no - nt_ * a.n_mtiles) * BM;
+            nn0 = nt_ * BN;
         }
+        // always issued (the last item prefetches the zero page): no branch around the loads, so
+        // they stay in flight under the MFMAs below
+        load_item(nm0, nn0, nc, has_next);
+        __builtin_amdgcn_sched_barrier(0);                      // keep the loads ABOVE the MFMA block
 
-        const float* cur = lds + buf * buf_elems;
+        const float* Ab = lds + buf * buf_elems + a_rd;
+        const float* Bb = lds + buf * buf_elems + b_rd;
+        if constexpr (KCT > 0) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int c0 = 0; c0 < KCT; c0 += 4) {
+                    float af[MT], bf[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) af[i] = Ab[i * 16 * (KCT + 2) + kw * (KCT + 2) + c0];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bf[j] = Bb[j * 48 * (KCT + 2) + kw * (KCT + 2) + c0];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll 1
-        for (int kw = 0; kw < 3; ++kw) {
-            const float* Ak = cur + a_rd + kw * S;
-            const float* Bk = cur + b_rd + kw * S;
+            for (int kw = 0; kw < 3; ++kw) {
+                const float* Ak = Ab + kw * S;
+                const float* Bk = Bb + kw * S;
 #pragma unroll 1
-            for (int c0 = 0; c0 < KC; c0 += 4) {
-                float af[MT], bf[NT];
+                for (int c0 = 0; c0 < KC; c0 += 4) {
+                    float af[MT], bf[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) af[i] = Ak[i * 16 * S + c0];
+                    for (int i = 0; i < MT; ++i) af[i] = Ak[i * 16 * S + c0];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bf[j] = Bk[j * 48 * S + c0];
+                    for (int j = 0; j < NT; ++j) bf[j] = Bk[j * 48 * S + c0];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
             }
         }
 
@@ -202,16 +230,38 @@ __global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a)
             float bias[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) bias[j] = a.bias[n0 + (wn * NT + j) * 16 + r];
+            // read index of a pooled row: one exact division per tile (wave-uniform), then a
+            // small-numerator float quotient per row (t < 2^16: exact)
+            const int pr0 = m0 >> 1;
+            const int b0 = pr0 / a.P_out;
+            const int p0 = pr0 - b0 * a.P_out;
+            // pass 1: pooled-row bookkeeping and the per-read length look-ups, all loads issued
+            // together (one L2 round trip instead of 2*MT serialised ones)
+            int prow_[MT][2];
+            int lim_[MT][2];                                       // valid pooled rows of the read, or 0
+            int pin_[MT][2];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int row = m0 + (wm * MT + i) * 16 + 4 * kq;   // even; rows row..row+3 = regs 0..3
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int prow = (row >> 1) + h;                // pooled output row
-                    if (2 * prow < a.rows_in) {
-                        const int b = prow / a.P_out;
-                        const int p = prow - b * a.P_out;
-                        const bool valid = p < (a.len[b] >> a.shift_out);
+                    const bool in = 2 * prow < a.rows_in;
+                    const int t = p0 + (prow - pr0);
+                    const int e = (int)(((float)t + 0.5f) * a.inv_P_out);
+                    const int b = in ? b0 + e : 0;
+                    prow_[i][h] = in ? prow : -1;
+                    pin_[i][h] = t - e * a.P_out;
+                    lim_[i][h] = a.len[b];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int prow = prow_[i][h];
+                    if (prow >= 0) {
+                        const bool valid = pin_[i][h] < (lim_[i][h] >> a.shift_out);
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
                             const int col = n0 + (wn * NT + j) * 16 + r;
@@ -242,18 +292,19 @@ using KernelFn = void (*)(const ConvArgs);
 
 struct Shape {
     int wm, wn, mt, nt;
-    KernelFn fn;
+    KernelFn fn[4];        // chunk = run-time, 16, 20, 24
 };
 
-#define RS_SHAPE(WM, WN, MT, NT) {WM, WN, MT, NT, conv_f32_kernel<WM, WN, MT, NT>}
+#define RS_SHAPE(WM, WN, MT, NT)                                                                        \
+    {WM, WN, MT, NT, {conv_f32_kernel<WM, WN, MT, NT, 0>, conv_f32_kernel<WM, WN, MT, NT, 16>,        \
+                      conv_f32_kernel<WM, WN, MT, NT, 20>, conv_f32_kernel<WM, WN, MT, NT, 24>}}
 const Shape kShapes[] = {
     // narrow outputs: all 8 waves stacked along rows
-    RS_SHAPE(8, 1, 2, 2), RS_SHAPE(8, 1, 4, 2), RS_SHAPE(8, 1, 2, 3), RS_SHAPE(8, 1, 4, 3),
-    RS_SHAPE(8, 1, 2, 5), RS_SHAPE(8, 1, 4, 5), RS_SHAPE(8, 1, 2, 7), RS_SHAPE(8, 1, 4, 7),
+    RS_SHAPE(8, 1, 4, 2), RS_SHAPE(8, 1, 4, 3), RS_SHAPE(8, 1, 2, 5), RS_SHAPE(8, 1, 4, 5),
+    RS_SHAPE(8, 1, 2, 7), RS_SHAPE(8, 1, 4, 7),
     // wide outputs: 4 x 2 waves
-    RS_SHAPE(4, 2, 2, 2), RS_SHAPE(4, 2, 4, 2), RS_SHAPE(4, 2, 2, 3), RS_SHAPE(4, 2, 4, 3),
-    RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 4, 4), RS_SHAPE(4, 2, 2, 5), RS_SHAPE(4, 2, 4, 5),
-    RS_SHAPE(4, 2, 2, 6), RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 2, 7), RS_SHAPE(4, 2, 4, 7),
+    RS_SHAPE(4, 2, 4, 2), RS_SHAPE(4, 2, 4, 3), RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 4, 4),
+    RS_SHAPE(4, 2, 4, 5), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 4, 7),
     RS_SHAPE(4, 2, 2, 8),
     // short batches (few rows): 2 x 4 waves
     RS_SHAPE(2, 4, 2, 2), RS_SHAPE(2, 4, 2, 4), RS_SHAPE(2, 4, 1, 4),
@@ -302,7 +353,7 @@ int conv_f32_max_bn() { return 256; }
 int conv_f32_kc_max() { return kKcMax; }
 
 int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
-                    int layer_index, int num_cu, hipStream_t st, int* bm_out, int* bn_out) {
+                    int layer_index, int num_cu, const float* d_zero, hipStream_t st, int* bm_out, int* bn_out) {
     const ConvPlan& p = L.plan;
     if (p.kc < 4 || p.kc > kKcMax || (p.kc & 3)) {
         set_error("conv_f32: unsupported channel chunk %d", p.kc);
@@ -326,8 +377,10 @@ int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const i
     a.bias = L.d_bias;
     a.y = d_y;
     a.len = d_len;
+    a.zero = d_zero;
     a.rows_in = (int)rows64;
     a.P_out = P_in / 2;
+    a.inv_P_out = 1.0f / (float)a.P_out;
     a.cp_in = L.cp_in;
     a.cp_out = L.cp_out;
     a.kc = p.kc;
@@ -336,11 +389,12 @@ int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const i
     a.n_mtiles = (a.rows_in + BM - 1) / BM;
     a.n_ntiles = (n16 * 16 + BN - 1) / BN;
     const size_t lds = lds_bytes(*s, p.kc);
-    RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s->fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+    KernelFn fn = s->fn[p.kc == 16 ? 1 : p.kc == 20 ? 2 : p.kc == 24 ? 3 : 0];
+    RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
     const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-    hipLaunchKernelGGL(s->fn, dim3(grid), dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds, st, a);
     RS_HIP(hipGetLastError());
     if (bm_out) *bm_out = BM;
     if (bn_out) *bn_out = BN;
