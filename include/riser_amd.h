@@ -47,7 +47,8 @@ typedef enum rs_status {
 /* arithmetic type of the conv stack (accumulation is always fp32) */
 typedef enum rs_dtype {
     RS_F32 = 0,             /* f32-input MFMA (v_mfma_f32_16x16x4_f32): exact fmaf chains */
-    RS_BF16 = 1             /* bf16 activations/weights, v_mfma_f32_16x16x32_bf16, fp32 accumulate */
+    RS_BF16 = 1,            /* bf16 activations/weights, v_mfma_f32_16x16x32_bf16, fp32 accumulate */
+    RS_F16 = 2              /* f16 activations/weights, v_mfma_f32_16x16x32_f16, fp32 accumulate */
 } rs_dtype;
 
 /* decisions of riser/control.py:75-82, as written into rs_decide's output */

@@ -58,7 +58,7 @@ namespace {
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
-int esize(const rs_model* m) { return m->dtype == RS_BF16 ? 2 : 4; }
+int esize(const rs_model* m) { return m->dtype == RS_F32 ? 4 : 2; }
 
 // ---- static part of the plan: the K chunking (fixes the weight packing) -------------------------
 // kc minimises nch * (3*kc/4 + 0.75) k-steps (0.75 step ~ the per-item barrier + LDS write);
@@ -119,6 +119,15 @@ void prof_mark(rs_model* m, int stage, hipStream_t st) {
     if (stage < 0) ++m->prof_calls;
 }
 
+// fp32 -> bf16 / f16 bits, round to nearest even (host side, weight packing)
+unsigned short to_h16(float f, int dtype) {
+    if (dtype == RS_F16) return __builtin_bit_cast(unsigned short, (_Float16)f);
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
 template <class T>
 int upload(T** dptr, const std::vector<T>& h) {
     RS_HIP(hipMalloc(reinterpret_cast<void**>(dptr), std::max<size_t>(h.size(), 1) * sizeof(T)));
@@ -156,8 +165,8 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         set_error("rs_model_create: n_classes must be 2 (got %d)", n_classes);
         return RS_ERR_ARG;
     }
-    if (dtype != RS_F32) {
-        set_error("rs_model_create: dtype %d not available in this build", dtype);
+    if (dtype != RS_F32 && dtype != RS_BF16 && dtype != RS_F16) {
+        set_error("rs_model_create: unknown dtype %d", dtype);
         return RS_ERR_ARG;
     }
     for (int i = 0; i < n_layers; ++i)
@@ -181,7 +190,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
     m->n_layers = n_layers;
     for (int i = 0; i < n_layers; ++i) {
         m->channels[i] = channels[i];
-        m->cp[i] = round_up(channels[i], 4);
+        m->cp[i] = round_up(channels[i], dtype == RS_F32 ? 4 : 8);
     }
     int rc = RS_OK;
     {   // layer 0: (w0, w1, w2, bias) per output channel
@@ -200,20 +209,41 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         L.c_out = channels[i];
         L.cp_in = m->cp[i - 1];
         L.cp_out = m->cp[i];
-        L.plan = plan_static_f32(L.cp_in, L.c_out);
+        if (dtype == RS_F32) {
+            L.plan = plan_static_f32(L.cp_in, L.c_out);
+            const ConvPlan& p = L.plan;
+            std::vector<float> wp((size_t)p.n_alloc * p.nch * 3 * p.kc, 0.0f);
+            for (int n = 0; n < L.c_out; ++n)
+                for (int ci = 0; ci < L.c_in; ++ci) {
+                    const int c = ci / p.kc, cc = ci - c * p.kc;
+                    for (int kw = 0; kw < 3; ++kw)
+                        wp[(((size_t)n * p.nch + c) * 3 + kw) * p.kc + cc] =
+                            conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw];
+                }
+            float* dw = nullptr;
+            rc = upload(&dw, wp);
+            L.d_w = dw;
+        } else {
+            // 16-bit: panels of 32 input channels, packed [panel][tap][n_alloc][32]
+            ConvPlan& p = L.plan;
+            p.kc = 32;
+            p.nch = (L.cp_in + 31) / 32;
+            p.n_alloc = round_up(L.c_out, 16) + conv_h16_max_bn();
+            std::vector<unsigned short> wp((size_t)p.nch * 3 * p.n_alloc * 32, 0);
+            for (int n = 0; n < L.c_out; ++n)
+                for (int ci = 0; ci < L.c_in; ++ci) {
+                    const int pn = ci / 32, cc = ci - pn * 32;
+                    for (int kw = 0; kw < 3; ++kw)
+                        wp[(((size_t)pn * 3 + kw) * p.n_alloc + n) * 32 + cc] =
+                            to_h16(conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw], dtype);
+                }
+            unsigned short* dw = nullptr;
+            rc = upload(&dw, wp);
+            L.d_w = dw;
+        }
         const ConvPlan& p = L.plan;
-        std::vector<float> wp((size_t)p.n_alloc * p.nch * 3 * p.kc, 0.0f);
-        for (int n = 0; n < L.c_out; ++n)
-            for (int ci = 0; ci < L.c_in; ++ci) {
-                const int c = ci / p.kc, cc = ci - c * p.kc;
-                for (int kw = 0; kw < 3; ++kw)
-                    wp[(((size_t)n * p.nch + c) * 3 + kw) * p.kc + cc] = conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw];
-            }
         std::vector<float> bp((size_t)p.n_alloc, 0.0f);
         for (int n = 0; n < L.c_out; ++n) bp[n] = conv_b[i][n];
-        float* dw = nullptr;
-        rc = upload(&dw, wp);
-        L.d_w = dw;
         if (rc == RS_OK) rc = upload(&L.d_bias, bp);
     }
     if (rc == RS_OK) rc = upload(&m->d_zero, std::vector<float>(64, 0.0f));
@@ -304,23 +334,26 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(d_ws);
     void* buf[2] = {ws + w.bufa_off, ws + w.bufb_off};
-    const bool bf16 = m->dtype == RS_BF16;
 
     if (!m->prof_on || m->ev_used == 0 || m->ev_stage[m->ev_used - 1] != 0) prof_mark(m, -1, st);
-    int rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], bf16, st);
+    int rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], m->dtype, st);
     if (rc != RS_OK) return rc;
     prof_mark(m, 1, st);
     int cur = 0;
     for (int i = 1; i < m->n_layers; ++i) {
         ConvLayerDev& L = m->layers[i];
         const int P_in = w.P0 >> i;
-        rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len, B,
-                             P_in, i, m->num_cu, m->d_zero, st, &m->last_bm[i], &m->last_bn[i]);
+        if (m->dtype == RS_F32)
+            rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
+                                 B, P_in, i, m->num_cu, m->d_zero, st, &m->last_bm[i], &m->last_bn[i]);
+        else
+            rc = launch_conv_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, m->d_zero,
+                                 m->dtype == RS_F16, st, &m->last_bm[i], &m->last_bn[i]);
         if (rc != RS_OK) return rc;
         prof_mark(m, 1 + i, st);
         cur ^= 1;
     }
-    rc = launch_head(buf[cur], bf16, m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
+    rc = launch_head(buf[cur], m->dtype, m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
                      w.P0 >> m->n_layers, m->n_layers, d_len, B, m->d_fcw, m->d_fcb, d_probs, d_logits, st);
     if (rc == RS_OK) prof_mark(m, m->n_layers + 1, st);
     return rc;

@@ -31,10 +31,10 @@ int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* 
 // layer 0: x fp32 [B, ldx] -> y [B*P1, cp_out] (fp32 or bf16 rows), fused bias+ReLU+maxpool
 int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int P0,
                  const float* d_w4 /* [cp_out][4] = w0,w1,w2,bias */, int cp_out,
-                 void* d_y, bool bf16_out, hipStream_t st);
+                 void* d_y, int dtype, hipStream_t st);
 
 struct ConvPlan {
-    int kc;           // input channels per K chunk (multiple of 4)
+    int kc;           // input channels per K chunk (fp32: multiple of 4; 16-bit: 32 = one MFMA k-step)
     int nch;          // number of chunks: kc * nch >= cp_in
     int n_alloc;      // rows of the packed weight / bias tables (couts + zero rows for any tile width)
 };
@@ -49,10 +49,14 @@ struct ConvLayerDev {
 int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len,
                     int B, int P_in, int layer_index, int num_cu, const float* d_zero, hipStream_t st,
                     int* bm_out, int* bn_out);
+int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
+                    int layer_index, int num_cu, const void* d_zero, bool f16, hipStream_t st, int* bm_out,
+                    int* bn_out);
+int conv_h16_max_bn();
 int conv_f32_max_bn();
 int conv_f32_kc_max();
 
-int launch_head(const void* d_y, bool bf16_in, int cp, int c, int P_last, int n_layers,
+int launch_head(const void* d_y, int dtype, int cp, int c, int P_last, int n_layers,
                 const int32_t* d_len, int B, const float* d_fcw, const float* d_fcb,
                 float* d_probs, float* d_logits, hipStream_t st);
 

@@ -1,0 +1,350 @@
+// K3 (16-bit): one ConvNet block i >= 1 on the bf16 / f16 MFMA (fp32 accumulate).
+//
+// Same lowering as conv_f32.hip (position-major activations, GEMM M = positions, N = output
+// channels, K = 3 * C_in, bias + ReLU + MaxPool fused in registers), re-tiled for a matrix
+// pipe that is 16x faster:
+//   * v_mfma_f32_16x16x32_{bf16,f16}: one k-step consumes 32 input channels of one tap; a lane
+//     holds 8 consecutive channels (16 bytes) of its A row / B column, so fragments are single
+//     ds_read_b128;
+//   * K is cut into PANELS of 32 channels; a work item = (tile, panel) stages a (BM+2) x 64 B
+//     slab of X and a 3 x BN x 64 B slab of weights; the three taps read the same X slab at
+//     row offsets 0 / 1 / 2;
+//   * 64-byte LDS rows are XOR-swizzled at 16-byte granularity, phys_slot = slot ^ (2 *
+//     ((row >> 2) & 1)): found by exhaustive search to make the ds_read_b128 lane groups of
+//     gfx950 ({0-3,12-15,20-27}, ...) conflict-free for all three tap shifts at once;
+//   * persistent 8-wave workgroups, double-buffered LDS, register prefetch of item k+1 issued
+//     above the MFMA block of item k (unconditional loads, zero page for masked units).
+// Channels are padded to 8 in HBM (16-byte rows pieces) and to 32 in K (zero weights).
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace rs {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 512;
+
+struct ConvHArgs {
+    const unsigned short* x;
+    const unsigned short* w;   // packed [panel][tap][n_alloc][32]
+    const float* bias;         // [n_alloc]
+    unsigned short* y;
+    const int32_t* len;
+    const unsigned short* zero;
+    int rows_in;
+    int P_out;
+    float inv_P_out;
+    int cp_in, cp_out;
+    int n_panels;
+    int n_alloc;
+    int shift_out;
+    int n_mtiles, n_ntiles;
+};
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
+                                                      0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                       c, 0, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ unsigned short cvt16(float f) {
+    if constexpr (F16)
+        return __builtin_bit_cast(unsigned short, (_Float16)f);
+    else
+        return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
+
+template <int WM, int WN, int MT, int NT, bool F16>
+__global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a) {
+    static_assert(WM * WN == 8, "8 waves per workgroup");
+    constexpr int BM = WM * 16 * MT;
+    constexpr int BN = WN * 16 * NT;
+    constexpr int A_BYTES = (BM + 2) * 64;
+    constexpr int BUF_BYTES = A_BYTES + 3 * BN * 64;
+    constexpr int A_UNITS = (BM + 2) * 4;
+    constexpr int B_UNITS = 3 * BN * 4;
+    constexpr int A_PER = (A_UNITS + kThreads - 1) / kThreads;
+    constexpr int B_PER = (B_UNITS + kThreads - 1) / kThreads;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int r = lane & 15, g = lane >> 4;
+
+    // ---- per-thread staging map ------------------------------------------------------------------
+    int a_lds[A_PER], a_key[A_PER];            // key = row * 4 + slot, -1 if unused
+    int b_lds[B_PER], b_g[B_PER];              // b_g: element offset inside one panel's weights, -1 if unused
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+        const int f = tid + u * kThreads;
+        const int row = f >> 2, c = f & 3;
+        a_lds[u] = row * 64 + ((c ^ swz(row)) << 4);
+        a_key[u] = f < A_UNITS ? f : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < B_PER; ++u) {
+        const int f = tid + u * kThreads;
+        const int tap = f / (BN * 4), rem = f - tap * (BN * 4);
+        const int n = rem >> 2, c = rem & 3;
+        b_lds[u] = A_BYTES + (tap * BN + n) * 64 + ((c ^ swz(n)) << 4);
+        b_g[u] = f < B_UNITS ? (tap * a.n_alloc + n) * 32 + 8 * c : -1;
+    }
+
+    u32x4 ra[A_PER], rb[B_PER];
+    auto load_item = [&](int m0, int n0, int p, bool live) {
+        const unsigned short* xb = a.x + (int64_t)(m0 - 1) * a.cp_in + p * 32;
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u) {
+            const int key = a_key[u];
+            const int row = key >> 2, c = key & 3;
+            const int gr = m0 - 1 + row;
+            const bool ok = live && key >= 0 && gr >= 0 && gr < a.rows_in && p * 32 + 8 * c < a.cp_in;
+            const unsigned short* src = ok ? xb + (int64_t)row * a.cp_in + 8 * c : a.zero;
+            ra[u] = *reinterpret_cast<const u32x4*>(src);
+        }
+        const unsigned short* wb = a.w + ((int64_t)p * 3 * a.n_alloc + n0) * 32;
+#pragma unroll
+        for (int u = 0; u < B_PER; ++u) {
+            const unsigned short* src = (live && b_g[u] >= 0) ? wb + b_g[u] : a.zero;
+            rb[u] = *reinterpret_cast<const u32x4*>(src);
+        }
+    };
+    auto store_item = [&](unsigned char* buf) {
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u)
+            if (a_key[u] >= 0) *reinterpret_cast<u32x4*>(buf + a_lds[u]) = ra[u];
+#pragma unroll
+        for (int u = 0; u < B_PER; ++u)
+            if (b_g[u] >= 0) *reinterpret_cast<u32x4*>(buf + b_lds[u]) = rb[u];
+    };
+
+    const int tiles = a.n_mtiles * a.n_ntiles;
+    const int nwg = gridDim.x;
+    int o = (nwg & 7) == 0 ? (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    if (o >= tiles) return;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int p = 0;
+    int ntile = o / a.n_mtiles;
+    int m0 = (o - ntile * a.n_mtiles) * BM, n0 = ntile * BN;
+    load_item(m0, n0, 0, true);
+    store_item(lds);
+    __syncthreads();
+    int buf = 0;
+
+    // fragment read addresses: slab row of lane = wm*16*MT + i*16 + r + tap (A), wn*16*NT + j*16 + r (B)
+    int a_rd[3];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        const int R = wm * 16 * MT + r + tap;
+        a_rd[tap] = R * 64 + ((g ^ swz(R)) << 4);
+    }
+    const int b_rd = A_BYTES + (wn * 16 * NT + r) * 64 + ((g ^ swz(r)) << 4);
+
+    while (true) {
+        int np = p + 1, no = o;
+        if (np == a.n_panels) {
+            np = 0;
+            no = o + nwg;
+        }
+        const bool has_next = no < tiles;
+        int nm0 = m0, nn0 = n0;
+        if (has_next && np == 0) {
+            const int nt_ = no / a.n_mtiles;
+            nm0 = (no - nt_ * a.n_mtiles) * BM;
+            nn0 = nt_ * BN;
+        }
+        load_item(nm0, nn0, np, has_next);
+        __builtin_amdgcn_sched_barrier(0);
+
+        const unsigned char* cur = lds + buf * BUF_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            u32x4 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4*>(cur + a_rd[tap] + i * 16 * 64);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bf[j] = *reinterpret_cast<const u32x4*>(cur + b_rd + (tap * BN + j * 16) * 64);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i], bf[j], acc[i][j]);
+        }
+
+        if (p == a.n_panels - 1) {
+            // ---- epilogue: bias + ReLU + MaxPool(2,2) in registers, masked store ------------------
+            float bias[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bias[j] = a.bias[n0 + (wn * NT + j) * 16 + r];
+            const int pr0 = m0 >> 1;
+            const int b0 = pr0 / a.P_out;
+            const int p0 = pr0 - b0 * a.P_out;
+            int prow_[MT][2], lim_[MT][2], pin_[MT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = m0 + (wm * MT + i) * 16 + 4 * g;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int prow = (row >> 1) + h;
+                    const bool in = 2 * prow < a.rows_in;
+                    const int t = p0 + (prow - pr0);
+                    const int e = (int)(((float)t + 0.5f) * a.inv_P_out);
+                    const int b = in ? b0 + e : 0;
+                    prow_[i][h] = in ? prow : -1;
+                    pin_[i][h] = t - e * a.P_out;
+                    lim_[i][h] = a.len[b];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int prow = prow_[i][h];
+                    if (prow >= 0) {
+                        const bool valid = pin_[i][h] < (lim_[i][h] >> a.shift_out);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const int col = n0 + (wn * NT + j) * 16 + r;
+                            if (col < a.cp_out) {
+                                const float v =
+                                    fmaxf(fmaxf(acc[i][j][2 * h], acc[i][j][2 * h + 1]) + bias[j], 0.0f);
+                                a.y[(int64_t)prow * a.cp_out + col] = valid ? cvt16<F16>(v) : (unsigned short)0;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (!has_next) break;
+        store_item(lds + (buf ^ 1) * BUF_BYTES);
+        __syncthreads();
+        buf ^= 1;
+        o = no;
+        p = np;
+        m0 = nm0;
+        n0 = nn0;
+    }
+}
+
+using KernelFn = void (*)(const ConvHArgs);
+
+struct Shape {
+    int wm, wn, mt, nt;
+    KernelFn fn[2];        // bf16, f16
+};
+
+#define RS_SHAPE(WM, WN, MT, NT) \
+    {WM, WN, MT, NT, {conv_h16_kernel<WM, WN, MT, NT, false>, conv_h16_kernel<WM, WN, MT, NT, true>}}
+const Shape kShapes[] = {
+    RS_SHAPE(8, 1, 4, 2), RS_SHAPE(8, 1, 4, 3), RS_SHAPE(8, 1, 2, 5), RS_SHAPE(8, 1, 4, 5), RS_SHAPE(8, 1, 2, 7),
+    RS_SHAPE(8, 1, 4, 7), RS_SHAPE(4, 2, 4, 2), RS_SHAPE(4, 2, 4, 3), RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 4, 4),
+    RS_SHAPE(4, 2, 4, 5), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 4, 7), RS_SHAPE(4, 2, 2, 8),
+    RS_SHAPE(2, 4, 2, 2), RS_SHAPE(2, 4, 2, 4), RS_SHAPE(2, 4, 1, 4),
+};
+#undef RS_SHAPE
+constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
+
+size_t lds_bytes(const Shape& s) {
+    const int bm = s.wm * 16 * s.mt, bn = s.wn * 16 * s.nt;
+    return 2 * (size_t)((bm + 2) + 3 * bn) * 64;
+}
+
+// cost model in SIMD cycles: MFMA issue (2 waves share a SIMD, 16 cycles per 16x16x32), LDS
+// fragment traffic (256 B/clk per CU shared by 8 waves), L2->LDS staging per item, fixed
+// per-item and per-tile overheads
+const Shape* choose_shape(int64_t rows, int n16, int n_panels, int num_cu) {
+    const Shape* best = nullptr;
+    double best_cost = 1e300;
+    for (int k = 0; k < kNumShapes; ++k) {
+        const Shape& s = kShapes[k];
+        if (lds_bytes(s) > 160 * 1024) continue;
+        const int bm = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
+        const int64_t mtiles = (rows + bm - 1) / bm;
+        const int64_t ntiles = (n16 + bnt - 1) / bnt;
+        const int64_t tiles = mtiles * ntiles;
+        const int64_t rounds = (tiles + num_cu - 1) / num_cu;
+        const double mfma = 3.0 * 2.0 * s.mt * s.nt * 16.0;
+        const double ldsr = 3.0 * 8.0 * (s.mt + s.nt) * 1024.0 / 256.0 * 1.3;
+        const double stage = ((bm + 2) + 3.0 * bnt * 16) * 64.0 / 24.0;      // ~24 B/clk/CU from L2
+        const double item = std::max(std::max(mfma, ldsr), stage) + 500.0;
+        const double tile = n_panels * item + 2000.0 + 30.0 * s.mt * s.nt;
+        const double cost = (double)rounds * tile;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = &s;
+        }
+    }
+    return best;
+}
+
+}  // namespace
+
+int conv_h16_max_bn() { return 256; }
+
+int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
+                    int layer_index, int num_cu, const void* d_zero, bool f16, hipStream_t st, int* bm_out,
+                    int* bn_out) {
+    const int64_t rows64 = (int64_t)B * P_in;
+    if (rows64 > 0x7fffffff) {
+        set_error("conv_h16: batch too large (%lld rows)", (long long)rows64);
+        return RS_ERR_ARG;
+    }
+    const int n16 = round_up(L.c_out, 16) / 16;
+    const Shape* s = choose_shape(rows64, n16, L.plan.nch, num_cu);
+    if (!s) {
+        set_error("conv_h16: no tile shape fits");
+        return RS_ERR_ARG;
+    }
+    const int BM = s->wm * 16 * s->mt, BN = s->wn * 16 * s->nt;
+    ConvHArgs a;
+    a.x = static_cast<const unsigned short*>(d_x);
+    a.w = static_cast<const unsigned short*>(L.d_w);
+    a.bias = L.d_bias;
+    a.y = static_cast<unsigned short*>(d_y);
+    a.len = d_len;
+    a.zero = static_cast<const unsigned short*>(d_zero);
+    a.rows_in = (int)rows64;
+    a.P_out = P_in / 2;
+    a.inv_P_out = 1.0f / (float)a.P_out;
+    a.cp_in = L.cp_in;
+    a.cp_out = L.cp_out;
+    a.n_panels = L.plan.nch;
+    a.n_alloc = L.plan.n_alloc;
+    a.shift_out = layer_index + 1;
+    a.n_mtiles = (a.rows_in + BM - 1) / BM;
+    a.n_ntiles = (n16 * 16 + BN - 1) / BN;
+    KernelFn fn = s->fn[f16 ? 1 : 0];
+    RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes(*s), st, a);
+    RS_HIP(hipGetLastError());
+    if (bm_out) *bm_out = BM;
+    if (bn_out) *bn_out = BN;
+    return RS_OK;
+}
+
+}  // namespace rs

@@ -3,58 +3,82 @@
 // accesses, one pass over their input.
 #include "common.hpp"
 
-#include <hip/hip_bf16.h>
-
 namespace rs {
 namespace {
 
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    return __builtin_bit_cast(unsigned short, __float2bfloat16(f));
+// DT: 0 = fp32, 1 = bf16, 2 = f16 (rs_dtype)
+template <int DT>
+__device__ __forceinline__ unsigned short to16(float f) {
+    if constexpr (DT == 2)
+        return __builtin_bit_cast(unsigned short, (_Float16)f);
+    else
+        return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
-__device__ __forceinline__ float bf2f(unsigned short u) {
-    return __builtin_bit_cast(float, (unsigned)u << 16);
+template <int DT>
+__device__ __forceinline__ float from16(unsigned short u) {
+    if constexpr (DT == 2)
+        return (float)__builtin_bit_cast(_Float16, u);
+    else
+        return __builtin_bit_cast(float, (unsigned)u << 16);
 }
 
 // ---- layer 0 ------------------------------------------------------------------------------
 // ConvNet layer 0 (riser/nets/cnn.py:52-65 with in_channels = 1): Conv1d(1 -> C, k=3, 'same',
-// bias) -> ReLU -> MaxPool1d(2,2).  x is the normalised signal [B, ldx] (zeros beyond each
-// read's length up to P0); y is position-major ("NLC") [B * P1, cp] with P1 = P0 / 2:
-// row b*P1 + p holds the C outputs of pooled position p, zeros for p >= len[b] / 2 (this is
-// what gives the next layer its 'same' zero padding and the per-read halo rows).
-// One thread = one pooled position x 4 channels -> one 16-byte (fp32) / 8-byte (bf16) store;
-// consecutive threads write consecutive addresses.  AI ~ 2.7 flop/B: HBM-bound on the store.
-template <bool BF16>
+// bias) -> ReLU -> MaxPool1d(2,2).  x is the normalised signal [B, ldx]; y is position-major
+// ("NLC") [B * P1, cp] with P1 = P0 / 2: row b*P1 + p holds the C outputs of pooled position
+// p, zeros for p >= len[b] / 2 (this is what gives the next layer its 'same' zero padding and
+// the per-read halo rows).
+// HBM-bound on the store (AI ~ 2.7 flop/B).  A thread owns one 16-byte output piece position
+// (q = 4 fp32 / 8 16-bit channels) for the whole block and keeps those channels' (w0,w1,w2,b)
+// in registers; per iteration the active threads cover `ppi` consecutive pooled positions, so
+// a wave's stores are one contiguous run of 16-byte pieces.  32-bit index arithmetic only.
+constexpr int kC0PosPerBlock = 1024;
+
+template <int DT>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, int64_t ldx,
-                                                    const int32_t* __restrict__ len, int P1, int cq /* cp/4 */,
-                                                    const float4* __restrict__ w4, void* __restrict__ yv,
-                                                    int64_t total) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= total) return;
-    const int q = (int)(g % cq);
-    const int64_t prow = g / cq;
-    const int b = (int)(prow / P1);
-    const int p = (int)(prow - (int64_t)b * P1);
+                                                    const int32_t* __restrict__ len, int P1, int cq, int cp,
+                                                    const float4* __restrict__ w4, void* __restrict__ yv) {
+    constexpr int CH = DT == 0 ? 4 : 8;
+    const int ppi = 256 / cq;                                     // positions per iteration
+    const int tid = threadIdx.x;
+    if (tid >= ppi * cq) return;
+    const int slot = tid / cq, q = tid - slot * cq;
+    const int b = blockIdx.y;
     const int n = len[b];
-    float o[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p < (n >> 1)) {
-        const float* xr = x + (int64_t)b * ldx + 2 * p;
-        const float xm = p > 0 ? xr[-1] : 0.0f;
-        const float x0 = xr[0], x1 = xr[1];
-        const float x2 = (2 * p + 2 < n) ? xr[2] : 0.0f;
+    const int half = n >> 1;
+    float4 w[CH];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 w = w4[q * 4 + j];                       // (w0, w1, w2, bias)
-            const float e = fmaf(w.z, x1, fmaf(w.y, x0, fmaf(w.x, xm, w.w)));
-            const float f = fmaf(w.z, x2, fmaf(w.y, x1, fmaf(w.x, x0, w.w)));
-            o[j] = fmaxf(fmaxf(e, f), 0.0f);
+    for (int j = 0; j < CH; ++j) w[j] = w4[q * CH + j];           // (w0, w1, w2, bias)
+    const float* xr0 = x + (int64_t)b * ldx;
+    const int p_begin = blockIdx.x * kC0PosPerBlock;
+    const int p_end = min(p_begin + kC0PosPerBlock, P1);
+    for (int p = p_begin + slot; p < p_end; p += ppi) {
+        float o[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) o[j] = 0.f;
+        if (p < half) {
+            const float* xr = xr0 + 2 * p;
+            const float xm = p > 0 ? xr[-1] : 0.0f;
+            const float x0 = xr[0], x1 = xr[1];
+            const float x2 = (2 * p + 2 < n) ? xr[2] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const float e = fmaf(w[j].z, x1, fmaf(w[j].y, x0, fmaf(w[j].x, xm, w[j].w)));
+                const float f = fmaf(w[j].z, x2, fmaf(w[j].y, x1, fmaf(w[j].x, x0, w[j].w)));
+                o[j] = fmaxf(fmaxf(e, f), 0.0f);
+            }
         }
-    }
-    if (BF16) {
-        ushort4 v;
-        v.x = f2bf(o[0]); v.y = f2bf(o[1]); v.z = f2bf(o[2]); v.w = f2bf(o[3]);
-        reinterpret_cast<ushort4*>(yv)[g] = v;
-    } else {
-        reinterpret_cast<float4*>(yv)[g] = make_float4(o[0], o[1], o[2], o[3]);
+        const int64_t piece = ((int64_t)b * P1 + p) * cq + q;     // 16-byte piece index
+        if constexpr (DT != 0) {
+            uint4 v;
+            v.x = to16<DT>(o[0]) | ((unsigned)to16<DT>(o[1]) << 16);
+            v.y = to16<DT>(o[2]) | ((unsigned)to16<DT>(o[3]) << 16);
+            v.z = to16<DT>(o[4]) | ((unsigned)to16<DT>(o[5]) << 16);
+            v.w = to16<DT>(o[6]) | ((unsigned)to16<DT>(o[7]) << 16);
+            reinterpret_cast<uint4*>(yv)[piece] = v;
+        } else {
+            reinterpret_cast<float4*>(yv)[piece] = make_float4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 
@@ -62,7 +86,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
 // AdaptiveAvgPool1d(1) -> Flatten -> Linear(C, 2) (riser/nets/cnn.py:28-33) -> softmax
 // (riser/model.py:27).  One wave per read: lanes stride over channels, the mean is over the
 // len >> n_layers valid rows of the read's slot in the last activation buffer.
-template <bool BF16>
+template <int DT>
 __global__ __launch_bounds__(64) void head_kernel(const void* __restrict__ yv, int cp, int c, int P_last,
                                                   int n_layers, const int32_t* __restrict__ len,
                                                   const float* __restrict__ fcw, const float* __restrict__ fcb,
@@ -75,7 +99,10 @@ __global__ __launch_bounds__(64) void head_kernel(const void* __restrict__ yv, i
         float s = 0.f;
         for (int t = 0; t < rows; ++t) {
             const int64_t idx = ((int64_t)b * P_last + t) * cp + ch;
-            s += BF16 ? bf2f(reinterpret_cast<const unsigned short*>(yv)[idx]) : reinterpret_cast<const float*>(yv)[idx];
+            if constexpr (DT != 0)
+                s += from16<DT>(reinterpret_cast<const unsigned short*>(yv)[idx]);
+            else
+                s += reinterpret_cast<const float*>(yv)[idx];
         }
         const float m = s * inv;
         a0 = fmaf(m, fcw[ch], a0);
@@ -129,28 +156,26 @@ __global__ __launch_bounds__(256) void decide_kernel(const float* __restrict__ p
 }  // namespace
 
 int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int P0, const float* d_w4,
-                 int cp_out, void* d_y, bool bf16_out, hipStream_t st) {
-    const int P1 = P0 / 2, cq = cp_out / 4;
-    const int64_t total = (int64_t)B * P1 * cq;
-    const unsigned grid = (unsigned)((total + 255) / 256);
-    if (bf16_out)
-        hipLaunchKernelGGL(conv0_kernel<true>, dim3(grid), dim3(256), 0, st, d_x, ldx, d_len, P1, cq,
-                           reinterpret_cast<const float4*>(d_w4), d_y, total);
-    else
-        hipLaunchKernelGGL(conv0_kernel<false>, dim3(grid), dim3(256), 0, st, d_x, ldx, d_len, P1, cq,
-                           reinterpret_cast<const float4*>(d_w4), d_y, total);
+                 int cp_out, void* d_y, int dtype, hipStream_t st) {
+    const int P1 = P0 / 2;
+    const int cq = cp_out / (dtype == RS_F32 ? 4 : 8);            // 16-byte pieces per output row
+    if (cq < 1 || cq > 256) {
+        set_error("conv0: unsupported first-layer width %d", cp_out);
+        return RS_ERR_ARG;
+    }
+    dim3 grid((P1 + kC0PosPerBlock - 1) / kC0PosPerBlock, B);
+    auto fn = dtype == RS_F16 ? conv0_kernel<2> : dtype == RS_BF16 ? conv0_kernel<1> : conv0_kernel<0>;
+    hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, d_x, ldx, d_len, P1, cq, cp_out,
+                       reinterpret_cast<const float4*>(d_w4), d_y);
     RS_HIP(hipGetLastError());
     return RS_OK;
 }
 
-int launch_head(const void* d_y, bool bf16_in, int cp, int c, int P_last, int n_layers, const int32_t* d_len,
+int launch_head(const void* d_y, int dtype, int cp, int c, int P_last, int n_layers, const int32_t* d_len,
                 int B, const float* d_fcw, const float* d_fcb, float* d_probs, float* d_logits, hipStream_t st) {
-    if (bf16_in)
-        hipLaunchKernelGGL(head_kernel<true>, dim3(B), dim3(64), 0, st, d_y, cp, c, P_last, n_layers, d_len, d_fcw,
-                           d_fcb, d_probs, d_logits);
-    else
-        hipLaunchKernelGGL(head_kernel<false>, dim3(B), dim3(64), 0, st, d_y, cp, c, P_last, n_layers, d_len, d_fcw,
-                           d_fcb, d_probs, d_logits);
+    auto fn = dtype == RS_F16 ? head_kernel<2> : dtype == RS_BF16 ? head_kernel<1> : head_kernel<0>;
+    hipLaunchKernelGGL(fn, dim3(B), dim3(64), 0, st, d_y, cp, c, P_last, n_layers, d_len, d_fcw, d_fcb, d_probs,
+                       d_logits);
     RS_HIP(hipGetLastError());
     return RS_OK;
 }

@@ -241,6 +241,60 @@ def test_small_custom_network(dev):
 
 
 # ------------------------------------------------------------------------------------------
+# 16-bit conv variants (BASELINE configs 3 / 5): fp32 accumulate, 16-bit activations + weights
+# ------------------------------------------------------------------------------------------
+H16_TOL = {"f16": 2e-2, "bf16": 1.5e-1}     # measured: 7e-3 / 6e-2 worst over 512 reads
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_h16_forward_vs_reference(dev, golden_dir, dtype):
+    """probabilities of the 16-bit paths against the reference's fp32 golden values; label flips
+    at 0.9 are counted and must stay rare and confined to reads within the tolerance of 0.9."""
+    from riser_amd.model import Model
+    net = np.load(os.path.join(golden_dir, "network.npz"))
+    tol = H16_TOL[dtype]
+    models = {}
+    worst, flips, total = 0.0, 0, 0
+    for seed, L, B, first in net["cases"]:
+        tag = f"s{seed}_L{L}_B{B}_r{first}"
+        seed = int(seed)
+        if seed not in models:
+            models[seed] = Model(synth.make_state_dict(seed), synth.Config(), None, "m", dtype=dtype, device=dev)
+        sigs = synth.make_signals(int(net["sig_seed"][0]), int(B), int(L), first_read=int(first))
+        xs = [ro.mad_normalise(s) for s in sigs]
+        probs = models[seed].classify_batch(xs).cpu().numpy()
+        want = net[f"{tag}.probs"]
+        assert np.isfinite(probs).all()
+        err = np.abs(probs - want).max(axis=1)
+        worst = max(worst, float(err.max()))
+        assert err.max() < tol, (tag, float(err.max()))
+        fl = (probs[:, 1] > 0.9) != (want[:, 1] > 0.9)
+        assert (np.abs(want[fl, 1] - 0.9) < tol).all(), "a flipped label must sit within tol of the threshold"
+        flips += int(fl.sum())
+        total += len(fl)
+    print(f"{dtype}: worst |dp| {worst:.2e}, label flips {flips}/{total}")
+    assert flips <= max(2, total // 25)
+    for m in models.values():
+        m.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_h16_mixed_lengths_and_determinism(dev, dtype):
+    from riser_amd.model import Model
+    m = Model(synth.make_state_dict(2), synth.Config(), None, "m", dtype=dtype, device=dev)
+    lens = [4096, 4097, 5000, 6024, 8000, 8615, 12000, 16000, 16001, 20000]
+    sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=300 + i)[0] for i, n in enumerate(lens)]
+    xs = [ro.mad_normalise(s) for s in sigs]
+    want = np.stack([ro.classify(synth.make_state_dict(2), x) for x in xs])
+    got = m.classify_batch(xs).cpu().numpy()
+    assert np.abs(got - want).max() < H16_TOL[dtype]
+    perm = np.random.default_rng(1).permutation(len(xs))
+    assert np.array_equal(m.classify_batch([xs[i] for i in perm]).cpu().numpy(), got[perm])
+    assert np.array_equal(m.classify_batch([xs[3]]).cpu().numpy()[0], got[3])
+    m.close()
+
+
+# ------------------------------------------------------------------------------------------
 # decision + control loop
 # ------------------------------------------------------------------------------------------
 def test_decide_matches_reference_rule(dev):
