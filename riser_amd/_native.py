@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libriser_amd.so")
+LIB_PATH = os.environ.get("RISER_AMD_LIB") or os.path.join(_HERE, "lib", "libriser_amd.so")
 
 RS_OK = 0
 RS_F32, RS_BF16, RS_F16 = 0, 1, 2

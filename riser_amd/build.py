@@ -41,7 +41,13 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), lib_name: str = None) -> str:
+    """extra_flags / lib_name build a diagnostic variant next to the shipped library."""
+    global OBJDIR, LIB
+    if lib_name:
+        OBJDIR = os.path.join(HERE, "csrc", "build_" + lib_name)
+        LIB = os.path.join(LIBDIR, f"lib{lib_name}.so")
+        force = True
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
@@ -55,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([hipcc, *FLAGS, *extra_flags, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -74,4 +80,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--item-stamps" in sys.argv:          # diagnostic variant, loaded with RISER_AMD_LIB=...
+        print(build(extra_flags=["-DRS_ITEM_STAMPS"], lib_name="riser_amd_stamps", verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

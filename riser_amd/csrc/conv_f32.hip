@@ -28,14 +28,34 @@
 // with ds_read_b32 then fall in 32 distinct banks.
 #include "common.hpp"
 
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include <algorithm>
+#include <vector>
 
 namespace rs {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 512;
+// Diagnostic build only (-DRS_ITEM_STAMPS): per-phase s_memtime sums of one item loop, written to
+// ConvArgs::stamps[2048 + ...]; never compiled into the shipped library.
+#ifdef RS_ITEM_STAMPS
+#define RS_STAMP(k)                                                                  \
+    do {                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        unsigned long long t__;                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");  \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        ph[k] += t__ - tl;                                                           \
+        tl = t__;                                                                    \
+    } while (0)
+#else
+#define RS_STAMP(k) do { } while (0)
+#endif
+
 constexpr int kKcMax = 24;                  // bounds the per-thread staging registers
 
 struct ConvArgs {
@@ -52,14 +72,16 @@ struct ConvArgs {
     int kc, nch;
     int shift_out;         // valid output rows of read b: len[b] >> shift_out
     int n_mtiles, n_ntiles;
+    unsigned long long* stamps;   // diagnostic (RS_CONV_STAMPS=1): per block {memtime, memrealtime} at entry / exit
 };
 
 // KCT > 0: the channel chunk is a compile-time constant, so every LDS fragment address in the
 // MFMA loop is "per-item base register + immediate" and the loop is fully unrolled (no address
 // VALU between MFMAs).  KCT == 0: generic fallback with the chunk taken from ConvArgs.
 template <int WM, int WN, int MT, int NT, int KCT>
-__global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a) {
-    static_assert(WM * WN == 8, "8 waves per workgroup");
+__global__ __launch_bounds__(WM * WN * 64) void conv_f32_kernel(const ConvArgs a) {
+    static_assert(WM * WN == 8 || WM * WN == 4, "8 waves (2 per SIMD) or 4 waves (1 per SIMD)");
+    constexpr int kThreads = WM * WN * 64;
     constexpr int BM = WM * 16 * MT;
     constexpr int BN = WN * 16 * NT;
     constexpr int KCB = KCT ? KCT : kKcMax;                    // bound for the staging registers
@@ -149,6 +171,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a)
     const int nwg = gridDim.x;
     int o = (nwg & 7) == 0 ? (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     if (o >= tiles) return;
+    if (a.stamps && tid == 0) {
+        a.stamps[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        a.stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -167,7 +193,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a)
     const int a_rd = (wm * 16 * MT + r) * S + kq;              // + i*16*S + kw*S + c0
     const int b_rd = a_elems + (wn * 16 * NT + r) * 3 * S + kq;   // + j*48*S + kw*S + c0
 
+#ifdef RS_ITEM_STAMPS
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+    int n_items = 0;
+#endif
     while (true) {
+        RS_STAMP(0);                                               // barrier exit -> loop top
         int nc = c + 1, no = o;
         if (nc == a.nch) {
             nc = 0;
@@ -180,31 +211,67 @@ __global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a)
             nm0 = (no - nt_ * a.n_mtiles) * BM;
             nn0 = nt_ * BN;
         }
-        // always issued (the last item prefetches the zero page): no branch around the loads, so
-        // they stay in flight under the MFMAs below
-        load_item(nm0, nn0, nc, has_next);
-        __builtin_amdgcn_sched_barrier(0);                      // keep the loads ABOVE the MFMA block
-
         const float* Ab = lds + buf * buf_elems + a_rd;
         const float* Bb = lds + buf * buf_elems + b_rd;
         if constexpr (KCT > 0) {
+            // Fully unrolled k-steps.  The next item's global loads (address VALU + 16-byte loads)
+            // are issued after the first k-step and its LDS writes before the last one, i.e. in
+            // the shadow of queued MFMAs rather than in the bubble around the barrier where both
+            // waves of a SIMD would do them at the same time.  The loads are unconditional (the
+            // last item prefetches the zero page) so nothing makes hipcc drain vmcnt early.
+            constexpr int KQ = KCT / 4, NSTEPS = 3 * KQ;
+            // the two waves of a SIMD (wave w and w + 4 under the usual 0,2,1,3 SIMD assignment)
+            // are staggered: the first group prefetches after k-step 0 and stores at 2/3 of the
+            // block, the second group prefetches at 1/3 and stores just before the end, so that
+            // one wave's VALU / VMEM / LDS-write phase overlaps the other's MFMA stream
+            constexpr int LOAD_A = 0, STORE_A = (2 * NSTEPS) / 3, LOAD_B = NSTEPS / 3, STORE_B = NSTEPS - 2;
+            const bool grp_b = __builtin_amdgcn_readfirstlane(wave) >= (WM * WN) / 2;
+            // fragments are double-buffered in registers: the ds_reads of k-step st+1 are issued
+            // before the MFMAs of k-step st, so no MFMA waits on LDS latency
+            float af[2][MT], bf[2][NT];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
+            for (int i = 0; i < MT; ++i) af[0][i] = Ab[i * 16 * (KCT + 2)];
 #pragma unroll
-                for (int c0 = 0; c0 < KCT; c0 += 4) {
-                    float af[MT], bf[NT];
+            for (int j = 0; j < NT; ++j) bf[0][j] = Bb[j * 48 * (KCT + 2)];
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) af[i] = Ab[i * 16 * (KCT + 2) + kw * (KCT + 2) + c0];
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) bf[j] = Bb[j * 48 * (KCT + 2) + kw * (KCT + 2) + c0];
+            for (int st = 0; st < NSTEPS; ++st) {
+                if (st + 1 < NSTEPS) {
+                    const int kw = (st + 1) / KQ, c0 = 4 * ((st + 1) % KQ);
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
+                        af[(st + 1) & 1][i] = Ab[i * 16 * (KCT + 2) + kw * (KCT + 2) + c0];
 #pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j)
+                        bf[(st + 1) & 1][j] = Bb[j * 48 * (KCT + 2) + kw * (KCT + 2) + c0];
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] =
+                            __builtin_amdgcn_mfma_f32_16x16x4f32(af[st & 1][i], bf[st & 1][j], acc[i][j], 0, 0, 0);
+                if ((st == LOAD_A && !grp_b) || (st == LOAD_B && grp_b)) {
+                    RS_STAMP(1);                                   // first k-step
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_item(nm0, nn0, nc, has_next);
+                    __builtin_amdgcn_sched_barrier(0);
+                    RS_STAMP(2);                                   // prefetch issue
+                }
+                if ((st == STORE_A && !grp_b) || (st == STORE_B && grp_b)) {
+                    RS_STAMP(3);                                   // MFMA body
+#ifdef RS_ITEM_STAMPS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    RS_STAMP(6);                                   // pure wait for the prefetch loads
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has_next) store_item(lds + (buf ^ 1) * buf_elems);
+                    __builtin_amdgcn_sched_barrier(0);
+                    RS_STAMP(4);                                   // vmcnt wait + LDS writes
                 }
             }
         } else {
+            load_item(nm0, nn0, nc, has_next);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
             for (int kw = 0; kw < 3; ++kw) {
                 const float* Ak = Ab + kw * S;
@@ -277,8 +344,24 @@ __global__ __launch_bounds__(kThreads, 2) void conv_f32_kernel(const ConvArgs a)
                 for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (!has_next) break;
-        store_item(lds + (buf ^ 1) * buf_elems);
+#ifdef RS_ITEM_STAMPS
+        ++n_items;
+#endif
+        if (!has_next) {
+#ifdef RS_ITEM_STAMPS
+            if (a.stamps && lane == 0 && blockIdx.x < 4) {
+                for (int k = 0; k < 7; ++k) a.stamps[2048 + (blockIdx.x * 8 + wave) * 8 + k] = ph[k];
+                a.stamps[2048 + (blockIdx.x * 8 + wave) * 8 + 7] = n_items;
+            }
+#endif
+            if (a.stamps && tid == 0) {
+                a.stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+                a.stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+            }
+            break;
+        }
+        if constexpr (KCT == 0) store_item(lds + (buf ^ 1) * buf_elems);
+        RS_STAMP(5);                                               // last k-steps (+ epilogue)
         __syncthreads();
         buf ^= 1;
         o = no;
@@ -308,6 +391,8 @@ const Shape kShapes[] = {
     RS_SHAPE(4, 2, 2, 8),
     // short batches (few rows): 2 x 4 waves
     RS_SHAPE(2, 4, 2, 2), RS_SHAPE(2, 4, 2, 4), RS_SHAPE(2, 4, 1, 4),
+    // experimental: 4 waves = one per SIMD
+    RS_SHAPE(4, 1, 4, 8), RS_SHAPE(2, 2, 8, 6), RS_SHAPE(4, 1, 4, 7), RS_SHAPE(4, 1, 4, 5), RS_SHAPE(2, 2, 8, 4),
 };
 #undef RS_SHAPE
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
@@ -324,7 +409,7 @@ const Shape* choose_shape(int64_t rows, int n16 /* couts / 16 */, int kc, int nc
     double best_cost = 1e300;
     for (int k = 0; k < kNumShapes; ++k) {
         const Shape& s = kShapes[k];
-        if (lds_bytes(s, kc) > 160 * 1024) continue;
+        if (lds_bytes(s, kc) > 160 * 1024 || s.wm * s.wn != 8) continue;
         const int bm = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
         const int64_t mtiles = (rows + bm - 1) / bm;
         const int64_t ntiles = (n16 + bnt - 1) / bnt;
@@ -366,6 +451,15 @@ int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const i
     }
     const int n16 = round_up(L.c_out, 16) / 16;
     const Shape* s = choose_shape(rows64, n16, p.kc, p.nch, num_cu, nullptr);
+    if (const char* force = getenv("RS_FORCE_SHAPE_F32")) {         // tuning aid: "layer:wm,wn,mt,nt;..."
+        int l, wm, wn, mt, nt;
+        for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
+            if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
+                for (int k = 0; k < kNumShapes; ++k)
+                    if (kShapes[k].wm == wm && kShapes[k].wn == wn && kShapes[k].mt == mt && kShapes[k].nt == nt &&
+                        lds_bytes(kShapes[k], p.kc) <= 160 * 1024)
+                        s = &kShapes[k];
+    }
     if (!s) {
         set_error("conv_f32: no tile shape fits (kc=%d)", p.kc);
         return RS_ERR_ARG;
@@ -394,8 +488,43 @@ int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const i
                                160 * 1024));
     const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds, st, a);
+    static unsigned long long* d_stamps = nullptr;
+    static const bool want_stamps = getenv("RS_CONV_STAMPS") != nullptr;
+    if (want_stamps && !d_stamps) RS_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), 4096 * 4 * 8));
+    a.stamps = want_stamps ? d_stamps : nullptr;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(s->wm * s->wn * 64), lds, st, a);
     RS_HIP(hipGetLastError());
+    if (want_stamps) {                                              // diagnostic only: synchronises
+        std::vector<unsigned long long> h(grid * 4);
+        RS_HIP(hipStreamSynchronize(st));
+        RS_HIP(hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> clk, dur;
+        for (unsigned k = 0; k < grid; ++k) {
+            const double dt = (double)(h[k * 4 + 2] - h[k * 4 + 0]), dr = (double)(h[k * 4 + 3] - h[k * 4 + 1]);
+            if (dr > 0) {
+                clk.push_back(dt / dr * 100.0);                     // MHz (memrealtime ticks at 100 MHz)
+                dur.push_back(dr / 100.0);                          // us
+            }
+        }
+        std::sort(clk.begin(), clk.end());
+        std::sort(dur.begin(), dur.end());
+#ifdef RS_ITEM_STAMPS
+        {
+            std::vector<unsigned long long> hp(4 * 8 * 8);
+            RS_HIP(hipMemcpy(hp.data(), d_stamps + 2048, hp.size() * 8, hipMemcpyDeviceToHost));
+            for (int w = 0; w < 8; w += 4) {
+                const unsigned long long* q = &hp[w * 8];
+                const double n = (double)q[7];
+                fprintf(stderr, "[item-stamps] layer %d wave %d items %.0f: per item cycles: barrier->top %.0f | step0 %.0f | "
+                        "prefetch issue %.0f | mfma body %.0f | vmcnt wait %.0f | lds store %.0f | tail(+epi) %.0f\n",
+                        layer_index, w, n, q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[6] / n, q[4] / n, q[5] / n);
+            }
+        }
+#endif
+        if (!clk.empty())
+            fprintf(stderr, "[stamps] layer %d tile %dx%d: shader clock median %.0f MHz (min %.0f max %.0f), block time median %.1f us max %.1f us\n",
+                    layer_index, BM, BN, clk[clk.size() / 2], clk.front(), clk.back(), dur[dur.size() / 2], dur.back());
+    }
     if (bm_out) *bm_out = BM;
     if (bn_out) *bn_out = BN;
     return RS_OK;
