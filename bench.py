@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-latency", action="store_true", help="skip the per-batch latency loop (profiling runs)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the f16 / bf16 / ensemble side measurements")
     args = ap.parse_args()
 
     rank, local_rank, world = rdist.env_world()
@@ -171,6 +172,58 @@ def main():
         "latency_note": "host wall time per 512-read batch incl. H2D of int16 signals from pinned memory and D2H of probabilities",
         "roofline": roofline,
     }
+
+    # ---- side measurements on the same batch (rank 0, N = 1 only; not the headline) --------------
+    if world == 1 and not args.no_variants and args.dtype == "f32":
+        ref = probs.cpu().numpy().copy()
+        variants = {}
+        for dt in ("f16", "bf16"):
+            mv = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dt, device=device)
+            pv = torch.empty((B, 2), dtype=torch.float32, device=device)
+            for _ in range(max(2, args.warmup)):
+                mv.classify_raw(sig, off, ln, lens, out=pv)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                mv.classify_raw(sig, off, ln, lens, out=pv)
+            torch.cuda.synchronize(device)
+            dtv = (time.perf_counter() - t1) / args.steps
+            pvh = pv.cpu().numpy()
+            variants[dt] = {"chunks_per_s": round(B / dtv, 1), "ms_per_step": round(dtv * 1e3, 4),
+                            "max_abs_dprob_vs_f32": float(np.abs(pvh - ref).max()),
+                            "label_flips_at_0.9_vs_f32": int(((pvh[:, 1] > 0.9) != (ref[:, 1] > 0.9)).sum()),
+                            "batch": B}
+            mv.close()
+        # BASELINE config 3: three-model ensemble, bf16, normalise once + three forwards + decision
+        from riser_amd.preprocess import Kit, SignalProcessor
+        from riser_amd import _native as nv
+        proc = SignalProcessor(Kit.create_from_version("RNA004"), device=device)
+        ens = [Model(synth.make_state_dict(sd_), synth.Config(), None, t_, dtype="bf16", device=device)
+               for sd_, t_ in ((1, "mRNA"), (2, "mtRNA"), (3, "globin"))]
+        pe = torch.empty((3, B, 2), dtype=torch.float32, device=device)
+        dec = torch.empty(B, dtype=torch.uint8, device=device)
+        P0 = ens[0].padded_length(L)
+
+        def ens_step():
+            x = proc.normalise_device(sig, off, ln, B, L, pad_to=P0)
+            for k, mk in enumerate(ens):
+                mk.forward_batch(x, lens, lens_dev=ln, out=pe[k])
+            nv.check(nv.lib().rs_decide(pe.data_ptr(), 3, B, ln.data_ptr(), L, 0.9, nv.RS_ENRICH, dec.data_ptr(),
+                                        torch.cuda.current_stream(device).cuda_stream), "rs_decide")
+        for _ in range(3):
+            ens_step()
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ens_step()
+        torch.cuda.synchronize(device)
+        dte = (time.perf_counter() - t1) / args.steps
+        variants["ensemble3_bf16"] = {"reads_per_s": round(B / dte, 1), "model_forwards_per_s": round(3 * B / dte, 1),
+                                      "ms_per_step": round(dte * 1e3, 4), "batch": B,
+                                      "accepted": int((dec == 1).sum().item())}
+        for mk in ens:
+            mk.close()
+        out["variants"] = variants
 
     # ---- CPU baseline (rank 0, N = 1 only): oracle port timed on this box's host cores ---------
     if world == 1 and not args.no_cpu_baseline:
