@@ -384,10 +384,10 @@ struct Shape {
 const Shape kShapes[] = {
     // narrow outputs: all 8 waves stacked along rows
     RS_SHAPE(8, 1, 4, 2), RS_SHAPE(8, 1, 4, 3), RS_SHAPE(8, 1, 2, 5), RS_SHAPE(8, 1, 4, 5),
-    RS_SHAPE(8, 1, 2, 7), RS_SHAPE(8, 1, 4, 7),
+    RS_SHAPE(8, 1, 2, 7),
     // wide outputs: 4 x 2 waves
     RS_SHAPE(4, 2, 4, 2), RS_SHAPE(4, 2, 4, 3), RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 4, 4),
-    RS_SHAPE(4, 2, 4, 5), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 4, 7),
+    RS_SHAPE(4, 2, 4, 5), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 2, 7),
     RS_SHAPE(4, 2, 2, 8),
     // short batches (few rows): 2 x 4 waves
     RS_SHAPE(2, 4, 2, 2), RS_SHAPE(2, 4, 2, 4), RS_SHAPE(2, 4, 1, 4),

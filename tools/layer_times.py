@@ -6,7 +6,7 @@ from riser_amd import synth
 from riser_amd.model import Model
 from riser_amd.preprocess import pack_reads
 dt = sys.argv[1] if len(sys.argv) > 1 else "f32"
-B, L = 512, 16000
+B, L = int(os.environ.get("RS_B", 512)), int(os.environ.get("RS_L", 16000))
 sigs = synth.make_signals(20260103, B, L)
 dev = torch.device("cuda", 0)
 sig, off, ln, lens = pack_reads(list(sigs), dev)
