@@ -223,6 +223,24 @@ def main():
                                       "accepted": int((dec == 1).sum().item())}
         for mk in ens:
             mk.close()
+        # BASELINE config 5: progressive 2 s / 3 s / 4 s chunks (8000 / 12000 / 16000 samples in equal
+        # thirds of one batch), f16: per-read lengths are carried through every layer, no bucketing
+        mix_lens = np.array([(8000, 12000, 16000)[i % 3] for i in range(B)], dtype=np.int32)
+        mix_off = torch.from_numpy((np.arange(B, dtype=np.int64) * L)).to(device)
+        mix_len = torch.from_numpy(mix_lens).to(device)
+        mm = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype="f16", device=device)
+        pm = torch.empty((B, 2), dtype=torch.float32, device=device)
+        for _ in range(3):
+            mm.classify_raw(sig, mix_off, mix_len, mix_lens, out=pm)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            mm.classify_raw(sig, mix_off, mix_len, mix_lens, out=pm)
+        torch.cuda.synchronize(device)
+        dtm = (time.perf_counter() - t1) / args.steps
+        variants["mixed_2s_3s_4s_f16"] = {"chunks_per_s": round(B / dtm, 1), "ms_per_step": round(dtm * 1e3, 4),
+                                          "batch": B, "samples_per_step": int(mix_lens.sum())}
+        mm.close()
         out["variants"] = variants
 
     # ---- CPU baseline (rank 0, N = 1 only): oracle port timed on this box's host cores ---------

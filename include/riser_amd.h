@@ -121,8 +121,12 @@ int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
  *             the padded pitch returned by rs_padded_length(m, Lmax) (<= ldx)
  *   d_probs   fp32 [B, 2] = (p_off_target, p_on_target), the order of riser/control.py:69
  *   d_logits  fp32 [B, 2] or NULL
+ *   Lmin      host-known lower bound of d_len (0 if unknown).  Only a speed hint: reads are laid
+ *             out in slots of rs_padded_length(Lmax) rows and tiles that fall entirely into a
+ *             shorter read's padding are skipped; when Lmin says no such tile can exist the
+ *             per-tile test is not even compiled into the walk.
  */
-int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmax,
+int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmin, int Lmax,
                void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream);
 
 /* Row pitch (in samples) the conv stack uses for reads of at most Lmax samples:
@@ -135,7 +139,7 @@ int rs_padded_length(const rs_model* m, int Lmax);
  * batch; the normalised signals live in the workspace.
  */
 int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len,
-                int B, int Lmax, void* d_ws, size_t ws_bytes,
+                int B, int Lmin, int Lmax, void* d_ws, size_t ws_bytes,
                 float* d_probs, float* d_logits, void* stream);
 
 /*

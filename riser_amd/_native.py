@@ -63,9 +63,9 @@ def lib():
     L.rs_normalise.restype = i32
     L.rs_normalise.argtypes = [vp, vp, vp, i32, i32, vp, i64, C.c_int32, vp, i64, vp, vp]
     L.rs_forward.restype = i32
-    L.rs_forward.argtypes = [vp, vp, i64, vp, i32, i32, vp, sz, vp, vp, vp]
+    L.rs_forward.argtypes = [vp, vp, i64, vp, i32, i32, i32, vp, sz, vp, vp, vp]
     L.rs_classify.restype = i32
-    L.rs_classify.argtypes = [vp, vp, vp, vp, i32, i32, vp, sz, vp, vp, vp]
+    L.rs_classify.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp]
     L.rs_decide.restype = i32
     L.rs_decide.argtypes = [vp, i32, i32, vp, i32, C.c_float, i32, vp, vp]
     L.rs_polya_end.restype = i32

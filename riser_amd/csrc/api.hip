@@ -308,8 +308,8 @@ int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
                             static_cast<hipStream_t>(stream));
 }
 
-int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmax, void* d_ws,
-               size_t ws_bytes, float* d_probs, float* d_logits, void* stream) {
+int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmin, int Lmax,
+               void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream) {
     if (!m || !d_x || !d_len || !d_ws || !d_probs || B < 1) {
         set_error("rs_forward: null argument or empty batch");
         return RS_ERR_ARG;
@@ -343,12 +343,15 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
     for (int i = 1; i < m->n_layers; ++i) {
         ConvLayerDev& L = m->layers[i];
         const int P_in = w.P0 >> i;
+        // a tile of >= 64 rows can only be all padding if some read leaves >= 64 rows of its slot
+        // unused at this layer; Lmin == 0 means "unknown": keep the test
+        const int check_dead = (Lmin <= 0 || (w.P0 >> i) - (Lmin >> i) >= 64) ? 1 : 0;
         if (m->dtype == RS_F32)
             rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
-                                 B, P_in, i, m->num_cu, m->d_zero, st, &m->last_bm[i], &m->last_bn[i]);
+                                 B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
         else
             rc = launch_conv_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, m->d_zero,
-                                 m->dtype == RS_F16, st, &m->last_bm[i], &m->last_bn[i]);
+                                 m->dtype == RS_F16, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
         if (rc != RS_OK) return rc;
         prof_mark(m, 1 + i, st);
         cur ^= 1;
@@ -359,8 +362,8 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
     return rc;
 }
 
-int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
-                void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream) {
+int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmin,
+                int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream) {
     if (!m || !d_sig || !d_off || !d_len || !d_ws || !d_probs || B < 1) {
         set_error("rs_classify: null argument or empty batch");
         return RS_ERR_ARG;
@@ -380,7 +383,7 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
                               static_cast<hipStream_t>(stream));
     if (rc != RS_OK) return rc;
     prof_mark(m, 0, static_cast<hipStream_t>(stream));
-    return rs_forward(m, xn, w.P0, d_len, B, Lmax, d_ws, ws_bytes, d_probs, d_logits, stream);
+    return rs_forward(m, xn, w.P0, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs, d_logits, stream);
 }
 
 int rs_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len, float threshold,

@@ -179,7 +179,7 @@ class Model:
         ws = self._ws.get(need)
         probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
         logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
-        nv.check(L.rs_forward(self._h, x.data_ptr(), ldx, lens_dev.data_ptr(), B, lmax, ws.data_ptr(),
+        nv.check(L.rs_forward(self._h, x.data_ptr(), ldx, lens_dev.data_ptr(), B, int(lens_host.min()), lmax, ws.data_ptr(),
                               ws.numel(), probs.data_ptr(), logits.data_ptr() if return_logits else None,
                               _stream_ptr(self.device)), "rs_forward")
         return (probs, logits) if return_logits else probs
@@ -196,7 +196,8 @@ class Model:
         ws = self._ws.get(need)
         probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
         logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
-        nv.check(L.rs_classify(self._h, sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), B, lmax,
+        nv.check(L.rs_classify(self._h, sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), B,
+                               int(lens_host.min()), lmax,
                                ws.data_ptr(), ws.numel(), probs.data_ptr(),
                                logits.data_ptr() if return_logits else None, _stream_ptr(self.device)),
                  "rs_classify")

@@ -50,7 +50,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.rs_workspace_bytes(None, 1, 4096) == 0
     assert lib.rs_padded_length(None, 4096) == 0
     assert lib.rs_decide(None, 0, 4, None, 1, 0.9, 0, None, None) == -1
-    assert lib.rs_forward(None, None, 0, None, 1, 4096, None, 0, None, None, None) == -1
+    assert lib.rs_forward(None, None, 0, None, 1, 4096, 4096, None, 0, None, None, None) == -1
     assert lib.rs_model_destroy(None) == 0
 
 

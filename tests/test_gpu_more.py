@@ -1,0 +1,166 @@
+"""Further GPU checks: state-dict file loading, RNA002 kit control loop against the oracle,
+cache behaviour, randomised property tests."""
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import riser_oracle as ro
+from oracle import torch_path
+from riser_amd import synth
+from riser_amd.fake_client import FakeClient, FakeRead
+
+pytestmark = pytest.mark.gpu
+SIG_SEED = 20260103
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def test_model_loads_pth_like_the_reference(dev, tmp_path):
+    """riser/model.py:19 does torch.load(state); the same file must load here."""
+    from riser_amd.model import Model
+    sd = synth.make_state_dict(2)
+    path = str(tmp_path / "mRNA_model_RNA004_RP4.pth")
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, path)
+    log = logging.getLogger("x")
+    m = Model(path, synth.Config(), log, "mRNA", device=dev)
+    assert m.target == "mRNA" and m.logger is log and m.device.type == "cuda"
+    x = ro.mad_normalise(synth.make_signals(SIG_SEED, 1, 6024, first_read=1)[0])
+    assert np.abs(m.classify(x).cpu().numpy() - ro.classify(sd, x)).max() < 1e-3
+    bad = dict(sd)
+    bad["layers.3.0.weight"] = bad["layers.3.0.weight"][:, :10]
+    with pytest.raises(ValueError):
+        Model(bad, synth.Config(), log, "mRNA", device=dev)
+    with pytest.raises(ValueError):
+        Model(sd, synth.Config(synth.CnnConfig(classifier="gap")), log, "mRNA", device=dev)
+    m.close()
+
+
+def _oracle_loop(batches, kit, seeds, mode, thr, cache_models):
+    """riser/control.py:31-97 restated with the oracle pieces -> (rows, rejected, finished)."""
+    max_len, fixed = ro.kit_max_length(kit), ro.kit_fixed_trim_length(kit)
+    cache, rows, rej_all, fin_all = {}, [], [], []
+    for batch in batches:
+        rej, acc, unc = [], [], []
+        for ch, read in batch:
+            sig = np.frombuffer(read.raw_data, np.int16)
+            sig, trimmed = ro.trim_polya(sig, read.id, cache)
+            if not trimmed:
+                if len(sig) > fixed + max_len:
+                    sig = sig[fixed:][:max_len]
+                else:
+                    continue
+            else:
+                if len(sig) < ro.MIN_INPUT_SIGNALS:
+                    continue
+                sig = sig[:max_len]
+            x = ro.mad_normalise(sig)
+            ps = [cache_models[s].classify(x).numpy() for s in seeds]
+            d = ro.decide([p[1] for p in ps], [p[0] for p in ps], thr, mode, len(sig), max_len)
+            rid = read.number if hasattr(read, "number") else read.id
+            {"accept": acc, "reject": rej, "no_decision": unc}.get(d, []).append((ch, rid))
+            rows.append((read.id, ch, len(sig), d, [float(p[1]) for p in ps]))
+        rej_all.append(rej)
+        fin_all.append(rej + acc + unc)
+    return rows, rej_all, fin_all
+
+
+@pytest.mark.parametrize("kit,seeds,mode", [("RNA002", (1,), "deplete"), ("RNA002", (2, 3), "enrich"),
+                                            ("RNA004", (3,), "deplete")])
+def test_control_loop_vs_oracle_loop(dev, tmp_path, kit, seeds, mode):
+    from riser_amd import Kit, Model, SequencerControl, SignalProcessor
+    rng = np.random.default_rng(hash((kit, seeds)) % 2**32)
+    batches = []
+    for b in range(3):
+        reads = []
+        for ch in range(1, 41):
+            rid = b * 7 + ch
+            n = int(rng.integers(3000, 26000))
+            rd = FakeRead(f"id-{rid}", synth.make_raw_read(55, rid, n, polya=(rid % 4 != 0)),
+                          number=(rid if rid % 2 else None))
+            reads.append((ch, rd))
+        batches.append(reads)
+    cpu_models = {s: torch_path.TorchCpuModel(synth.make_state_dict(s)) for s in seeds}
+    want_rows, want_rej, want_fin = _oracle_loop(batches, kit, seeds, mode, 0.9, cpu_models)
+    models = [Model(synth.make_state_dict(s), synth.Config(), None, f"t{s}", device=dev) for s in seeds]
+    proc = SignalProcessor(Kit.create_from_version(kit), device=dev)
+    client = FakeClient(batches)
+    out = str(tmp_path / "o")
+    ctl = SequencerControl(client, models, proc, logging.getLogger("c"), out)
+    ctl.start(); ctl.target(mode, 0.5, 0.9); ctl.finish()
+    lines = open(out + ".csv").read().strip().split("\n")[1:]
+    assert len(lines) == len(want_rows) > 20
+    near = 0
+    for ln, w in zip(lines, want_rows):
+        p = ln.split(",")
+        assert (p[1], int(p[2]), int(p[3])) == w[:3]
+        got_p = [float(v) for v in p[5].split(";")]
+        assert np.allclose(got_p, w[4], atol=1e-3)
+        if any(abs(q - 0.9) < 1e-4 or abs(1 - q - 0.9) < 1e-4 for q in w[4]):
+            near += 1                                   # a probability within 1e-4 of the threshold may flip
+            continue
+        assert p[8] == w[3], (p, w)
+    assert near <= 1
+    if near == 0:
+        assert [[tuple(x) for x in b] for b in client.rejected] == want_rej
+        assert [[tuple(x) for x in b] for b in client.finished] == want_fin
+    for m in models:
+        m.close()
+
+
+def test_control_rejects_bad_mode_and_handles_empty_batches(dev, tmp_path):
+    from riser_amd import Kit, Model, SequencerControl, SignalProcessor
+    m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", device=dev)
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    short = FakeRead("s", synth.make_raw_read(1, 1, 3000, True))
+    client = FakeClient([[], [(1, short)], []])
+    ctl = SequencerControl(client, [m], proc, logging.getLogger("c"), str(tmp_path / "e"))
+    with pytest.raises(ValueError):
+        ctl.target("purify", 1.0, 0.9)
+    ctl.target("enrich", 1.0, 0.9)
+    assert client.rejected == [[], [], []] and client.finished == [[], [], []]
+    assert open(str(tmp_path / "e.csv")).read().count("\n") == 1        # header only (the bad mode raised before the file was opened)
+    m.close()
+
+
+def test_polya_cache_is_used_and_bounded(dev):
+    from riser_amd import Kit, SignalProcessor
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    sig = synth.make_raw_read(9, 2, 15000, True)
+    cache = {}
+    a, ok = proc.trim_polya(sig, "r", cache) if hasattr(proc, "trim_polya") else proc.trim_polyA(sig, "r", cache)
+    assert ok and "r" in cache
+    cache["r"] = 123                                       # a cached value is trusted, as in the reference
+    b, ok2 = proc.trim_polyA(sig, "r", cache)
+    assert ok2 and len(b) == len(sig) - 124
+
+
+def test_random_batches_property(dev):
+    """random lengths / offsets / batch sizes: every read's result equals its solo result bit for
+    bit and the oracle within tolerance."""
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    m = Model(synth.make_state_dict(3), synth.Config(), None, "g", device=dev)
+    sd = synth.make_state_dict(3)
+    rng = np.random.default_rng(2026)
+    for trial in range(4):
+        B = int(rng.integers(1, 40))
+        lens = rng.integers(4096, 20000, B)
+        sigs = [synth.make_signals(SIG_SEED + trial, 1, int(n) + 50, first_read=int(i))[0] for i, n in enumerate(lens)]
+        sig, off, ln, lh = pack_reads(sigs, dev)
+        trim = rng.integers(0, 50, B)
+        off2 = off + torch.from_numpy(trim.astype(np.int64)).to(dev)
+        ln2 = torch.from_numpy(lens.astype(np.int32)).to(dev)
+        got = m.classify_raw(sig, off2, ln2, lens.astype(np.int32)).cpu().numpy()
+        k = int(rng.integers(0, B))
+        solo = m.classify_raw(sig, off2[k:k + 1].contiguous(), ln2[k:k + 1].contiguous(), lens[k:k + 1].astype(np.int32)).cpu().numpy()
+        assert np.array_equal(solo[0], got[k])
+        want = ro.classify_reads(sd, [sigs[k][trim[k]:trim[k] + lens[k]]])
+        assert np.abs(got[k] - want[0]).max() < 1e-3
+    m.close()

@@ -1,0 +1,28 @@
+"""A/B two builds of the library in one process launch sequence (alternating), fp32 per-step time."""
+import sys, os, subprocess, json
+libs = sys.argv[1:]
+code = r'''
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from riser_amd import synth
+from riser_amd.model import Model
+from riser_amd.preprocess import pack_reads
+B, L = 512, 16000
+sigs = synth.make_signals(20260103, B, L)
+dev = torch.device("cuda", 0)
+sig, off, ln, lens = pack_reads(list(sigs), dev)
+m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA")
+out = torch.empty((B, 2), device=dev)
+for _ in range(5): m.classify_raw(sig, off, ln, lens, out=out)
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(30): m.classify_raw(sig, off, ln, lens, out=out)
+torch.cuda.synchronize(); print("%.4f" % ((time.perf_counter() - t) / 30 * 1e3))
+'''
+res = {l: [] for l in libs}
+for rnd in range(3):
+    for l in libs:
+        env = dict(os.environ); env["RISER_AMD_LIB"] = os.path.abspath(l)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        res[l].append(float(out.stdout.strip().split("\n")[-1]))
+for l in libs: print(l, res[l], "median %.4f" % sorted(res[l])[1])
