@@ -1,0 +1,71 @@
+"""StreamClassifier: classify a large host-resident population of reads in sub-batches, with the
+PCIe upload of sub-batch i+1 overlapped with the kernels of sub-batch i (two HIP streams, double
+buffered device and pinned host staging).
+
+This is the shape of BASELINE config 4 (a PromethION-scale 144 k concurrent chunks, 18 k per GPU):
+reads are independent, so a GPU simply walks its shard; nothing is exchanged between GPUs
+(riser_amd.dist shards by read id).  Per read the wire cost is 2 bytes/sample up and 8 bytes
+down per model.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+class StreamClassifier:
+    def __init__(self, models, sub_batch: int = 1024, max_len: int = 16000):
+        self.models = list(models)
+        self.device = self.models[0].device
+        self.sub_batch = int(sub_batch)
+        self.max_len = int(max_len)
+        self.copy_stream = torch.cuda.Stream(self.device)
+        self.compute_stream = torch.cuda.Stream(self.device)
+        n = self.sub_batch * self.max_len
+        self._pinned = [torch.empty(n, dtype=torch.int16).pin_memory() for _ in range(2)]
+        self._dev = [torch.empty(n, dtype=torch.int16, device=self.device) for _ in range(2)]
+        self._probs = [torch.empty((len(self.models), self.sub_batch, 2), dtype=torch.float32, device=self.device)
+                       for _ in range(2)]
+        self._uploaded = [torch.cuda.Event() for _ in range(2)]
+        self._consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def classify(self, signals: np.ndarray, lengths: np.ndarray | None = None) -> np.ndarray:
+        """signals: int16 [N, L] (row i valid for lengths[i] samples, default L) in host memory
+        (numpy, or a pinned torch tensor to skip the staging copy).  Returns float32
+        [n_models, N, 2] = (p_off, p_on) on the host."""
+        pinned_in = torch.is_tensor(signals) and signals.is_pinned()
+        N, L = signals.shape
+        if L > self.max_len:
+            raise ValueError("rows longer than max_len")
+        lengths = np.full(N, L, dtype=np.int32) if lengths is None else np.asarray(lengths, dtype=np.int32)
+        out = torch.empty((len(self.models), N, 2), dtype=torch.float32).pin_memory()
+        SB = self.sub_batch
+        n_sub = (N + SB - 1) // SB
+        for i in range(n_sub):
+            k = i & 1
+            lo, hi = i * SB, min(N, (i + 1) * SB)
+            nb = hi - lo
+            # ---- upload on the copy stream (after the kernels that last read this buffer) -------
+            with torch.cuda.stream(self.copy_stream):
+                if i >= 2:
+                    self.copy_stream.wait_event(self._consumed[k])
+                    self._consumed[k].synchronize()                 # the pinned staging buffer is host-written
+                if pinned_in:
+                    src = signals[lo:hi].reshape(-1)
+                else:
+                    src = self._pinned[k][: nb * L]
+                    src.numpy()[:] = np.asarray(signals[lo:hi]).reshape(-1)
+                self._dev[k][: nb * L].copy_(src, non_blocking=True)
+                self._uploaded[k].record(self.copy_stream)
+            # ---- kernels on the compute stream ---------------------------------------------------
+            lens_h = lengths[lo:hi]
+            with torch.cuda.stream(self.compute_stream):
+                self.compute_stream.wait_event(self._uploaded[k])
+                off = torch.arange(nb, dtype=torch.int64, device=self.device) * L
+                ln = torch.from_numpy(lens_h).to(self.device, non_blocking=True)
+                for m, model in enumerate(self.models):
+                    model.classify_raw(self._dev[k], off, ln, lens_h, out=self._probs[k][m, :nb])
+                out[:, lo:hi].copy_(self._probs[k][:, :nb], non_blocking=True)
+                self._consumed[k].record(self.compute_stream)
+        self.compute_stream.synchronize()
+        return out.numpy()

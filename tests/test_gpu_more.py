@@ -164,3 +164,23 @@ def test_random_batches_property(dev):
         want = ro.classify_reads(sd, [sigs[k][trim[k]:trim[k] + lens[k]]])
         assert np.abs(got[k] - want[0]).max() < 1e-3
     m.close()
+
+
+def test_stream_classifier_matches_direct(dev):
+    """host-resident reads streamed in sub-batches (copy/compute overlap) == one direct call."""
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    from riser_amd.stream import StreamClassifier
+    m = Model(synth.make_state_dict(1), synth.Config(), None, "m", device=dev)
+    N, L = 300, 6024
+    sigs = synth.make_signals(SIG_SEED, N, L)
+    lens = np.full(N, L, dtype=np.int32)
+    lens[::7] = 4500
+    sc = StreamClassifier([m], sub_batch=64, max_len=L)
+    got = sc.classify(sigs, lens)
+    sig, off, ln, _ = pack_reads(list(sigs), dev)
+    want = m.classify_raw(sig, off, torch.from_numpy(lens).to(dev), lens).cpu().numpy()
+    assert got.shape == (1, N, 2) and np.array_equal(got[0], want)
+    got2 = sc.classify(torch.from_numpy(sigs).pin_memory(), lens)          # pinned input path
+    assert np.array_equal(got2[0], want)
+    m.close()
