@@ -175,6 +175,28 @@ typedef struct rs_layer_info {
 int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out);
 
 /*
+ * Sequential conv programs: the secondary ResNet architecture (riser/nets/resnet.py:7-131; not
+ * loadable by the reference's Model, no shipped config or weights).  The host folds eval-mode
+ * BatchNorm into each conv and hands over an execution list; activations live in `n_buffers`
+ * numbered buffers (0 = the normalised input [B, L], the rest carved from the workspace).
+ * One uniform length per batch.  Parity-grade direct fp32 kernels, not the tuned hot path.
+ */
+typedef struct rs_seq_op {
+    int32_t kind;           /* 0 = conv1d (+bias, +residual, +relu), 1 = MaxPool1d(2, 2, padding 1) */
+    int32_t src, dst, add;  /* buffer ids; add = -1 for no residual input */
+    int32_t c_in, c_out, k, stride, pad, relu;
+    const float* w;         /* HOST fp32 [c_out, c_in, k], BN already folded in (conv only) */
+    const float* b;         /* HOST fp32 [c_out] */
+} rs_seq_op;
+typedef struct rs_seqnet rs_seqnet;
+int rs_seqnet_create(const rs_seq_op* ops, int n_ops, int n_buffers, const float* fc_w /* [2, c_last] */,
+                     const float* fc_b, int c_last, int device, rs_seqnet** out);
+int rs_seqnet_destroy(rs_seqnet* m);
+size_t rs_seqnet_workspace_bytes(const rs_seqnet* m, int B, int L);
+int rs_seqnet_forward(rs_seqnet* m, const float* d_x /* fp32 [B, L] */, int B, int L, void* d_ws, size_t ws_bytes,
+                      float* d_probs, float* d_logits, void* stream);
+
+/*
  * Stage timing with HIP events on the launch stream (used by bench.py's roofline leg).
  * While enabled, rs_forward / rs_classify record one event before their first launch and
  * one after every kernel launch, on the caller's stream; no synchronisation is added.

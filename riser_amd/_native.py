@@ -22,7 +22,13 @@ SYMBOLS = (
     "rs_last_error", "rs_version", "rs_device_count", "rs_model_create", "rs_model_destroy",
     "rs_workspace_bytes", "rs_normalise", "rs_forward", "rs_padded_length", "rs_classify",
     "rs_decide", "rs_polya_end", "rs_model_layer_info", "rs_profile_enable", "rs_profile_read",
+    "rs_seqnet_create", "rs_seqnet_destroy", "rs_seqnet_workspace_bytes", "rs_seqnet_forward",
 )
+
+
+class SeqOp(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "src", "dst", "add", "c_in", "c_out", "k", "stride", "pad", "relu")] + \
+               [("w", C.c_void_p), ("b", C.c_void_p)]
 
 
 class LayerInfo(C.Structure):
@@ -72,6 +78,14 @@ def lib():
     L.rs_polya_end.argtypes = [vp, vp, vp, i32, vp, vp]
     L.rs_model_layer_info.restype = i32
     L.rs_model_layer_info.argtypes = [vp, i32, C.POINTER(LayerInfo)]
+    L.rs_seqnet_create.restype = i32
+    L.rs_seqnet_create.argtypes = [C.POINTER(SeqOp), i32, i32, vp, vp, i32, i32, C.POINTER(vp)]
+    L.rs_seqnet_destroy.restype = i32
+    L.rs_seqnet_destroy.argtypes = [vp]
+    L.rs_seqnet_workspace_bytes.restype = sz
+    L.rs_seqnet_workspace_bytes.argtypes = [vp, i32, i32]
+    L.rs_seqnet_forward.restype = i32
+    L.rs_seqnet_forward.argtypes = [vp, vp, i32, i32, vp, sz, vp, vp, vp]
     L.rs_profile_enable.restype = i32
     L.rs_profile_enable.argtypes = [vp, i32]
     L.rs_profile_read.restype = i32

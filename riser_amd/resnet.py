@@ -1,0 +1,138 @@
+"""ResNetModel: the reference's secondary architecture (riser/nets/resnet.py:7-131) on the GPU.
+
+The reference's `Model` cannot load a ResNet (it hard-imports ConvNet, riser/model.py:3,18) and
+ships neither a `config.resnet` section nor weights, so this class mirrors `Model`'s surface
+(`classify(signal) -> Tensor[2]`) for users who train one with riser/train.py:177-178.  Eval-mode
+BatchNorm is folded into the preceding conv here on the host; the device runs the resulting
+conv / max-pool program (csrc/seqnet.hip) - parity-grade kernels, not the tuned ConvNet path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nv
+
+_BN_EPS = 1e-5
+
+
+def _fold(w, bn, prefix, conv_bias=None):
+    """conv weight [co, ci, k] + BatchNorm1d(eval) -> (w', b') with y = conv(x; w') + b'."""
+    g, b = bn[prefix + ".weight"], bn[prefix + ".bias"]
+    mu, var = bn[prefix + ".running_mean"], bn[prefix + ".running_var"]
+    scale = (g.astype(np.float64) / np.sqrt(var.astype(np.float64) + _BN_EPS))
+    wf = (w.astype(np.float64) * scale[:, None, None]).astype(np.float32)
+    shift = b.astype(np.float64) - mu.astype(np.float64) * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.astype(np.float64) * scale
+    return np.ascontiguousarray(wf), np.ascontiguousarray(shift.astype(np.float32))
+
+
+def build_program(sd, c):
+    """(ops, n_buffers, fc_w, fc_b, c_last): the conv / max-pool program of a reference ResNet
+    state dict.  ops = list of dicts {kind, src, dst, add, w, b, stride, pad, relu}; buffer 0 is the
+    input.  Pure numpy (unit-testable without a GPU)."""
+    ops = []
+
+    def conv(src, dst, w, b, stride, pad, relu, add=-1):
+        ops.append(dict(kind=0, src=src, dst=dst, add=add, w=np.ascontiguousarray(w, dtype=np.float32),
+                        b=np.ascontiguousarray(b, dtype=np.float32), stride=int(stride), pad=int(pad), relu=int(relu)))
+
+    # stem (resnet.py:79-84): conv(bias) + BN + ReLU, MaxPool1d(2, 2, padding 1)
+    w, b = _fold(sd["conv_block.0.weight"], sd, "conv_block.1", sd["conv_block.0.bias"])
+    conv(0, 1, w, b, int(c.stride), int(c.padding), True)
+    ops.append(dict(kind=1, src=1, dst=2, add=-1))
+    cur, in_ch = 2, int(c.channels[0])
+    bottleneck = c.block == "bottleneck"
+    n_buffers = 7
+    for i in range(int(c.n_layers)):
+        out_ch = int(c.channels[i])
+        for j in range(int(c.blocks[i])):
+            stride = 2 if (i > 0 and j == 0) else 1
+            pre = f"layers.{i}.{j}"
+            free = [k for k in range(1, n_buffers) if k != cur]
+            res = cur
+            if in_ch != out_ch or stride != 1:                    # should_apply_shortcut (resnet.py:45-47)
+                w, b = _fold(sd[pre + ".shortcut.0.weight"], sd, pre + ".shortcut.1")
+                res = free.pop()
+                conv(cur, res, w, b, stride, 0, False)
+            if bottleneck:                                        # resnet.py:60-70
+                w, b = _fold(sd[pre + ".blocks.0.0.weight"], sd, pre + ".blocks.0.1")
+                t1 = free.pop(); conv(cur, t1, w, b, 1, 0, True)
+                w, b = _fold(sd[pre + ".blocks.1.0.weight"], sd, pre + ".blocks.1.1")
+                t2 = free.pop(); conv(t1, t2, w, b, stride, 1, True)
+                w, b = _fold(sd[pre + ".blocks.2.0.weight"], sd, pre + ".blocks.2.1")
+                t3 = free.pop(); conv(t2, t3, w, b, 1, 0, True, add=res)      # relu(blocks + residual), :42
+                cur = t3
+            else:                                                 # resnet.py:50-57
+                w, b = _fold(sd[pre + ".blocks.0.0.weight"], sd, pre + ".blocks.0.1")
+                t1 = free.pop(); conv(cur, t1, w, b, stride, 1, True)
+                w, b = _fold(sd[pre + ".blocks.1.0.weight"], sd, pre + ".blocks.1.1")
+                t2 = free.pop(); conv(t1, t2, w, b, 1, 1, True, add=res)
+                cur = t2
+            in_ch = out_ch
+    fw = np.ascontiguousarray(sd["decoder.2.weight"], dtype=np.float32)
+    fb = np.ascontiguousarray(sd["decoder.2.bias"], dtype=np.float32)
+    return ops, n_buffers, fw, fb, in_ch
+
+
+class ResNetModel:
+    def __init__(self, state, config, logger, target, device=None):
+        self.target, self.logger = target, logger
+        nv.require_gpu()
+        d = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+        c = config.resnet
+        sd = state if isinstance(state, dict) else torch.load(state, map_location="cpu")
+        sd = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
+        if int(c.n_classes) != 2:
+            raise ValueError("riser_amd supports two-class heads only")
+        prog, n_buffers, fw, fb, c_last = build_program(sd, c)
+        self._keep = prog
+        ops = []
+        for o in prog:
+            if o["kind"] == 0:
+                w, b = o["w"], o["b"]
+                ops.append(nv.SeqOp(0, o["src"], o["dst"], o["add"], w.shape[1], w.shape[0], w.shape[2], o["stride"],
+                                    o["pad"], o["relu"], w.ctypes.data, b.ctypes.data))
+            else:
+                ops.append(nv.SeqOp(1, o["src"], o["dst"], -1, 0, 0, 0, 0, 0, 0, None, None))
+        arr = (nv.SeqOp * len(ops))(*ops)
+        h = C.c_void_p()
+        nv.check(nv.lib().rs_seqnet_create(arr, len(ops), n_buffers, fw.ctypes.data, fb.ctypes.data, c_last,
+                                           self.device.index, C.byref(h)), "rs_seqnet_create")
+        self._h = h
+        self._ws = None
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            nv.lib().rs_seqnet_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def classify(self, signal):
+        return self.classify_batch(np.asarray(signal)[None, :])[0]
+
+    def classify_batch(self, signals, return_logits: bool = False):
+        """signals: [B, L] normalised (one common length).  Returns fp32 [B, 2] on the device."""
+        x = torch.as_tensor(np.ascontiguousarray(signals)).to(self.device, dtype=torch.float).contiguous()
+        B, L = x.shape
+        lib = nv.lib()
+        need = lib.rs_seqnet_workspace_bytes(self._h, B, L)
+        if need == 0:
+            raise ValueError(f"signal of {L} samples is too short for this network")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        probs = torch.empty((B, 2), dtype=torch.float32, device=self.device)
+        logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
+        nv.check(lib.rs_seqnet_forward(self._h, x.data_ptr(), B, L, self._ws.data_ptr(), self._ws.numel(),
+                                       probs.data_ptr(), logits.data_ptr() if return_logits else None,
+                                       torch.cuda.current_stream(self.device).cuda_stream), "rs_seqnet_forward")
+        return (probs, logits) if return_logits else probs

@@ -1,0 +1,54 @@
+"""ResNet variant (riser/nets/resnet.py): oracle pinned to the reference's outputs (CPU) and the
+GPU sequential-conv program against both."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+from oracle import resnet_oracle as rr
+from oracle import riser_oracle as ro
+from riser_amd import synth
+
+
+def _load(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "resnet.npz"))
+    cfg = json.loads(str(g[f"{name}.cfg"]))
+    sd = {k[len(name) + 4:]: g[k] for k in g.files if k.startswith(name + ".sd.")}
+    return g, cfg, sd
+
+
+def _inputs(L):
+    sigs = synth.make_signals(20260103, 3, L, first_read=40)
+    return np.stack([ro.mad_normalise(s) for s in sigs]).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["basic", "bottleneck"])
+def test_resnet_oracle_vs_reference(golden_dir, name):
+    g, cfg, sd = _load(golden_dir, name)
+    for L in (3000, 4097):
+        lg = rr.resnet_forward(sd, cfg, _inputs(L))
+        assert np.abs(lg - g[f"{name}.L{L}.logits"]).max() < 1e-5
+        assert np.abs(ro.softmax(lg) - g[f"{name}.L{L}.probs"]).max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["basic", "bottleneck"])
+def test_resnet_gpu_vs_reference(golden_dir, name):
+    import torch
+    from riser_amd.resnet import ResNetModel
+    g, cfg, sd = _load(golden_dir, name)
+    config = types.SimpleNamespace(resnet=types.SimpleNamespace(**cfg))
+    m = ResNetModel(sd, config, None, "x", device=torch.device("cuda", 0))
+    for L in (3000, 4097):
+        x = _inputs(L)
+        probs, logits = m.classify_batch(x, return_logits=True)
+        assert np.abs(logits.cpu().numpy() - g[f"{name}.L{L}.logits"]).max() < 1e-4
+        assert np.abs(probs.cpu().numpy() - g[f"{name}.L{L}.probs"]).max() < 1e-3
+        one = m.classify(x[1])
+        assert one.shape == (2,) and abs(one[1].item() - g[f"{name}.L{L}.probs"][1, 1]) < 1e-3
+    if cfg["kernel"] > 4 + 2 * cfg["padding"]:                 # the stem kernel does not fit: torch raises too
+        with pytest.raises(ValueError):
+            m.classify_batch(np.zeros((1, 4), dtype=np.float32))
+    m.close()

@@ -228,10 +228,58 @@ def f4_polya():
     print("F4:", [c[4] for c in cases])
 
 
+# --------------------------------------------------------------------------------------
+def f5_resnet():
+    """reference ResNet (riser/nets/resnet.py) in eval mode with randomised weights AND BatchNorm
+    running statistics (default mean 0 / var 1 would hide folding bugs)."""
+    from nets.resnet import ResNet
+    out = {}
+    rng = np.random.default_rng(31337)
+    cfgs = {"basic": dict(channels=[8, 12, 20], kernel=19, padding=5, stride=3, block="basic", n_layers=3,
+                          blocks=[1, 2, 1], n_classes=2),
+            "bottleneck": dict(channels=[16, 24, 32], kernel=7, padding=3, stride=2, block="bottleneck", n_layers=3,
+                               blocks=[2, 1, 2], n_classes=2)}
+    for name, cfg in cfgs.items():
+        net = ResNet(types.SimpleNamespace(**cfg))
+        sd = net.state_dict()
+        new = {}
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                new[k] = v
+            elif k.endswith("running_var"):
+                new[k] = torch.from_numpy(rng.uniform(0.5, 2.0, v.shape).astype(np.float32))
+            elif k.endswith("running_mean"):
+                new[k] = torch.from_numpy((rng.standard_normal(v.shape) * 0.3).astype(np.float32))
+            elif ".1.weight" in k and v.dim() == 1:                        # BN gamma
+                new[k] = torch.from_numpy(rng.uniform(0.6, 1.4, v.shape).astype(np.float32))
+            elif v.dim() == 1:                                             # biases / BN beta
+                new[k] = torch.from_numpy((rng.standard_normal(v.shape) * 0.1).astype(np.float32))
+            else:
+                fan_in = v.shape[1] * (v.shape[2] if v.dim() == 3 else 1)
+                new[k] = torch.from_numpy((rng.standard_normal(v.shape) * np.sqrt(1.5 / fan_in)).astype(np.float32))
+        net.load_state_dict(new)
+        net.eval()
+        for L in (3000, 4097):
+            sigs = synth.make_signals(SIG_SEED, 3, L, first_read=40)
+            proc = SignalProcessor(Kit.create_from_version("RNA004"))
+            x = np.stack([proc.mad_normalise(s.copy()) for s in sigs]).astype(np.float32)
+            with torch.no_grad():
+                logits = net(torch.from_numpy(x))
+                probs = torch.softmax(logits, dim=1)
+            out[f"{name}.L{L}.logits"] = logits.numpy()
+            out[f"{name}.L{L}.probs"] = probs.numpy()
+        for k, v in new.items():
+            if not k.endswith("num_batches_tracked"):
+                out[f"{name}.sd.{k}"] = v.numpy()
+        out[f"{name}.cfg"] = np.array(json.dumps(cfg))
+        print("F5:", name, out[f"{name}.L3000.probs"][:, 1])
+    np.savez_compressed(os.path.join(OUT, "resnet.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5"]
     if "f1" in which:
         f1_normalise()
     if "f4" in which:
@@ -240,3 +288,5 @@ if __name__ == "__main__":
         f2_network()
     if "f3" in which:
         f3_control()
+    if "f5" in which:
+        f5_resnet()
