@@ -166,6 +166,41 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f32_kernel(const ConvArgs a
             }
     };
 
+    // per-unit forms (u in [0, A_PER + B_PER)): the unrolled k-step loop issues one or two staging
+    // units per k-step instead of the whole prefetch / store as a block, so a wave never leaves its
+    // MFMA stream for more than a few instructions
+    auto load_unit = [&](int u, int m0, int n0, int c, bool live) {
+        const int cbase = c * KC;
+        if (u < A_PER) {
+            const int key = a_key[u];
+            const int row = key >> 3, c4 = key & 7;
+            const int gr = m0 - 1 + row;
+            const bool ok = live && key >= 0 && gr >= 0 && gr < a.rows_in && cbase + 4 * c4 < a.cp_in;
+            const float* src = ok ? a.x + (int64_t)(m0 - 1 + row) * a.cp_in + cbase + 4 * c4 : a.zero;
+            ra[u] = *reinterpret_cast<const float4*>(src);
+        } else {
+            const int v = u - A_PER;
+            const float* src = (live && b_g[v] >= 0) ? a.w + ((int64_t)n0 * a.nch + c) * (3 * KC) + b_g[v] : a.zero;
+            rb[v] = *reinterpret_cast<const float4*>(src);
+        }
+    };
+    auto store_unit = [&](int u, float* buf) {
+        if (u < A_PER) {
+            if (a_key[u] >= 0) {
+                float2* d = reinterpret_cast<float2*>(buf + a_lds[u]);
+                d[0] = make_float2(ra[u].x, ra[u].y);
+                d[1] = make_float2(ra[u].z, ra[u].w);
+            }
+        } else {
+            const int v = u - A_PER;
+            if (b_g[v] >= 0) {
+                float2* d = reinterpret_cast<float2*>(buf + b_lds[v]);
+                d[0] = make_float2(rb[v].x, rb[v].y);
+                d[1] = make_float2(rb[v].z, rb[v].w);
+            }
+        }
+    };
+
     // ---- tile walk: round k gives XCD x (= blockIdx % 8) a contiguous block of the n-major tile
     // order, so the workgroups sharing an L2 stream the same weight slab at the same time -------
     const int tiles = a.n_mtiles * a.n_ntiles;
@@ -298,23 +333,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f32_kernel(const ConvArgs a
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] =
                             __builtin_amdgcn_mfma_f32_16x16x4f32(af[st & 1][i], bf[st & 1][j], acc[i][j], 0, 0, 0);
-                if ((st == LOAD_A && !grp_b) || (st == LOAD_B && grp_b)) {
-                    RS_STAMP(1);                                   // first k-step
+                {
+                    // distributed staging: units are loaded in the first half of the item and written
+                    // to the other LDS buffer in the second half, UPS units per k-step
+                    constexpr int UNITS = A_PER + B_PER;
+                    constexpr int HALF = NSTEPS / 2;
+                    constexpr int UPS = (UNITS + HALF - 1) / HALF;
                     __builtin_amdgcn_sched_barrier(0);
-                    load_item(nm0, nn0, nc, has_next);
+                    if (st < HALF) {
+#pragma unroll
+                        for (int q = 0; q < UPS; ++q)
+                            if (st * UPS + q < UNITS) load_unit(st * UPS + q, nm0, nn0, nc, has_next);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < UPS; ++q)
+                            if ((st - HALF) * UPS + q < UNITS && has_next)
+                                store_unit((st - HALF) * UPS + q, lds + (buf ^ 1) * buf_elems);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
-                    RS_STAMP(2);                                   // prefetch issue
-                }
-                if ((st == STORE_A && !grp_b) || (st == STORE_B && grp_b)) {
-                    RS_STAMP(3);                                   // MFMA body
-#ifdef RS_ITEM_STAMPS
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    RS_STAMP(6);                                   // pure wait for the prefetch loads
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (has_next) store_item(lds + (buf ^ 1) * buf_elems);
-                    __builtin_amdgcn_sched_barrier(0);
-                    RS_STAMP(4);                                   // vmcnt wait + LDS writes
                 }
             }
         } else {
