@@ -58,7 +58,9 @@ namespace {
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
-int esize(const rs_model* m) { return m->dtype == RS_F32 ? 4 : 2; }
+// storage type of the activations: the Winograd fp32 path shares every non-conv kernel with RS_F32
+int act_dtype(const rs_model* m) { return m->dtype == RS_F32W ? RS_F32 : m->dtype; }
+int esize(const rs_model* m) { return act_dtype(m) == RS_F32 ? 4 : 2; }
 
 // ---- static part of the plan: the K chunking (fixes the weight packing) -------------------------
 // kc minimises nch * (3*kc/4 + 0.75) k-steps (0.75 step ~ the per-item barrier + LDS write);
@@ -79,6 +81,24 @@ ConvPlan plan_static_f32(int cp_in, int c_out) {
         }
     }
     p.n_alloc = round_up(c_out, 16) + conv_f32_max_bn();
+    return p;
+}
+
+// Winograd F(2,3): a chunk of kc channels is 4 * kc / 4 = kc MFMA slots; ~1.5 slots per item for
+// the barrier and the staging writes
+ConvPlan plan_static_wino(int cp_in, int c_out) {
+    ConvPlan p{};
+    double best_cost = -1;
+    for (int kc = 16; kc <= 24; kc += 4) {
+        const int nch = (cp_in + kc - 1) / kc;
+        const double cost = nch * (kc + 1.5);
+        if (best_cost < 0 || cost < best_cost - 1e-9) {
+            best_cost = cost;
+            p.kc = kc;
+            p.nch = nch;
+        }
+    }
+    p.n_alloc = round_up(c_out, 16) + conv_wino_max_bn();
     return p;
 }
 
@@ -165,7 +185,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         set_error("rs_model_create: n_classes must be 2 (got %d)", n_classes);
         return RS_ERR_ARG;
     }
-    if (dtype != RS_F32 && dtype != RS_BF16 && dtype != RS_F16) {
+    if (dtype != RS_F32 && dtype != RS_BF16 && dtype != RS_F16 && dtype != RS_F32W) {
         set_error("rs_model_create: unknown dtype %d", dtype);
         return RS_ERR_ARG;
     }
@@ -190,7 +210,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
     m->n_layers = n_layers;
     for (int i = 0; i < n_layers; ++i) {
         m->channels[i] = channels[i];
-        m->cp[i] = round_up(channels[i], dtype == RS_F32 ? 4 : 8);
+        m->cp[i] = round_up(channels[i], (dtype == RS_F32 || dtype == RS_F32W) ? 4 : 8);
     }
     int rc = RS_OK;
     {   // layer 0: (w0, w1, w2, bias) per output channel
@@ -219,6 +239,24 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
                     for (int kw = 0; kw < 3; ++kw)
                         wp[(((size_t)n * p.nch + c) * 3 + kw) * p.kc + cc] =
                             conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw];
+                }
+            float* dw = nullptr;
+            rc = upload(&dw, wp);
+            L.d_w = dw;
+        } else if (dtype == RS_F32W) {
+            // Winograd F(2,3) filter transform (fp64, rounded once): U0 = g0, U1 = (g0+g1+g2)/2,
+            // U2 = (g0-g1+g2)/2, U3 = g2; packed [n_alloc][nch][4][kc]
+            L.plan = plan_static_wino(L.cp_in, L.c_out);
+            const ConvPlan& p = L.plan;
+            std::vector<float> wp((size_t)p.n_alloc * p.nch * 4 * p.kc, 0.0f);
+            for (int n = 0; n < L.c_out; ++n)
+                for (int ci = 0; ci < L.c_in; ++ci) {
+                    const int c = ci / p.kc, cc = ci - c * p.kc;
+                    const float* g = &conv_w[i][((size_t)n * L.c_in + ci) * 3];
+                    const double g0 = g[0], g1 = g[1], g2 = g[2];
+                    const double u[4] = {g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2};
+                    for (int j = 0; j < 4; ++j)
+                        wp[(((size_t)n * p.nch + c) * 4 + j) * p.kc + cc] = (float)u[j];
                 }
             float* dw = nullptr;
             rc = upload(&dw, wp);
@@ -336,7 +374,7 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
     void* buf[2] = {ws + w.bufa_off, ws + w.bufb_off};
 
     if (!m->prof_on || m->ev_used == 0 || m->ev_stage[m->ev_used - 1] != 0) prof_mark(m, -1, st);
-    int rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], m->dtype, st);
+    int rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
     if (rc != RS_OK) return rc;
     prof_mark(m, 1, st);
     int cur = 0;
@@ -346,7 +384,10 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
         // a tile of >= 64 rows can only be all padding if some read leaves >= 64 rows of its slot
         // unused at this layer; Lmin == 0 means "unknown": keep the test
         const int check_dead = (Lmin <= 0 || (w.P0 >> i) - (Lmin >> i) >= 64) ? 1 : 0;
-        if (m->dtype == RS_F32)
+        if (m->dtype == RS_F32W)
+            rc = launch_conv_wino(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
+                                  B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
+        else if (m->dtype == RS_F32)
             rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
                                  B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
         else
@@ -356,7 +397,7 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
         prof_mark(m, 1 + i, st);
         cur ^= 1;
     }
-    rc = launch_head(buf[cur], m->dtype, m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
+    rc = launch_head(buf[cur], act_dtype(m), m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
                      w.P0 >> m->n_layers, m->n_layers, d_len, B, m->d_fcw, m->d_fcb, d_probs, d_logits, st);
     if (rc == RS_OK) prof_mark(m, m->n_layers + 1, st);
     return rc;
@@ -456,7 +497,7 @@ int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out) {
     const ConvLayerDev& L = m->layers[layer];
     out->c_in = L.c_in;
     out->cp_in = L.cp_in;
-    out->k_pad = 3 * L.plan.kc * L.plan.nch;
+    out->k_pad = (m->dtype == RS_F32W ? 4 : 3) * L.plan.kc * L.plan.nch;
     out->n_pad = m->last_bn[layer] ? round_up(round_up(L.c_out, 16), m->last_bn[layer]) : round_up(L.c_out, 16);
     out->bm = m->last_bm[layer];
     out->bn = m->last_bn[layer];

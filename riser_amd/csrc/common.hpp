@@ -52,6 +52,10 @@ int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const i
 int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
                     int layer_index, int num_cu, const void* d_zero, bool f16, int check_dead, hipStream_t st,
                     int* bm_out, int* bn_out);
+int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len,
+                     int B, int P_in, int layer_index, int num_cu, const float* d_zero, int check_dead,
+                     hipStream_t st, int* bm_out, int* bn_out);
+int conv_wino_max_bn();
 int conv_h16_max_bn();
 int conv_f32_max_bn();
 int conv_f32_kc_max();

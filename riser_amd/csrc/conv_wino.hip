@@ -1,0 +1,469 @@
+// K3 (fp32, Winograd): one ConvNet block i >= 1 with the conv lowered to Winograd F(2,3) on the
+// f32-input MFMA.
+//
+//   Conv1d(C_in -> C_out, k=3, stride 1, zero 'same' padding, bias) -> ReLU -> MaxPool1d(2,2)
+//   (riser/nets/cnn.py:52-65, depth 1)
+//
+// MaxPool(2,2) consumes the conv outputs in pairs (y[2T], y[2T+1]) - exactly the output tile of
+// the minimal-filtering algorithm F(2,3), which produces such a pair from the four inputs
+// d0..d3 = x[2T-1 .. 2T+2] with 4 multiplications per input channel instead of 6:
+//     m1 = (d0 - d2) * g0              m2 = (d1 + d2) * (g0 + g1 + g2) / 2
+//     m4 = (d1 - d3) * g2              m3 = (d2 - d1) * (g0 - g1 + g2) / 2
+//     y[2T] = m1 + m2 + m3             y[2T+1] = m2 - m3 - m4
+// so the layer is FOUR GEMMs  M_j[T][n] = sum_c V_j[T][c] * U_j[n][c]  (j = 0..3) over POOLED
+// rows T, i.e. 2/3 of the matrix-pipe work of the direct lowering (conv_f32.hip), and the
+// output transform + bias + ReLU + MaxPool is a handful of VALU operations per pooled value in
+// the epilogue: out[T][n] = relu(max(m1 + m2 + m3, m2 - m3 - m4) + bias[n]).
+// The filter transform U_j is done once on the host in fp64 (rs_model_create); the input
+// transform V_j is done on the fly at fragment-read time (4 LDS reads + 4 VALU per 4 fragments).
+// fp32 throughout; the result differs from the direct fp32 chain by a few ulp (same error
+// against an fp64 evaluation, see tests/test_gpu_parity.py).
+//
+// Data layout as in conv_f32.hip (position-major activations, P-row slots, zero rows beyond each
+// read's length).  GEMM orientation: MFMA "A" operand = weights (rows = output channels), "B"
+// operand = transformed activations (columns = pooled positions), so a lane of the 16x16
+// accumulator holds 4 CONSECUTIVE CHANNELS of one pooled position: the epilogue stores 16 bytes
+// per lane straight into the position-major output.
+//
+// LDS per item (one K chunk of KC input channels): the (2*BMP + 2) input rows of the tile are
+// split by parity into two planes (x[2T+1] -> odd plane, x[2T] -> even plane) so that the four
+// inputs of pooled row T are rows T, T+1 of the two planes - unit row stride across lanes, and
+// with a row pitch of KC + 2 floats (= 2 mod 4) every ds_read_b32 of a 32-lane half hits 32
+// distinct banks.  Weights: [component][n][KC + 2].
+// Schedule: persistent 8-wave workgroups, double-buffered LDS, register prefetch of the next
+// item distributed over the MFMA slots of the current one (conv_f32.hip has the rationale).
+#include "common.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <utility>
+
+namespace rs {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: the body sees its index as a constant expression, so every register-array
+// index in the slot loop is static whatever hipcc's unroll heuristics decide
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+struct WinoArgs {
+    const float* x;
+    const float* w;        // packed [n_alloc][nch][4][kc] (U0..U3), zero rows beyond c_out
+    const float* bias;     // [n_alloc]
+    float* y;
+    const int32_t* len;
+    const float* zero;     // >= 16 bytes of zeros (target of masked-off staging loads)
+    int rows_in;           // B * P_in
+    int rows_out;          // B * P_out
+    int P_out;
+    float inv_P_out;
+    int cp_in, cp_out;
+    int nch;
+    int shift_out;         // valid output rows of read b: len[b] >> shift_out
+    int n_mtiles, n_ntiles;
+    int check_dead;
+};
+
+template <int WM, int WN, int MT, int NT, int KCT>
+__global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
+    static_assert(WM * WN == 8, "8 waves per workgroup (2 per SIMD)");
+    static_assert(KCT % 4 == 0 && KCT >= 8, "channel chunk");
+    constexpr int kThreads = 512;
+    constexpr int BMP = WM * 16 * MT;                  // pooled rows per tile
+    constexpr int BN = WN * 16 * NT;
+    constexpr int S = KCT + 2;
+    constexpr int KQ = KCT / 4;
+    constexpr int PL = (BMP + 1) * S;                  // one parity plane
+    constexpr int A_ELEMS = 2 * PL;
+    constexpr int BUF = A_ELEMS + 4 * BN * S;
+    constexpr int A_UNITS = (2 * BMP + 2) * KQ;
+    constexpr int B_UNITS = BN * 4 * KQ;
+    constexpr int A_PER = (A_UNITS + kThreads - 1) / kThreads;
+    constexpr int B_PER = (B_UNITS + kThreads - 1) / kThreads;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int r = lane & 15, kq = lane >> 4;
+
+    // ---- staging map, recomputed per use from an opaque copy of the thread index (keeping the
+    // per-unit LDS / global offsets in registers for the whole persistent loop costs ~14 VGPRs
+    // that the accumulators need) -----------------------------------------------------------------
+    // A unit f: slab row s = f / KQ (global input row 2*m0p - 1 + s), 4 channels at 4*(f % KQ).
+    // Even s = odd global row -> odd plane (offset 0), odd s -> even plane (offset PL); index s >> 1.
+    // B unit f: n = f / (4*KQ), rem = f % (4*KQ) = comp * KQ + c4; global packing [n][nch][4][KC].
+    float4 ra[A_PER], rb[B_PER];
+    auto load_unit = [&](int u, int m0p, int n0, int c, bool live) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int cbase = c * KCT;
+        if (u < A_PER) {
+            // UNCONDITIONAL load: masked-off units read the zero page (a conditional load makes
+            // hipcc drain vmcnt(0) before the MFMA block)
+            const int f = t + u * kThreads;
+            const int s = f / KQ, c4 = f - s * KQ;
+            const int gr = 2 * m0p - 1 + s;
+            const bool ok = live && f < A_UNITS && gr >= 0 && gr < a.rows_in && cbase + 4 * c4 < a.cp_in;
+            const float* src = ok ? a.x + (int64_t)gr * a.cp_in + cbase + 4 * c4 : a.zero;
+            ra[u] = *reinterpret_cast<const float4*>(src);
+        } else {
+            const int v = u - A_PER;
+            const int f = t + v * kThreads;
+            const int n = f / (4 * KQ), rem = f - n * (4 * KQ);
+            const float* src = (live && f < B_UNITS)
+                                   ? a.w + ((int64_t)(n0 + n) * a.nch + c) * (4 * KCT) + 4 * rem
+                                   : a.zero;
+            rb[v] = *reinterpret_cast<const float4*>(src);
+        }
+    };
+    auto store_unit = [&](int u, float* buf) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        if (u < A_PER) {
+            const int f = t + u * kThreads;
+            const int s = f / KQ, c4 = f - s * KQ;
+            if (f < A_UNITS) {
+                float2* d = reinterpret_cast<float2*>(buf + ((s & 1) ? PL : 0) + (s >> 1) * S + 4 * c4);
+                d[0] = make_float2(ra[u].x, ra[u].y);
+                d[1] = make_float2(ra[u].z, ra[u].w);
+            }
+        } else {
+            const int v = u - A_PER;
+            const int f = t + v * kThreads;
+            const int n = f / (4 * KQ), rem = f - n * (4 * KQ);
+            const int comp = rem / KQ, c4 = rem - comp * KQ;
+            if (f < B_UNITS) {
+                float2* d = reinterpret_cast<float2*>(buf + A_ELEMS + (comp * BN + n) * S + 4 * c4);
+                d[0] = make_float2(rb[v].x, rb[v].y);
+                d[1] = make_float2(rb[v].z, rb[v].w);
+            }
+        }
+    };
+
+    // ---- tile walk (conv_f32.hip): n-major order, XCD-contiguous blocks per round, rotation and
+    // zero-fill of tiles that lie entirely in a shorter read's padding ----------------------------
+    const int tiles = a.n_mtiles * a.n_ntiles;
+    auto tile_origin = [&](int q, int& tm0, int& tn0) {
+        const int nt_ = a.n_ntiles == 1 ? 0 : q / a.n_mtiles;
+        const int mi = q - nt_ * a.n_mtiles;
+        tm0 = mi * BMP;
+        tn0 = nt_ * BN;
+    };
+    const int nwg_ = gridDim.x;
+    const int blk_ = (nwg_ & 7) == 0 ? nwg_ >> 3 : nwg_;
+    const int blk_base_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x & 7) * blk_ : 0;
+    int slot_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int round_base_ = 0;
+    auto order_index = [&]() {
+        const int q = round_base_ + blk_base_ + slot_;
+        round_base_ += nwg_;
+        if (a.check_dead) {
+            slot_ += 5 % blk_;
+            if (slot_ >= blk_) slot_ -= blk_;
+        }
+        return q;
+    };
+    auto next_live = [&]() {
+        int q = order_index();
+        while (a.check_dead && q < tiles) {
+            int tm0, tn0;
+            tile_origin(q, tm0, tn0);
+            const int b = tm0 / a.P_out;
+            const int t0 = tm0 - b * a.P_out;
+            if (!(t0 + BMP <= a.P_out && t0 >= (a.len[b] >> a.shift_out))) break;
+            const int pieces_per_row = BN / 4;
+            for (int f = threadIdx.x; f < BMP * pieces_per_row; f += blockDim.x) {
+                const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 4;
+                const int prow = tm0 + rr, col = tn0 + cc;
+                if (prow < a.rows_out && col < a.cp_out)
+                    *reinterpret_cast<float4*>(a.y + (int64_t)prow * a.cp_out + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            q = order_index();
+        }
+        return q;
+    };
+    int o = next_live();
+    if (o >= tiles) return;
+
+    f32x4 acc[MT][NT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int c = 0;
+    int m0, n0;
+    tile_origin(o, m0, n0);
+#pragma unroll
+    for (int u = 0; u < A_PER + B_PER; ++u) load_unit(u, m0, n0, 0, true);
+#pragma unroll
+    for (int u = 0; u < A_PER + B_PER; ++u) store_unit(u, lds);
+    __syncthreads();
+    int buf = 0;
+
+    const int a_rd = (wm * 16 * MT + r) * S + kq;                  // + i*16*S (+ S) + c0, (+ PL for the even plane)
+    const int b_rd = A_ELEMS + (wn * 16 * NT + r) * S + kq;        // + (comp*BN + j*16)*S + c0
+
+    while (true) {
+        int nc = c + 1, no = o;
+        if (nc == a.nch) {
+            nc = 0;
+            no = next_live();
+        }
+        const bool has_next = no < tiles;
+        int nm0 = m0, nn0 = n0;
+        if (has_next && nc == 0) tile_origin(no, nm0, nn0);
+        const float* Ab = lds + buf * BUF + a_rd;
+        const float* Bb = lds + buf * BUF + b_rd;
+        float* nbuf = lds + (buf ^ 1) * BUF;
+
+        constexpr int NSLOTS = 4 * KQ;                 // slot = (k-step, component): MT * NT MFMAs
+        constexpr int UNITS = A_PER + B_PER;
+        // distributed staging: unit u of the next item is loaded after slot ld(u) and written to the
+        // other LDS buffer after slot ld(u) + DIST, so only ~DIST * UNITS / NSLOTS units are in
+        // registers at any time
+        constexpr int DIST = NSLOTS >= 20 ? 5 : 4;
+        constexpr int SPAN = NSLOTS - DIST;            // load slots 0 .. SPAN-1
+        float dr[MT][4];                               // raw inputs d0..d3 of the lane's pooled rows (next k-step)
+        float uf[2][NT];                               // weight fragments, double-buffered per slot
+        float v[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            dr[i][0] = Ab[i * 16 * S];
+            dr[i][2] = Ab[i * 16 * S + S];
+            dr[i][1] = Ab[PL + i * 16 * S];
+            dr[i][3] = Ab[PL + i * 16 * S + S];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) uf[0][j] = Bb[j * 16 * S];
+        static_for<NSLOTS>([&](auto SL) {
+            constexpr int sl = decltype(SL)::value;
+            constexpr int st = sl >> 2, comp = sl & 3;
+            if constexpr (comp == 0) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const float d0 = dr[i][0], d1 = dr[i][1], d2 = dr[i][2], d3 = dr[i][3];
+                    v[i][0] = d0 - d2;
+                    v[i][1] = d1 + d2;
+                    v[i][2] = d2 - d1;
+                    v[i][3] = d1 - d3;
+                }
+            }
+            if constexpr (comp == 1 && st + 1 < KQ) {
+                constexpr int c0 = 4 * (st + 1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    dr[i][0] = Ab[i * 16 * S + c0];
+                    dr[i][2] = Ab[i * 16 * S + S + c0];
+                    dr[i][1] = Ab[PL + i * 16 * S + c0];
+                    dr[i][3] = Ab[PL + i * 16 * S + S + c0];
+                }
+            }
+            if constexpr (sl + 1 < NSLOTS) {
+                constexpr int nst = (sl + 1) >> 2, ncomp = (sl + 1) & 3;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) uf[(sl + 1) & 1][j] = Bb[(ncomp * BN + j * 16) * S + 4 * nst];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j][comp] =
+                        __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl & 1][j], v[i][comp], acc[i][j][comp], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<UNITS>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                if constexpr ((u * SPAN) / UNITS == sl) load_unit(u, nm0, nn0, nc, has_next);
+                if constexpr ((u * SPAN) / UNITS + DIST == sl) {
+                    if (has_next) store_unit(u, nbuf);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+
+        if (c == a.nch - 1) {
+            // ---- epilogue: output transform + bias + ReLU + MaxPool, masked 16-byte stores -------
+            const int b0 = m0 / a.P_out;
+            const int p0 = m0 - b0 * a.P_out;
+            int prow_[MT];
+            bool valid_[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int loc = (wm * MT + i) * 16 + r;
+                const int prow = m0 + loc;
+                const bool in = prow < a.rows_out;
+                const int t = p0 + loc;
+                const int e = (int)(((float)t + 0.5f) * a.inv_P_out);     // t < P_out + BMP < 2^16: exact
+                const int b = in ? b0 + e : 0;
+                prow_[i] = in ? prow : -1;
+                valid_[i] = (t - e * a.P_out) < (a.len[b] >> a.shift_out);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + (wn * NT + j) * 16 + 4 * kq;
+                const float4 bi = *reinterpret_cast<const float4*>(a.bias + col);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    if (prow_[i] >= 0 && col < a.cp_out) {
+                        float o4[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float m1 = acc[i][j][0][q], m2 = acc[i][j][1][q], m3 = acc[i][j][2][q],
+                                        m4 = acc[i][j][3][q];
+                            const float y0 = (m1 + m2) + m3;
+                            const float y1 = (m2 - m3) - m4;
+                            const float bq = q == 0 ? bi.x : q == 1 ? bi.y : q == 2 ? bi.z : bi.w;
+                            o4[q] = valid_[i] ? fmaxf(fmaxf(y0, y1) + bq, 0.0f) : 0.0f;
+                        }
+                        *reinterpret_cast<float4*>(a.y + (int64_t)prow_[i] * a.cp_out + col) =
+                            make_float4(o4[0], o4[1], o4[2], o4[3]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();
+        buf ^= 1;
+        o = no;
+        c = nc;
+        m0 = nm0;
+        n0 = nn0;
+    }
+}
+
+using KernelFn = void (*)(const WinoArgs);
+
+struct Shape {
+    int wm, wn, mt, nt;
+    KernelFn fn[3];        // chunk = 16, 20, 24
+};
+
+#define RS_SHAPE(WM, WN, MT, NT)                                                                       \
+    {WM, WN, MT, NT, {conv_wino_kernel<WM, WN, MT, NT, 16>, conv_wino_kernel<WM, WN, MT, NT, 20>,     \
+                      conv_wino_kernel<WM, WN, MT, NT, 24>}}
+const Shape kShapes[] = {
+    // all 8 waves stacked along pooled rows
+    RS_SHAPE(8, 1, 2, 2), RS_SHAPE(8, 1, 2, 3), RS_SHAPE(8, 1, 2, 4), RS_SHAPE(8, 1, 1, 5), RS_SHAPE(8, 1, 1, 6),
+    RS_SHAPE(8, 1, 1, 7), RS_SHAPE(8, 1, 1, 8),
+    // 4 x 2 waves
+    RS_SHAPE(4, 2, 2, 3), RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 1, 5), RS_SHAPE(4, 2, 1, 7), RS_SHAPE(4, 2, 1, 8),
+    // 2 x 4 waves (few rows)
+    RS_SHAPE(2, 4, 2, 2), RS_SHAPE(2, 4, 2, 3), RS_SHAPE(2, 4, 1, 4),
+};
+#undef RS_SHAPE
+constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
+
+size_t lds_bytes(const Shape& s, int kc) {
+    const int bmp = s.wm * 16 * s.mt, bn = s.wn * 16 * s.nt;
+    return 2 * (size_t)(2 * (bmp + 1) + 4 * bn) * (kc + 2) * sizeof(float);
+}
+
+// Tile shape for a layer launch.  Model: one persistent workgroup per CU; time = rounds x (MFMA
+// issue of a tile + per-item staging and barrier + per-tile epilogue), in SIMD cycles.
+const Shape* choose_shape(int64_t rows_out, int n16, int kc, int nch, int num_cu, double* cost_out) {
+    const Shape* best = nullptr;
+    double best_cost = 1e300;
+    for (int k = 0; k < kNumShapes; ++k) {
+        const Shape& s = kShapes[k];
+        if (lds_bytes(s, kc) > 160 * 1024) continue;
+        const int bmp = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
+        const int64_t mtiles = (rows_out + bmp - 1) / bmp;
+        const int64_t ntiles = (n16 + bnt - 1) / bnt;
+        const int64_t tiles = mtiles * ntiles;
+        const int64_t rounds = (tiles + num_cu - 1) / num_cu;
+        const double slots = kc;                                    // 4 components x kc / 4 k-steps
+        const double staged = ((2.0 * bmp + 2) + 4.0 * bnt * 16) * kc * 4.0;   // bytes per item
+        const double item = slots * (2.0 * s.mt * s.nt * 32.0 + 4.0 * (s.mt + s.nt)) + 900.0 + 0.06 * staged;
+        const double tile = nch * item + 1500.0 + 60.0 * s.mt * s.nt;
+        const double cost = (double)rounds * tile;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = &s;
+        }
+    }
+    if (cost_out) *cost_out = best_cost;
+    return best;
+}
+
+}  // namespace
+
+int conv_wino_max_bn() { return 256; }
+
+int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
+                     int layer_index, int num_cu, const float* d_zero, int check_dead, hipStream_t st, int* bm_out,
+                     int* bn_out) {
+    const ConvPlan& p = L.plan;
+    if (p.kc != 16 && p.kc != 20 && p.kc != 24) {
+        set_error("conv_wino: unsupported channel chunk %d", p.kc);
+        return RS_ERR_ARG;
+    }
+    const int64_t rows64 = (int64_t)B * P_in;
+    if (rows64 > 0x7fffffff) {
+        set_error("conv_wino: batch too large (%lld rows)", (long long)rows64);
+        return RS_ERR_ARG;
+    }
+    const int n16 = round_up(L.c_out, 16) / 16;
+    const Shape* s = choose_shape(rows64 / 2, n16, p.kc, p.nch, num_cu, nullptr);
+    if (const char* force = getenv("RS_FORCE_SHAPE_WINO")) {        // tuning aid: "layer:wm,wn,mt,nt;..."
+        int l, wm, wn, mt, nt;
+        for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
+            if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
+                for (int k = 0; k < kNumShapes; ++k)
+                    if (kShapes[k].wm == wm && kShapes[k].wn == wn && kShapes[k].mt == mt && kShapes[k].nt == nt &&
+                        lds_bytes(kShapes[k], p.kc) <= 160 * 1024)
+                        s = &kShapes[k];
+    }
+    if (!s) {
+        set_error("conv_wino: no tile shape fits (kc=%d)", p.kc);
+        return RS_ERR_ARG;
+    }
+    const int BMP = s->wm * 16 * s->mt, BN = s->wn * 16 * s->nt;
+    WinoArgs a;
+    a.x = d_x;
+    a.w = static_cast<const float*>(L.d_w);
+    a.bias = L.d_bias;
+    a.y = d_y;
+    a.len = d_len;
+    a.zero = d_zero;
+    a.rows_in = (int)rows64;
+    a.rows_out = (int)(rows64 / 2);
+    a.P_out = P_in / 2;
+    a.inv_P_out = 1.0f / (float)a.P_out;
+    a.cp_in = L.cp_in;
+    a.cp_out = L.cp_out;
+    a.nch = p.nch;
+    a.shift_out = layer_index + 1;
+    a.n_mtiles = (a.rows_out + BMP - 1) / BMP;
+    a.n_ntiles = (n16 * 16 + BN - 1) / BN;
+    a.check_dead = check_dead;
+    const size_t lds = lds_bytes(*s, p.kc);
+    KernelFn fn = s->fn[p.kc == 16 ? 0 : p.kc == 20 ? 1 : 2];
+    RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, a);
+    RS_HIP(hipGetLastError());
+    if (bm_out) *bm_out = 2 * BMP;          // reported in conv rows, like the direct kernels
+    if (bn_out) *bn_out = BN;
+    return RS_OK;
+}
+
+}  // namespace rs

@@ -16,7 +16,7 @@ from . import _native as nv
 
 _DTYPES = {"f32": nv.RS_F32, "fp32": nv.RS_F32, "float32": nv.RS_F32,
            "bf16": nv.RS_BF16, "bfloat16": nv.RS_BF16, "f16": nv.RS_F16, "fp16": nv.RS_F16,
-           "float16": nv.RS_F16}
+           "float16": nv.RS_F16, "f32w": nv.RS_F32W, "f32_winograd": nv.RS_F32W}
 
 
 def _stream_ptr(device) -> int:

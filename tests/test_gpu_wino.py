@@ -1,0 +1,108 @@
+"""Parity of the Winograd F(2,3) fp32 conv path (rs_dtype RS_F32W, csrc/conv_wino.hip) through the
+C ABI: same bars as the direct fp32 path - probabilities within 1e-3 of the reference's torch-CPU
+results (golden fixtures) and of the numpy oracle, accept/reject labels identical at 0.9."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import riser_oracle as ro
+from riser_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-3
+SIG_SEED = 20260103
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+_models = {}
+
+
+def get_model(seed, dev, dtype="f32w"):
+    from riser_amd.model import Model
+    key = (seed, dtype)
+    if key not in _models:
+        _models[key] = Model(synth.make_state_dict(seed), synth.Config(), None, "mRNA", dtype=dtype, device=dev)
+    return _models[key]
+
+
+def test_wino_forward_golden(dev, golden_dir):
+    net = np.load(os.path.join(golden_dir, "network.npz"))
+    worst = 0.0
+    for seed, L, B, first in net["cases"]:
+        tag = f"s{seed}_L{L}_B{B}_r{first}"
+        sigs = synth.make_signals(int(net["sig_seed"][0]), int(B), int(L), first_read=int(first))
+        m = get_model(int(seed), dev)
+        xs = [ro.mad_normalise(s) for s in sigs]
+        probs, logits = m.classify_batch(xs, return_logits=True)
+        probs, logits = probs.cpu().numpy(), logits.cpu().numpy()
+        want = net[f"{tag}.probs"]
+        err = float(np.abs(probs - want).max())
+        worst = max(worst, err)
+        assert err < PROB_TOL, (tag, err)
+        assert np.array_equal(probs[:, 1] > 0.9, want[:, 1] > 0.9), tag
+        assert np.allclose(logits, net[f"{tag}.logits"], atol=2e-3), tag
+    print("winograd fp32: worst |dp| vs reference:", worst)
+    assert worst < 1e-4        # observed ~1e-5, the same as the direct fp32 path
+
+
+def test_wino_mixed_lengths_permutation_and_direct(dev):
+    m = get_model(2, dev)
+    md = get_model(2, dev, "f32")
+    lens = [4096, 4097, 4099, 5000, 6023, 6024, 8191, 8192, 8193, 8615, 11999, 12048, 15999, 16000, 16383, 16384, 20001]
+    sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=50 + i)[0] for i, n in enumerate(lens)]
+    xs = [ro.mad_normalise(s) for s in sigs]
+    sd = synth.make_state_dict(2)
+    want = np.stack([ro.classify(sd, x) for x in xs])
+    got = m.classify_batch(xs).cpu().numpy()
+    assert np.abs(got - want).max() < PROB_TOL
+    direct = md.classify_batch(xs).cpu().numpy()
+    assert np.abs(got - direct).max() < 1e-4
+    perm = np.random.default_rng(0).permutation(len(xs))
+    got_p = m.classify_batch([xs[i] for i in perm]).cpu().numpy()
+    assert np.array_equal(got_p, got[perm]), "per-read result must not depend on batch position"
+    for i in (0, 9, 16):
+        assert np.array_equal(m.classify_batch([xs[i]]).cpu().numpy()[0], got[i]), "batch of 1 == batched"
+
+
+def test_wino_small_custom_network(dev):
+    from riser_amd.model import Model
+    rng = np.random.default_rng(3)
+    channels = [8, 13, 21, 40, 70, 17]
+    sd, c_in = {}, 1
+    for i, c in enumerate(channels):
+        sd[f"layers.{i}.0.weight"] = (rng.standard_normal((c, c_in, 3)) * np.sqrt(2.0 / (3 * c_in))).astype(np.float32)
+        sd[f"layers.{i}.0.bias"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        c_in = c
+    sd["classifier.2.weight"] = rng.standard_normal((2, c_in)).astype(np.float32)
+    sd["classifier.2.bias"] = rng.standard_normal(2).astype(np.float32)
+    cfg = synth.Config(synth.CnnConfig(channels=channels, kernels=[3] * 6))
+    m = Model(sd, cfg, None, "x", dtype="f32w", device=dev)
+    xs = [rng.standard_normal(n).astype(np.float64) for n in (64, 65, 100, 777, 2048)]
+    got = m.classify_batch(xs).cpu().numpy()
+    want = np.stack([ro.classify(sd, x) for x in xs])
+    assert np.abs(got - want).max() < 1e-4
+    m.close()
+
+
+def test_wino_fused_raw_and_full_batch(dev):
+    """raw int16 -> probabilities on a 512 x 16000 batch: equal to the direct fp32 path within 1e-4,
+    labels identical, and a sample of reads checked against the oracle."""
+    from riser_amd.preprocess import pack_reads
+    B, L = 512, 16000
+    sigs = synth.make_signals(SIG_SEED, B, L)
+    sig, off, ln, lens = pack_reads(list(sigs), dev)
+    pw = get_model(1, dev).classify_raw(sig, off, ln, lens).cpu().numpy()
+    pd = get_model(1, dev, "f32").classify_raw(sig, off, ln, lens).cpu().numpy()
+    assert np.abs(pw - pd).max() < 1e-4
+    assert np.array_equal(pw[:, 1] > 0.9, pd[:, 1] > 0.9)
+    idx = [0, 17, 255, 511]
+    want = ro.classify_reads(synth.make_state_dict(1), [sigs[i] for i in idx])
+    assert np.abs(pw[idx] - want).max() < PROB_TOL
