@@ -45,6 +45,7 @@ namespace rs {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // compile-time loop: the body sees its index as a constant expression, so every register-array
 // index in the slot loop is static whatever hipcc's unroll heuristics decide
@@ -63,7 +64,8 @@ struct WinoArgs {
     const float* bias;     // [n_alloc]
     float* y;
     const int32_t* len;
-    const float* zero;     // >= 16 bytes of zeros (target of masked-off staging loads)
+    unsigned x_bytes;      // size of the activation buffer x (rows_in * cp_in floats), < 2^31
+    unsigned w_bytes;      // size of the packed weights, < 2^31
     int rows_in;           // B * P_in
     int rows_out;          // B * P_out
     int P_out;
@@ -87,10 +89,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     constexpr int PL = (BMP + 1) * S;                  // one parity plane
     constexpr int A_ELEMS = 2 * PL;
     constexpr int BUF = A_ELEMS + 4 * BN * S;
-    constexpr int A_UNITS = (2 * BMP + 2) * KQ;
-    constexpr int B_UNITS = BN * 4 * KQ;
-    constexpr int A_PER = (A_UNITS + kThreads - 1) / kThreads;
-    constexpr int B_PER = (B_UNITS + kThreads - 1) / kThreads;
+    // staging passes: a pass of the workgroup covers RPT slab rows x KQ 16-byte units of the X slab,
+    // or NPP output channels x 4 components x KQ units of the weight slab
+    constexpr int RPT = (kThreads / KQ) & ~1;
+    constexpr int A_ROWS = 2 * BMP + 2;
+    constexpr int A_PER = (A_ROWS + RPT - 1) / RPT;
+    constexpr int NPP = kThreads / (4 * KQ);
+    constexpr int B_PER = (BN + NPP - 1) / NPP;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
@@ -99,56 +104,70 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     const int wm = wave % WM, wn = wave / WM;
     const int r = lane & 15, kq = lane >> 4;
 
-    // ---- staging map, recomputed per use from an opaque copy of the thread index (keeping the
-    // per-unit LDS / global offsets in registers for the whole persistent loop costs ~14 VGPRs
-    // that the accumulators need) -----------------------------------------------------------------
-    // A unit f: slab row s = f / KQ (global input row 2*m0p - 1 + s), 4 channels at 4*(f % KQ).
-    // Even s = odd global row -> odd plane (offset 0), odd s -> even plane (offset PL); index s >> 1.
-    // B unit f: n = f / (4*KQ), rem = f % (4*KQ) = comp * KQ + c4; global packing [n][nch][4][KC].
-    float4 ra[A_PER], rb[B_PER];
-    auto load_unit = [&](int u, int m0p, int n0, int c, bool live) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        const int cbase = c * KCT;
-        if (u < A_PER) {
-            // UNCONDITIONAL load: masked-off units read the zero page (a conditional load makes
-            // hipcc drain vmcnt(0) before the MFMA block)
-            const int f = t + u * kThreads;
-            const int s = f / KQ, c4 = f - s * KQ;
-            const int gr = 2 * m0p - 1 + s;
-            const bool ok = live && f < A_UNITS && gr >= 0 && gr < a.rows_in && cbase + 4 * c4 < a.cp_in;
-            const float* src = ok ? a.x + (int64_t)gr * a.cp_in + cbase + 4 * c4 : a.zero;
-            ra[u] = *reinterpret_cast<const float4*>(src);
+    // ---- staging map ------------------------------------------------------------------------------
+    // Thread t of a pass owns slab row t / KQ (global input row 2*m0p - 1 + row), channels 4*(t % KQ)
+    // of the chunk; pass u adds u * RPT rows.  RPT is even, so the parity plane of a thread's rows is
+    // fixed: even slab row = odd global row -> odd plane (offset 0), odd slab row -> even plane
+    // (offset PL), index row >> 1, and pass u is an immediate LDS offset.  Weights: thread t owns
+    // output channel t / (4*KQ), unit t % (4*KQ) = comp * KQ + c4 of the packed [n][nch][4][KC] row.
+    // Global loads are BUFFER loads with a 32-bit byte offset: rows before the first / after the last
+    // row of the activation buffer, the K padding of the last chunk, idle threads and the prefetch
+    // after the last item all resolve to an out-of-range offset, which the hardware answers with
+    // zeros - no address arithmetic beyond one add per unit, no branches, no zero page.
+    const int a_row = tid / KQ, a_c4 = tid - a_row * KQ;
+    const bool a_act = a_row < RPT;
+    const int b_n = tid / (4 * KQ), b_rem = tid - b_n * (4 * KQ);
+    const bool b_act = b_n < NPP;
+    const int a_st = ((a_row & 1) ? PL : 0) + (a_row >> 1) * S + 4 * a_c4;          // + u * (RPT/2) * S
+    const int b_st = A_ELEMS + ((b_rem / KQ) * BN + b_n) * S + 4 * (b_rem % KQ);    // + u * NPP * S
+    const unsigned a_tb = (unsigned)(a_row * a.cp_in + 4 * a_c4) * 4u;
+    const unsigned b_tb = (unsigned)(b_n * a.nch * 4 * KCT + 4 * b_rem) * 4u;
+    const unsigned a_step = (unsigned)(RPT * a.cp_in) * 4u;
+    const unsigned b_step = (unsigned)(NPP * a.nch * 4 * KCT) * 4u;
+    constexpr unsigned kOob = 0x80000000u;             // >= num_records of either buffer (host checks)
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+
+    u32x4 ra[A_PER], rb[B_PER];
+    unsigned a_ib = kOob, b_ib = kOob;                  // per-item byte offsets of this thread's first units
+    auto item_offsets = [&](int m0p, int n0, int c, bool live) {
+        const bool a_ok = live && a_act && c * KCT + 4 * a_c4 < a.cp_in;
+        a_ib = a_ok ? a_tb + (unsigned)((2 * m0p - 1) * a.cp_in + c * KCT) * 4u : kOob;
+        b_ib = (live && b_act) ? b_tb + (unsigned)((n0 * a.nch + c) * 4 * KCT) * 4u : kOob;
+    };
+    auto load_unit = [&](auto U) {
+        constexpr int u = decltype(U)::value;
+        if constexpr (u < A_PER) {
+            unsigned off = a_ib + (unsigned)u * a_step;
+            if constexpr ((u + 1) * RPT > A_ROWS) off = (a_row + u * RPT < A_ROWS) ? off : kOob;
+            ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
         } else {
-            const int v = u - A_PER;
-            const int f = t + v * kThreads;
-            const int n = f / (4 * KQ), rem = f - n * (4 * KQ);
-            const float* src = (live && f < B_UNITS)
-                                   ? a.w + ((int64_t)(n0 + n) * a.nch + c) * (4 * KCT) + 4 * rem
-                                   : a.zero;
-            rb[v] = *reinterpret_cast<const float4*>(src);
+            constexpr int v = u - A_PER;
+            unsigned off = b_ib + (unsigned)v * b_step;
+            if constexpr ((v + 1) * NPP > BN) off = (b_n + v * NPP < BN) ? off : kOob;
+            rb[v] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
         }
     };
-    auto store_unit = [&](int u, float* buf) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        if (u < A_PER) {
-            const int f = t + u * kThreads;
-            const int s = f / KQ, c4 = f - s * KQ;
-            if (f < A_UNITS) {
-                float2* d = reinterpret_cast<float2*>(buf + ((s & 1) ? PL : 0) + (s >> 1) * S + 4 * c4);
-                d[0] = make_float2(ra[u].x, ra[u].y);
-                d[1] = make_float2(ra[u].z, ra[u].w);
+    auto store_unit = [&](auto U, float* buf) {
+        constexpr int u = decltype(U)::value;
+        if constexpr (u < A_PER) {
+            bool act = a_act;
+            if constexpr ((u + 1) * RPT > A_ROWS) act = act && (a_row + u * RPT < A_ROWS);
+            if (act) {
+                uint2* d = reinterpret_cast<uint2*>(buf + a_st + u * (RPT / 2) * S);
+                d[0] = make_uint2(ra[u].x, ra[u].y);
+                d[1] = make_uint2(ra[u].z, ra[u].w);
             }
         } else {
-            const int v = u - A_PER;
-            const int f = t + v * kThreads;
-            const int n = f / (4 * KQ), rem = f - n * (4 * KQ);
-            const int comp = rem / KQ, c4 = rem - comp * KQ;
-            if (f < B_UNITS) {
-                float2* d = reinterpret_cast<float2*>(buf + A_ELEMS + (comp * BN + n) * S + 4 * c4);
-                d[0] = make_float2(rb[v].x, rb[v].y);
-                d[1] = make_float2(rb[v].z, rb[v].w);
+            constexpr int v = u - A_PER;
+            bool act = b_act;
+            if constexpr ((v + 1) * NPP > BN) act = act && (b_n + v * NPP < BN);
+            if (act) {
+                uint2* d = reinterpret_cast<uint2*>(buf + b_st + v * NPP * S);
+                d[0] = make_uint2(rb[v].x, rb[v].y);
+                d[1] = make_uint2(rb[v].z, rb[v].w);
             }
         }
     };
@@ -209,10 +228,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     int c = 0;
     int m0, n0;
     tile_origin(o, m0, n0);
-#pragma unroll
-    for (int u = 0; u < A_PER + B_PER; ++u) load_unit(u, m0, n0, 0, true);
-#pragma unroll
-    for (int u = 0; u < A_PER + B_PER; ++u) store_unit(u, lds);
+    item_offsets(m0, n0, 0, true);
+    static_for<A_PER + B_PER>([&](auto U) { load_unit(U); });
+    static_for<A_PER + B_PER>([&](auto U) { store_unit(U, lds); });
     __syncthreads();
     int buf = 0;
 
@@ -231,6 +249,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
         const float* Ab = lds + buf * BUF + a_rd;
         const float* Bb = lds + buf * BUF + b_rd;
         float* nbuf = lds + (buf ^ 1) * BUF;
+        item_offsets(nm0, nn0, nc, has_next);
 
         constexpr int NSLOTS = 4 * KQ;                 // slot = (k-step, component): MT * NT MFMAs
         constexpr int UNITS = A_PER + B_PER;
@@ -288,9 +307,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             static_for<UNITS>([&](auto U) {
                 constexpr int u = decltype(U)::value;
-                if constexpr ((u * SPAN) / UNITS == sl) load_unit(u, nm0, nn0, nc, has_next);
+                if constexpr ((u * SPAN) / UNITS == sl) load_unit(U);
                 if constexpr ((u * SPAN) / UNITS + DIST == sl) {
-                    if (has_next) store_unit(u, nbuf);
+                    if (has_next) store_unit(U, nbuf);
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
@@ -441,7 +460,14 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
     a.bias = L.d_bias;
     a.y = d_y;
     a.len = d_len;
-    a.zero = d_zero;
+    const int64_t xb = rows64 * L.cp_in * 4, wb = (int64_t)p.n_alloc * p.nch * 4 * p.kc * 4;
+    if (xb >= 0x80000000LL || wb >= 0x80000000LL) {
+        set_error("conv_wino: activation buffer of %lld bytes exceeds the 2 GiB buffer-load window, split the batch",
+                  (long long)xb);
+        return RS_ERR_ARG;
+    }
+    a.x_bytes = (unsigned)xb;
+    a.w_bytes = (unsigned)wb;
     a.rows_in = (int)rows64;
     a.rows_out = (int)(rows64 / 2);
     a.P_out = P_in / 2;
