@@ -66,6 +66,10 @@ struct WinoArgs {
     const int32_t* len;
     unsigned x_bytes;      // size of the activation buffer x (rows_in * cp_in floats), < 2^31
     unsigned w_bytes;      // size of the packed weights, < 2^31
+    unsigned y_bytes;      // size of the output buffer (rows_out * cp_out floats), < 2^31
+    unsigned y_row_bytes;  // cp_out * 4
+    unsigned len_bytes;    // B * 4
+    unsigned bias_bytes;   // n_alloc * 4
     int rows_in;           // B * P_in
     int rows_out;          // B * P_out
     int P_out;
@@ -130,12 +134,22 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
 
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_len =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.len), 0, a.len_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_bias =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias_bytes, 0x00020000);
+
     u32x4 ra[A_PER], rb[B_PER];
     unsigned a_ib = kOob, b_ib = kOob;                  // per-item byte offsets of this thread's first units
     auto item_offsets = [&](int m0p, int n0, int c, bool live) {
         const bool a_ok = live && a_act && c * KCT + 4 * a_c4 < a.cp_in;
         a_ib = a_ok ? a_tb + (unsigned)((2 * m0p - 1) * a.cp_in + c * KCT) * 4u : kOob;
         b_ib = (live && b_act) ? b_tb + (unsigned)((n0 * a.nch + c) * 4 * KCT) * 4u : kOob;
+#ifdef RS_ABL_NOLOAD                                    // timing experiment only: every staging load out of range
+        a_ib = kOob;
+        b_ib = kOob;
+#endif
     };
     auto load_unit = [&](auto U) {
         constexpr int u = decltype(U)::value;
@@ -155,6 +169,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
         if constexpr (u < A_PER) {
             bool act = a_act;
             if constexpr ((u + 1) * RPT > A_ROWS) act = act && (a_row + u * RPT < A_ROWS);
+#ifdef RS_ABL_NOLDSW
+            asm volatile("" ::"v"(ra[u].x), "v"(ra[u].y), "v"(ra[u].z), "v"(ra[u].w));
+            act = false;
+#endif
             if (act) {
                 uint2* d = reinterpret_cast<uint2*>(buf + a_st + u * (RPT / 2) * S);
                 d[0] = make_uint2(ra[u].x, ra[u].y);
@@ -164,6 +182,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
             constexpr int v = u - A_PER;
             bool act = b_act;
             if constexpr ((v + 1) * NPP > BN) act = act && (b_n + v * NPP < BN);
+#ifdef RS_ABL_NOLDSW
+            asm volatile("" ::"v"(rb[v].x), "v"(rb[v].y), "v"(rb[v].z), "v"(rb[v].w));
+            act = false;
+#endif
             if (act) {
                 uint2* d = reinterpret_cast<uint2*>(buf + b_st + v * NPP * S);
                 d[0] = make_uint2(rb[v].x, rb[v].y);
@@ -217,13 +239,15 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     int o = next_live();
     if (o >= tiles) return;
 
-    f32x4 acc[MT][NT][4];
+    f32x4 acc[MT][NT][4];                             // small shapes: written by the first item of every tile
+    if constexpr (MT * NT > 6) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 4; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     int c = 0;
     int m0, n0;
@@ -255,105 +279,163 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
         constexpr int UNITS = A_PER + B_PER;
         // distributed staging: unit u of the next item is loaded after slot ld(u) and written to the
         // other LDS buffer after slot ld(u) + DIST, so only ~DIST * UNITS / NSLOTS units are in
-        // registers at any time
-        constexpr int DIST = NSLOTS >= 20 ? 5 : 4;
+        // registers at any time (more where the accumulators leave registers free: the early
+        // layers stream from HBM and need the longer flight time)
+        constexpr int DIST_LONG = NSLOTS - UNITS > 4 ? NSLOTS - UNITS : 4;
+        constexpr int DIST = MT * NT <= 4 ? DIST_LONG : MT * NT <= 6 ? (NSLOTS / 2 < DIST_LONG ? NSLOTS / 2 : DIST_LONG)
+                                                                  : (NSLOTS >= 20 ? 5 : 4);
         constexpr int SPAN = NSLOTS - DIST;            // load slots 0 .. SPAN-1
-        float dr[MT][4];                               // raw inputs d0..d3 of the lane's pooled rows (next k-step)
-        float uf[2][NT];                               // weight fragments, double-buffered per slot
-        float v[MT][4];
+        constexpr int EPI_SLOT = NSLOTS - 3;           // where the epilogue's look-ups are issued
+        // the 128-accumulator shapes have no registers to spare (and their tiles are long: an exposed L2
+        // round trip and 128 v_mov per tile are noise): they look up / zero in the epilogue instead
+        constexpr bool HOIST = MT * NT <= 6;
+        constexpr bool HOIST_BIAS = HOIST;
+        // epilogue look-ups (per-read lengths of the lane's rows, bias of its channels): issued
+        // UNCONDITIONALLY near the end of every item so that their L2 latency hides under the last
+        // MFMAs; only the tile's last item uses them
+        const int b0 = m0 / a.P_out;
+        const int p0 = m0 - b0 * a.P_out;
+        int pin_[MT];
+        unsigned lenv_[MT];
+        u32x4 bi_[NT];
+        auto run_item = [&](auto FIRST) {
+            constexpr bool first = decltype(FIRST)::value;     // first item of a tile: accumulate onto zero
+            float dr[MT][4];                           // raw inputs d0..d3 of the lane's pooled rows (next k-step)
+            float uf[2][NT];                           // weight fragments, double-buffered per slot
+            float v[MT][4];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            dr[i][0] = Ab[i * 16 * S];
-            dr[i][2] = Ab[i * 16 * S + S];
-            dr[i][1] = Ab[PL + i * 16 * S];
-            dr[i][3] = Ab[PL + i * 16 * S + S];
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) uf[0][j] = Bb[j * 16 * S];
-        static_for<NSLOTS>([&](auto SL) {
-            constexpr int sl = decltype(SL)::value;
-            constexpr int st = sl >> 2, comp = sl & 3;
-            if constexpr (comp == 0) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const float d0 = dr[i][0], d1 = dr[i][1], d2 = dr[i][2], d3 = dr[i][3];
-                    v[i][0] = d0 - d2;
-                    v[i][1] = d1 + d2;
-                    v[i][2] = d2 - d1;
-                    v[i][3] = d1 - d3;
-                }
-            }
-            if constexpr (comp == 1 && st + 1 < KQ) {
-                constexpr int c0 = 4 * (st + 1);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    dr[i][0] = Ab[i * 16 * S + c0];
-                    dr[i][2] = Ab[i * 16 * S + S + c0];
-                    dr[i][1] = Ab[PL + i * 16 * S + c0];
-                    dr[i][3] = Ab[PL + i * 16 * S + S + c0];
-                }
-            }
-            if constexpr (sl + 1 < NSLOTS) {
-                constexpr int nst = (sl + 1) >> 2, ncomp = (sl + 1) & 3;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) uf[(sl + 1) & 1][j] = Bb[(ncomp * BN + j * 16) * S + 4 * nst];
+            for (int i = 0; i < MT; ++i) {
+                dr[i][0] = Ab[i * 16 * S];
+                dr[i][2] = Ab[i * 16 * S + S];
+                dr[i][1] = Ab[PL + i * 16 * S];
+                dr[i][3] = Ab[PL + i * 16 * S + S];
             }
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int j = 0; j < NT; ++j) uf[0][j] = Bb[j * 16 * S];
+            static_for<NSLOTS>([&](auto SL) {
+                constexpr int sl = decltype(SL)::value;
+                constexpr int st = sl >> 2, comp = sl & 3;
+                if constexpr (comp == 0) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j][comp] =
-                        __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl & 1][j], v[i][comp], acc[i][j][comp], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<UNITS>([&](auto U) {
-                constexpr int u = decltype(U)::value;
-                if constexpr ((u * SPAN) / UNITS == sl) load_unit(U);
-                if constexpr ((u * SPAN) / UNITS + DIST == sl) {
-                    if (has_next) store_unit(U, nbuf);
+                    for (int i = 0; i < MT; ++i) {
+                        const float d0 = dr[i][0], d1 = dr[i][1], d2 = dr[i][2], d3 = dr[i][3];
+                        v[i][0] = d0 - d2;
+                        v[i][1] = d1 + d2;
+                        v[i][2] = d2 - d1;
+                        v[i][3] = d1 - d3;
+                    }
                 }
+                if constexpr (comp == 1 && st + 1 < KQ) {
+                    constexpr int c0 = 4 * (st + 1);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        dr[i][0] = Ab[i * 16 * S + c0];
+                        dr[i][2] = Ab[i * 16 * S + S + c0];
+                        dr[i][1] = Ab[PL + i * 16 * S + c0];
+                        dr[i][3] = Ab[PL + i * 16 * S + S + c0];
+                    }
+                }
+                if constexpr (sl + 1 < NSLOTS) {
+                    constexpr int nst = (sl + 1) >> 2, ncomp = (sl + 1) & 3;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) uf[(sl + 1) & 1][j] = Bb[(ncomp * BN + j * 16) * S + 4 * nst];
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        if constexpr (first && st == 0)
+                            acc[i][j][comp] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                uf[sl & 1][j], v[i][comp], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        else
+                            acc[i][j][comp] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl & 1][j], v[i][comp],
+                                                                                   acc[i][j][comp], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<UNITS>([&](auto U) {
+                    constexpr int u = decltype(U)::value;
+                    if constexpr ((u * SPAN) / UNITS == sl) load_unit(U);
+                    if constexpr ((u * SPAN) / UNITS + DIST == sl) {
+                        if (has_next) store_unit(U, nbuf);
+                    }
+                });
+                if constexpr (HOIST && sl == EPI_SLOT) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const int t = p0 + (wm * MT + i) * 16 + r;
+                        const int e = (int)(((float)t + 0.5f) * a.inv_P_out);     // t < P_out + BMP < 2^16: exact
+                        pin_[i] = t - e * a.P_out;
+                        // rows past the end of the batch look up a read index >= B: out of range -> 0 -> masked
+                        lenv_[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_len, (unsigned)(b0 + e) * 4u, 0, 0);
+                    }
+                    if constexpr (HOIST_BIAS) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            bi_[j] = __builtin_amdgcn_raw_buffer_load_b128(
+                                rs_bias, (unsigned)(n0 + (wn * NT + j) * 16 + 4 * kq) * 4u, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             });
-            __builtin_amdgcn_sched_barrier(0);
-        });
+        };
+        if constexpr (HOIST) {
+            if (c == 0)
+                run_item(std::true_type{});
+            else
+                run_item(std::false_type{});
+        } else {
+            run_item(std::false_type{});
+        }
 
         if (c == a.nch - 1) {
-            // ---- epilogue: output transform + bias + ReLU + MaxPool, masked 16-byte stores -------
-            const int b0 = m0 / a.P_out;
-            const int p0 = m0 - b0 * a.P_out;
-            int prow_[MT];
+            // ---- epilogue: output transform + bias + ReLU + MaxPool, 16-byte buffer stores (rows past the
+            // end of the batch and columns past cp_out resolve to out-of-range offsets and are dropped;
+            // rows beyond their read's length are written as zeros) -------------------------------------
+            if constexpr (!HOIST) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int t = p0 + (wm * MT + i) * 16 + r;
+                    const int e = (int)(((float)t + 0.5f) * a.inv_P_out);
+                    pin_[i] = t - e * a.P_out;
+                    lenv_[i] = __builtin_amdgcn_raw_buffer_load_b32(rs_len, (unsigned)(b0 + e) * 4u, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bi_[j] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rs_bias, (unsigned)(n0 + (wn * NT + j) * 16 + 4 * kq) * 4u, 0, 0);
+            }
+            unsigned rowoff_[MT];
             bool valid_[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int loc = (wm * MT + i) * 16 + r;
-                const int prow = m0 + loc;
-                const bool in = prow < a.rows_out;
-                const int t = p0 + loc;
-                const int e = (int)(((float)t + 0.5f) * a.inv_P_out);     // t < P_out + BMP < 2^16: exact
-                const int b = in ? b0 + e : 0;
-                prow_[i] = in ? prow : -1;
-                valid_[i] = (t - e * a.P_out) < (a.len[b] >> a.shift_out);
+                rowoff_[i] = (unsigned)(m0 + (wm * MT + i) * 16 + r) * a.y_row_bytes;
+                valid_[i] = pin_[i] < (int)(lenv_[i] >> a.shift_out);
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int col = n0 + (wn * NT + j) * 16 + 4 * kq;
-                const float4 bi = *reinterpret_cast<const float4*>(a.bias + col);
+                const unsigned coloff = col < a.cp_out ? (unsigned)col * 4u : kOob;
+                const f32x4 bi = __builtin_bit_cast(f32x4, bi_[j]);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    if (prow_[i] >= 0 && col < a.cp_out) {
-                        float o4[4];
+                    f32x4 o4;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float m1 = acc[i][j][0][q], m2 = acc[i][j][1][q], m3 = acc[i][j][2][q],
-                                        m4 = acc[i][j][3][q];
-                            const float y0 = (m1 + m2) + m3;
-                            const float y1 = (m2 - m3) - m4;
-                            const float bq = q == 0 ? bi.x : q == 1 ? bi.y : q == 2 ? bi.z : bi.w;
-                            o4[q] = valid_[i] ? fmaxf(fmaxf(y0, y1) + bq, 0.0f) : 0.0f;
-                        }
-                        *reinterpret_cast<float4*>(a.y + (int64_t)prow_[i] * a.cp_out + col) =
-                            make_float4(o4[0], o4[1], o4[2], o4[3]);
+                    for (int q = 0; q < 4; ++q) {
+                        const float m1 = acc[i][j][0][q], m2 = acc[i][j][1][q], m3 = acc[i][j][2][q],
+                                    m4 = acc[i][j][3][q];
+                        const float y0 = (m1 + m2) + m3;
+                        const float y1 = (m2 - m3) - m4;
+                        o4[q] = valid_[i] ? fmaxf(fmaxf(y0, y1) + bi[q], 0.0f) : 0.0f;
                     }
+#ifdef RS_ABL_NOSTORE
+                    asm volatile("" ::"v"(o4[0]), "v"(o4[1]), "v"(o4[2]), "v"(o4[3]));
+#else
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), rs_y, rowoff_[i] + coloff, 0, 0);
+#endif
+                    if constexpr (!HOIST) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        for (int q = 0; q < 4; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
                 }
             }
         }
@@ -468,6 +550,14 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
     }
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
+    a.y_bytes = (unsigned)(rows64 / 2 * L.cp_out * 4);          // < x_bytes * 2 ... checked below
+    a.y_row_bytes = (unsigned)L.cp_out * 4u;
+    a.len_bytes = (unsigned)B * 4u;
+    a.bias_bytes = (unsigned)p.n_alloc * 4u;
+    if (rows64 / 2 * L.cp_out * 4 >= 0x80000000LL) {
+        set_error("conv_wino: output buffer exceeds the 2 GiB buffer-store window, split the batch");
+        return RS_ERR_ARG;
+    }
     a.rows_in = (int)rows64;
     a.rows_out = (int)(rows64 / 2);
     a.P_out = P_in / 2;

@@ -1,4 +1,4 @@
-"""A/B two builds of the library in one process launch sequence (alternating), fp32 per-step time."""
+"""A/B two builds of the library in one process launch sequence (alternating), per-step time of dtype $RS_DT (default f32)."""
 import sys, os, subprocess, json
 libs = sys.argv[1:]
 code = r'''
@@ -12,7 +12,7 @@ B, L = 512, 16000
 sigs = synth.make_signals(20260103, B, L)
 dev = torch.device("cuda", 0)
 sig, off, ln, lens = pack_reads(list(sigs), dev)
-m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA")
+m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=os.environ.get("RS_DT", "f32"))
 out = torch.empty((B, 2), device=dev)
 for _ in range(5): m.classify_raw(sig, off, ln, lens, out=out)
 torch.cuda.synchronize(); t = time.perf_counter()
