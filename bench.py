@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py - chunks/s of the squiggle-classification hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|f32_direct|bf16|f16]
 
 One "step" = one pass of the hot path over one batch of 512 synthetic RNA004 4 s chunks
 (512 x 16000 int16 samples, BASELINE.json configs[1]) already resident in HBM:
-MAD-normalise + 12-layer ConvNet forward + softmax, through the C ABI.  With N > 1 (launched
+MAD-normalise + 12-layer ConvNet forward + softmax, through the C ABI.  The default
+arithmetic is fp32 end to end with the conv layers lowered to Winograd F(2,3) on the f32-input
+MFMA (rs_dtype RS_F32W); --dtype f32_direct runs the direct lowering (exact fmaf chains).  With N > 1 (launched
 by torch.distributed.run, one rank per GPU) every rank steps its own 512-read shard - reads
 are independent, there is no data-path collective - and the printed value is the whole-job
 aggregate over the max-over-ranks time ("scaling": "weak").
@@ -54,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f32_direct", "bf16", "f16"])
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--chunk", type=int, default=CHUNK)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -77,7 +79,8 @@ def main():
     from riser_amd.preprocess import pack_reads
 
     B, L = args.batch, args.chunk
-    model = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=args.dtype, device=device)
+    lib_dtype = {"f32": "f32w", "f32_direct": "f32"}.get(args.dtype, args.dtype)
+    model = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=lib_dtype, device=device)
     # each rank owns a different shard of the synthetic read population
     sigs = synth.make_signals(SIG_SEED, B, L, first_read=rank * B)
     sig, off, ln, lens = pack_reads(list(sigs), device)
@@ -134,25 +137,35 @@ def main():
     conv_ms = float(stage_ms[2:2 + model.n_layers - 1].sum()) / max(calls, 1)      # per step, all conv launches
     conv_flop = sum(flops[1:]) * B
     achieved_tf = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    peak = PEAK_F32_MFMA_TF if args.dtype == "f32" else PEAK_BF16_MFMA_TF
+    peak = PEAK_F32_MFMA_TF if args.dtype in ("f32", "f32_direct") else PEAK_BF16_MFMA_TF
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
             with open(pmc_path) as f:
-                traffic = json.load(f).get(args.dtype, {}).get("conv_stack_hbm_bytes_per_step")
+                traffic = json.load(f).get(lib_dtype, {}).get("conv_stack_hbm_bytes_per_step")
         except Exception:
             traffic = None
     info = model.layer_info()
     per_layer = []
+    executed_flop = 0.0                    # MFMA FLOPs the kernels really issue: padded tiles, Winograd's 4-for-6
     for i in range(1, model.n_layers):
         ms = float(stage_ms[1 + i]) / max(calls, 1)
+        P_in = model.padded_length(L) >> i
+        rows = B * (P_in // 2 if lib_dtype == "f32w" else P_in)          # GEMM rows: pooled rows for Winograd
+        executed_flop += 2.0 * rows * info[i]["n_pad"] * info[i]["k_pad"]
         per_layer.append({"layer": i, "ms": round(ms, 4),
                           "tflops": round(flops[i] * B / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
                           "tile": [info[i]["bm"], info[i]["bn"], info[i]["kc"]]})
-    roofline = {"bound": "mfma", "kernel": "conv_%s_kernel (11 launches/step, layers 1-11)" % args.dtype,
+    executed_tf = executed_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    kname = {"f32w": "conv_wino_kernel (Winograd F(2,3), f32-input MFMA)", "f32": "conv_f32_kernel (direct, f32-input MFMA)"}.get(
+        lib_dtype, "conv_h16_kernel (%s MFMA)" % lib_dtype)
+    roofline = {"bound": "mfma", "kernel": kname + ", 11 launches/step, layers 1-11",
                 "achieved": round(achieved_tf, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / peak, 4), "traffic": traffic,
+                "achieved_note": "algorithmic FLOPs of the direct convolution (SURVEY.md 8(d): 582.95 MFLOP per chunk in "
+                                 "layers 1-11) / measured time; Winograd F(2,3) issues 2/3 of them on the matrix pipe",
+                "executed_mfma_tflops": round(executed_tf, 2), "executed_mfma_frac": round(executed_tf / peak, 4),
                 "avg_launch_ms": round(conv_ms / (model.n_layers - 1), 4),
                 "stage_ms": {"normalise": round(float(stage_ms[0]) / max(calls, 1), 4),
                              "conv0": round(float(stage_ms[1]) / max(calls, 1), 4),
@@ -164,9 +177,11 @@ def main():
         "metric": "signal chunks classified/sec (RNA004 4 s chunks, batch=512)",
         "value": round(value, 1), "unit": "chunks/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32" if lib_dtype in ("f32", "f32w") else lib_dtype,
+        "data": "synthetic",
         "config": {"workload": f"mRNA RNA004 model, batch={B} x {L}-sample (4 s) int16 chunks resident in HBM, "
                                f"MAD-normalise + 12-layer ConvNet forward + softmax, {args.dtype}",
+                   "conv_algorithm": {"f32w": "winograd_f23_fp32", "f32": "direct_fp32"}.get(lib_dtype, "direct_" + lib_dtype),
                    "batch_per_gpu": B, "chunk_samples": L, "sharding": "reads by id across GPUs, no collectives"},
         "p50_batch_latency_ms": round(p50, 3), "p99_batch_latency_ms": round(p99, 3),
         "latency_note": "host wall time per 512-read batch incl. H2D of int16 signals from pinned memory and D2H of probabilities",
@@ -177,7 +192,7 @@ def main():
     if world == 1 and not args.no_variants and args.dtype == "f32":
         ref = probs.cpu().numpy().copy()
         variants = {}
-        for dt in ("f16", "bf16"):
+        for dt in ("f32", "f16", "bf16"):
             mv = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dt, device=device)
             pv = torch.empty((B, 2), dtype=torch.float32, device=device)
             for _ in range(max(2, args.warmup)):
@@ -189,10 +204,11 @@ def main():
             torch.cuda.synchronize(device)
             dtv = (time.perf_counter() - t1) / args.steps
             pvh = pv.cpu().numpy()
-            variants[dt] = {"chunks_per_s": round(B / dtv, 1), "ms_per_step": round(dtv * 1e3, 4),
-                            "max_abs_dprob_vs_f32": float(np.abs(pvh - ref).max()),
-                            "label_flips_at_0.9_vs_f32": int(((pvh[:, 1] > 0.9) != (ref[:, 1] > 0.9)).sum()),
-                            "batch": B}
+            variants["f32_direct" if dt == "f32" else dt] = {
+                "chunks_per_s": round(B / dtv, 1), "ms_per_step": round(dtv * 1e3, 4),
+                "max_abs_dprob_vs_f32": float(np.abs(pvh - ref).max()),
+                "label_flips_at_0.9_vs_f32": int(((pvh[:, 1] > 0.9) != (ref[:, 1] > 0.9)).sum()),
+                "batch": B}
             mv.close()
         # BASELINE config 3: three-model ensemble, bf16, normalise once + three forwards + decision
         from riser_amd.preprocess import Kit, SignalProcessor

@@ -33,13 +33,16 @@ def get_model(seed, dev, dtype="f32w"):
     return _models[key]
 
 
-def test_wino_forward_golden(dev, golden_dir):
+@pytest.mark.parametrize("dtype", ["f32w", "f32"])
+def test_wino_forward_golden(dev, golden_dir, dtype):
+    """both fp32 lowerings (Winograd = the default of Model, and the direct one) against the
+    reference's own outputs"""
     net = np.load(os.path.join(golden_dir, "network.npz"))
     worst = 0.0
     for seed, L, B, first in net["cases"]:
         tag = f"s{seed}_L{L}_B{B}_r{first}"
         sigs = synth.make_signals(int(net["sig_seed"][0]), int(B), int(L), first_read=int(first))
-        m = get_model(int(seed), dev)
+        m = get_model(int(seed), dev, dtype)
         xs = [ro.mad_normalise(s) for s in sigs]
         probs, logits = m.classify_batch(xs, return_logits=True)
         probs, logits = probs.cpu().numpy(), logits.cpu().numpy()
@@ -49,7 +52,7 @@ def test_wino_forward_golden(dev, golden_dir):
         assert err < PROB_TOL, (tag, err)
         assert np.array_equal(probs[:, 1] > 0.9, want[:, 1] > 0.9), tag
         assert np.allclose(logits, net[f"{tag}.logits"], atol=2e-3), tag
-    print("winograd fp32: worst |dp| vs reference:", worst)
+    print(dtype, "worst |dp| vs reference:", worst)
     assert worst < 1e-4        # observed ~1e-5, the same as the direct fp32 path
 
 
