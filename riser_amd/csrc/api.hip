@@ -117,8 +117,8 @@ WsLayout ws_layout(const rs_model* m, int B, int Lmax) {
         buf = std::max(buf, rows * m->cp[i] * esize(m));
     }
     buf = align_up(buf + kAlign);
-    w.xnorm_off = 0;
-    w.bufa_off = align_up((size_t)B * w.P0 * sizeof(float));
+    w.xnorm_off = kAlign;                                   // the last 16 bytes before the rows are a zero prefix
+    w.bufa_off = align_up(w.xnorm_off + (size_t)B * w.P0 * sizeof(float));
     w.bufb_off = w.bufa_off + buf;
     w.total = w.bufb_off + buf;
     return w;
@@ -346,8 +346,17 @@ int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
                             static_cast<hipStream_t>(stream));
 }
 
+static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmin, int Lmax,
+                        void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream, bool zero_prefix);
+
 int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmin, int Lmax,
                void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream) {
+    return forward_impl(m, d_x, ldx, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs, d_logits, stream, false);
+}
+
+// zero_prefix: d_x[-4 .. -1] are readable zeros and the rows sit at the padded pitch (rs_classify's layout)
+static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmin, int Lmax,
+                        void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream, bool zero_prefix) {
     if (!m || !d_x || !d_len || !d_ws || !d_probs || B < 1) {
         set_error("rs_forward: null argument or empty batch");
         return RS_ERR_ARG;
@@ -374,7 +383,11 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
     void* buf[2] = {ws + w.bufa_off, ws + w.bufb_off};
 
     if (!m->prof_on || m->ev_used == 0 || m->ev_stage[m->ev_used - 1] != 0) prof_mark(m, -1, st);
-    int rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
+    // Winograd fp32 path: ConvNet layer 0 (one input channel) is folded into the staging of layer 1
+    // when the signal rows are laid out at the padded pitch (always true via rs_classify)
+    const bool fuse0 = zero_prefix && m->dtype == RS_F32W && ldx == w.P0 && conv_wino_can_fuse0(m->layers[1], w.P0 >> 1);
+    int rc = RS_OK;
+    if (!fuse0) rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
     if (rc != RS_OK) return rc;
     prof_mark(m, 1, st);
     int cur = 0;
@@ -386,7 +399,8 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
         const int check_dead = (Lmin <= 0 || (w.P0 >> i) - (Lmin >> i) >= 64) ? 1 : 0;
         if (m->dtype == RS_F32W)
             rc = launch_conv_wino(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
-                                  B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
+                                  B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i],
+                                  (fuse0 && i == 1) ? d_x : nullptr, m->d_w0);
         else if (m->dtype == RS_F32)
             rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
                                  B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
@@ -421,10 +435,10 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
     float* xn = reinterpret_cast<float*>(static_cast<char*>(d_ws) + w.xnorm_off);
     prof_mark(m, -1, static_cast<hipStream_t>(stream));
     int rc = launch_normalise(d_sig, d_off, d_len, B, Lmax, xn, w.P0, w.P0, nullptr, 0, nullptr,
-                              static_cast<hipStream_t>(stream));
+                              static_cast<hipStream_t>(stream), /*zero_prefix=*/1);
     if (rc != RS_OK) return rc;
     prof_mark(m, 0, static_cast<hipStream_t>(stream));
-    return rs_forward(m, xn, w.P0, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs, d_logits, stream);
+    return forward_impl(m, xn, w.P0, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs, d_logits, stream, true);
 }
 
 int rs_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len, float threshold,

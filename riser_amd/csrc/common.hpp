@@ -26,7 +26,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // ---- kernel launchers (each returns RS_OK or records an error) -------------------------
 int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
                      float* d_out32, int64_t ld32, int32_t pad_to, double* d_out64, int64_t ld64,
-                     double* d_stats, hipStream_t st);
+                     double* d_stats, hipStream_t st, int zero_prefix = 0);
 
 // layer 0: x fp32 [B, ldx] -> y [B*P1, cp_out] (fp32 or bf16 rows), fused bias+ReLU+maxpool
 int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int P0,
@@ -54,7 +54,9 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
                     int* bm_out, int* bn_out);
 int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len,
                      int B, int P_in, int layer_index, int num_cu, const float* d_zero, int check_dead,
-                     hipStream_t st, int* bm_out, int* bn_out);
+                     hipStream_t st, int* bm_out, int* bn_out, const float* fuse_xs = nullptr,
+                     const float* fuse_w0 = nullptr);
+bool conv_wino_can_fuse0(const ConvLayerDev& L, int P_in);
 int conv_wino_max_bn();
 int conv_h16_max_bn();
 int conv_f32_max_bn();

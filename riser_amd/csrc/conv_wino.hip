@@ -79,9 +79,16 @@ struct WinoArgs {
     int shift_out;         // valid output rows of read b: len[b] >> shift_out
     int n_mtiles, n_ntiles;
     int check_dead;
+    // FUSE0 (layer 1 only): the input rows are not read from x but computed on the fly from the
+    // normalised signal - ConvNet layer 0 (C_in = 1: 3 FMAs per output) folded into the staging
+    const float* xs;       // normalised signals, flat [B * P0] (row pitch == P0, zero beyond each read's length),
+                           // preceded by >= 16 readable bytes of zeros
+    unsigned xs_bytes;
+    const float* w0;       // layer 0: [cp_in][4] = (w0, w1, w2, bias)
+    int n_reads;
 };
 
-template <int WM, int WN, int MT, int NT, int KCT>
+template <int WM, int WN, int MT, int NT, int KCT, bool FUSE0 = false>
 __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     static_assert(WM * WN == 8, "8 waves per workgroup (2 per SIMD)");
     static_assert(KCT % 4 == 0 && KCT >= 8, "channel chunk");
@@ -140,11 +147,42 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     const __amdgpu_buffer_rsrc_t rs_bias =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias_bytes, 0x00020000);
 
+    // FUSE0: input row g of this layer = output row g of layer 0 = relu(max(conv(x)[2t], conv(x)[2t+1]) + b)
+    // of read b = g / P_in at t = g % P_in, computed from the four samples x[2g-1 .. 2g+2] of the FLAT
+    // signal buffer (pitch P0 = 2 * P_in, so sample 2t of read b is element 2g; the zero fill beyond
+    // each read's length supplies both 'same' pads).  A thread's four channels are fixed (4 * a_c4 ..),
+    // so their (w0, w1, w2, bias) live in registers.  A tile spans at most two reads (host-checked).
+    // (the descriptor starts 16 bytes before the first sample - the caller guarantees four zero floats
+    // there - so the offset of x[2g-1] is never negative: a load that STARTS out of range returns zeros
+    // for all four dwords, including the three in-range ones)
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(FUSE0 ? a.xs - 4 : a.x), 0, FUSE0 ? a.xs_bytes + 16u : 0u, 0x00020000);
+    const int P_in = 2 * a.P_out;
+    f32x4 w0r[4];
+    if constexpr (FUSE0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            w0r[q] = *reinterpret_cast<const f32x4*>(a.w0 + (size_t)(4 * (a_act ? a_c4 : 0) + q) * 4);
+    }
+    int f_g0 = 0, f_base = 0, f_gb = 0, f_lim_lo = 0, f_lim_hi = 0;
+
     u32x4 ra[A_PER], rb[B_PER];
     unsigned a_ib = kOob, b_ib = kOob;                  // per-item byte offsets of this thread's first units
     auto item_offsets = [&](int m0p, int n0, int c, bool live) {
-        const bool a_ok = live && a_act && c * KCT + 4 * a_c4 < a.cp_in;
-        a_ib = a_ok ? a_tb + (unsigned)((2 * m0p - 1) * a.cp_in + c * KCT) * 4u : kOob;
+        if constexpr (FUSE0) {
+            const int g0 = 2 * m0p - 1;                 // first slab row (global input row)
+            const int b_lo = (g0 < 0 ? 0 : g0) / P_in;
+            f_g0 = g0;
+            f_base = b_lo * P_in;
+            f_gb = f_base + P_in;
+            f_lim_lo = a.len[b_lo < a.n_reads ? b_lo : a.n_reads - 1] >> 1;
+            f_lim_hi = b_lo + 1 < a.n_reads ? a.len[b_lo + 1] >> 1 : 0;
+            if (b_lo >= a.n_reads) f_lim_lo = 0;
+            a_ib = (live && a_act) ? (unsigned)(2 * (g0 + a_row) - 1 + 4) * 4u : kOob;     // g0 + a_row >= -1: offset >= 4
+        } else {
+            const bool a_ok = live && a_act && c * KCT + 4 * a_c4 < a.cp_in;
+            a_ib = a_ok ? a_tb + (unsigned)((2 * m0p - 1) * a.cp_in + c * KCT) * 4u : kOob;
+        }
         b_ib = (live && b_act) ? b_tb + (unsigned)((n0 * a.nch + c) * 4 * KCT) * 4u : kOob;
 #ifdef RS_ABL_NOLOAD                                    // timing experiment only: every staging load out of range
         a_ib = kOob;
@@ -154,9 +192,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     auto load_unit = [&](auto U) {
         constexpr int u = decltype(U)::value;
         if constexpr (u < A_PER) {
-            unsigned off = a_ib + (unsigned)u * a_step;
+            unsigned off = a_ib + (unsigned)u * (FUSE0 ? (unsigned)(2 * RPT * 4) : a_step);
             if constexpr ((u + 1) * RPT > A_ROWS) off = (a_row + u * RPT < A_ROWS) ? off : kOob;
-            ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+            ra[u] = __builtin_amdgcn_raw_buffer_load_b128(FUSE0 ? rs_s : rs_x, off, 0, 0);
         } else {
             constexpr int v = u - A_PER;
             unsigned off = b_ib + (unsigned)v * b_step;
@@ -173,6 +211,20 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
             asm volatile("" ::"v"(ra[u].x), "v"(ra[u].y), "v"(ra[u].z), "v"(ra[u].w));
             act = false;
 #endif
+            if constexpr (FUSE0) {
+                const int g = f_g0 + a_row + u * RPT;
+                const bool hi = g >= f_gb;
+                const bool valid = g >= 0 && (g - (hi ? f_gb : f_base)) < (hi ? f_lim_hi : f_lim_lo);
+                const f32x4 xv = __builtin_bit_cast(f32x4, ra[u]);             // x[2g-1], x[2g], x[2g+1], x[2g+2]
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                                  // same fmaf chains as conv0_kernel
+                    const float e = fmaf(w0r[q][2], xv[2], fmaf(w0r[q][1], xv[1], fmaf(w0r[q][0], xv[0], w0r[q][3])));
+                    const float f = fmaf(w0r[q][2], xv[3], fmaf(w0r[q][1], xv[2], fmaf(w0r[q][0], xv[1], w0r[q][3])));
+                    o[q] = valid ? fmaxf(fmaxf(e, f), 0.0f) : 0.0f;
+                }
+                ra[u] = __builtin_bit_cast(u32x4, o);
+            }
             if (act) {
                 uint2* d = reinterpret_cast<uint2*>(buf + a_st + u * (RPT / 2) * S);
                 d[0] = make_uint2(ra[u].x, ra[u].y);
@@ -319,10 +371,17 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
                         const float d0 = dr[i][0], d1 = dr[i][1], d2 = dr[i][2], d3 = dr[i][3];
+#ifdef RS_ABL_NOXFORM                                      // timing experiment only
+                        v[i][0] = d0;
+                        v[i][1] = d1;
+                        v[i][2] = d2;
+                        v[i][3] = d3;
+#else
                         v[i][0] = d0 - d2;
                         v[i][1] = d1 + d2;
                         v[i][2] = d2 - d1;
                         v[i][3] = d1 - d3;
+#endif
                     }
                 }
                 if constexpr (comp == 1 && st + 1 < KQ) {
@@ -351,6 +410,18 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
                             acc[i][j][comp] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl & 1][j], v[i][comp],
                                                                                    acc[i][j][comp], 0, 0, 0);
                     }
+#ifndef RS_WINO_NO_SGB2
+                {   // one LDS read in the shadow of each of the first MFMAs, so the next slot's fragments are
+                    // in flight early without a read burst ahead of the MFMAs
+                    constexpr int n_rd = (sl + 1 < NSLOTS ? NT : 0) + ((comp == 1 && st + 1 < KQ) ? 2 * MT : 0);
+                    constexpr int n_pair = n_rd < MT * NT ? n_rd : MT * NT;
+                    static_for<n_pair>([&](auto) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    });
+                    if constexpr (MT * NT - n_pair > 0) __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - n_pair, 0);
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<UNITS>([&](auto U) {
                     constexpr int u = decltype(U)::value;
@@ -440,7 +511,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
             }
         }
         if (!has_next) break;
+#ifndef RS_ABL_NOBARRIER                                // timing experiment only
         __syncthreads();
+#endif
         buf ^= 1;
         o = no;
         c = nc;
@@ -455,6 +528,9 @@ struct Shape {
     int wm, wn, mt, nt;
     KernelFn fn[3];        // chunk = 16, 20, 24
 };
+// layer 1 of the shipped net (20 -> 30 channels) with layer 0 folded into its staging
+const KernelFn kFusedL1 = conv_wino_kernel<8, 1, 2, 2, 20, true>;
+constexpr int kFusedBMP = 8 * 16 * 2, kFusedBN = 32;
 
 #define RS_SHAPE(WM, WN, MT, NT)                                                                       \
     {WM, WN, MT, NT, {conv_wino_kernel<WM, WN, MT, NT, 16>, conv_wino_kernel<WM, WN, MT, NT, 20>,     \
@@ -507,9 +583,16 @@ const Shape* choose_shape(int64_t rows_out, int n16, int kc, int nch, int num_cu
 
 int conv_wino_max_bn() { return 256; }
 
+// layer 0 can be folded into this layer's staging when the layer is the shipped net's layer 1
+// (20 input channels = one 20-channel chunk, <= 32 outputs) and a tile spans at most two reads
+bool conv_wino_can_fuse0(const ConvLayerDev& L, int P_in) {
+    return L.cp_in == 20 && L.plan.kc == 20 && L.plan.nch == 1 && L.c_out <= kFusedBN && P_in >= 2 * kFusedBMP + 2 &&
+           getenv("RS_NO_FUSE0") == nullptr;
+}
+
 int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
                      int layer_index, int num_cu, const float* d_zero, int check_dead, hipStream_t st, int* bm_out,
-                     int* bn_out) {
+                     int* bn_out, const float* fuse_xs, const float* fuse_w0) {
     const ConvPlan& p = L.plan;
     if (p.kc != 16 && p.kc != 20 && p.kc != 24) {
         set_error("conv_wino: unsupported channel chunk %d", p.kc);
@@ -531,24 +614,41 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
                         lds_bytes(kShapes[k], p.kc) <= 160 * 1024)
                         s = &kShapes[k];
     }
+    const bool fused = fuse_xs != nullptr;
+    if (fused) {
+        if (!conv_wino_can_fuse0(L, P_in) || !fuse_w0) {
+            set_error("conv_wino: layer cannot take the fused layer-0 path");
+            return RS_ERR_ARG;
+        }
+        for (int k = 0; k < kNumShapes; ++k)
+            if (kShapes[k].wm == 8 && kShapes[k].wn == 1 && kShapes[k].mt == 2 && kShapes[k].nt == 2) s = &kShapes[k];
+    }
     if (!s) {
         set_error("conv_wino: no tile shape fits (kc=%d)", p.kc);
         return RS_ERR_ARG;
     }
     const int BMP = s->wm * 16 * s->mt, BN = s->wn * 16 * s->nt;
     WinoArgs a;
+    a.xs = fuse_xs;
+    a.xs_bytes = (unsigned)std::min<int64_t>(rows64 * 2 * 4, 0x7fffffffLL);      // B * P0 floats (P0 = 2 * P_in)
+    a.w0 = fuse_w0;
+    a.n_reads = B;
+    if (fused && rows64 * 2 * 4 >= 0x80000000LL) {
+        set_error("conv_wino: signal buffer exceeds the 2 GiB buffer-load window, split the batch");
+        return RS_ERR_ARG;
+    }
     a.x = d_x;
     a.w = static_cast<const float*>(L.d_w);
     a.bias = L.d_bias;
     a.y = d_y;
     a.len = d_len;
     const int64_t xb = rows64 * L.cp_in * 4, wb = (int64_t)p.n_alloc * p.nch * 4 * p.kc * 4;
-    if (xb >= 0x80000000LL || wb >= 0x80000000LL) {
+    if ((!fused && xb >= 0x80000000LL) || wb >= 0x80000000LL) {
         set_error("conv_wino: activation buffer of %lld bytes exceeds the 2 GiB buffer-load window, split the batch",
                   (long long)xb);
         return RS_ERR_ARG;
     }
-    a.x_bytes = (unsigned)xb;
+    a.x_bytes = fused ? 0u : (unsigned)xb;
     a.w_bytes = (unsigned)wb;
     a.y_bytes = (unsigned)(rows64 / 2 * L.cp_out * 4);          // < x_bytes * 2 ... checked below
     a.y_row_bytes = (unsigned)L.cp_out * 4u;
@@ -570,7 +670,7 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
     a.n_ntiles = (n16 * 16 + BN - 1) / BN;
     a.check_dead = check_dead;
     const size_t lds = lds_bytes(*s, p.kc);
-    KernelFn fn = s->fn[p.kc == 16 ? 0 : p.kc == 20 ? 1 : 2];
+    KernelFn fn = fused ? kFusedL1 : s->fn[p.kc == 16 ? 0 : p.kc == 20 ? 1 : 2];
     RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
     const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;

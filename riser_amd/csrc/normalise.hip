@@ -127,8 +127,11 @@ __device__ void block_select2(KeyFn key, int n, int R, int k_lo, int k_hi, unsig
 __global__ __launch_bounds__(kThreads) void normalise_kernel(
     const int16_t* __restrict__ sig, const int64_t* __restrict__ off, const int32_t* __restrict__ len,
     float* __restrict__ out32, int64_t ld32, int32_t pad_to, double* __restrict__ out64, int64_t ld64,
-    double* __restrict__ stats, int lmax) {
+    double* __restrict__ stats, int lmax, int zero_prefix) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // rs_classify lays the fp32 rows out behind 16 zero bytes: the conv kernel that folds layer 0
+    // into its staging reads x[-1] of the first read from there
+    if (zero_prefix && out32 && blockIdx.x == 0 && threadIdx.x < 4) out32[(int)threadIdx.x - 4] = 0.0f;
     unsigned* hist = reinterpret_cast<unsigned*>(smem);
     Scratch* sc = reinterpret_cast<Scratch*>(smem + kBins * 4);
     int16_t* sx = reinterpret_cast<int16_t*>(smem + kBins * 4 + 512);
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
 
 int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
                      float* d_out32, int64_t ld32, int32_t pad_to, double* d_out64, int64_t ld64,
-                     double* d_stats, hipStream_t st) {
+                     double* d_stats, hipStream_t st, int zero_prefix) {
     if (B <= 0) return RS_OK;
     if (Lmax < 1 || Lmax > kMaxNormLen) {
         set_error("rs_normalise: read length %d outside [1, %d]", Lmax, kMaxNormLen);
@@ -259,7 +262,7 @@ int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* 
         attr_set = true;
     }
     hipLaunchKernelGGL(normalise_kernel, dim3(B), dim3(kThreads), lds, st, d_sig, d_off, d_len, d_out32, ld32,
-                       pad_to, d_out64, ld64, d_stats, Lmax);
+                       pad_to, d_out64, ld64, d_stats, Lmax, zero_prefix);
     RS_HIP(hipGetLastError());
     return RS_OK;
 }
