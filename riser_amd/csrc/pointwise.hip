@@ -84,37 +84,64 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
 
 // ---- head ---------------------------------------------------------------------------------
 // AdaptiveAvgPool1d(1) -> Flatten -> Linear(C, 2) (riser/nets/cnn.py:28-33) -> softmax
-// (riser/model.py:27).  One wave per read: lanes stride over channels, the mean is over the
-// len >> n_layers valid rows of the read's slot in the last activation buffer.
+// (riser/model.py:27).  One 256-thread workgroup per read: threads stride over channels (coalesced
+// 4-byte loads, all rows of a channel in flight together), the mean is over the len >> n_layers
+// valid rows of the read's slot in the last activation buffer; wave shuffles + one LDS hop reduce
+// the two dot products.  The summation order depends only on the channel count, never on the batch.
+constexpr int kHeadThreads = 256;
+constexpr int kHeadRowsUnroll = 4;
+
 template <int DT>
-__global__ __launch_bounds__(64) void head_kernel(const void* __restrict__ yv, int cp, int c, int P_last,
-                                                  int n_layers, const int32_t* __restrict__ len,
-                                                  const float* __restrict__ fcw, const float* __restrict__ fcb,
-                                                  float* __restrict__ probs, float* __restrict__ logits) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(kHeadThreads) void head_kernel(const void* __restrict__ yv, int cp, int c, int P_last,
+                                                           int n_layers, const int32_t* __restrict__ len,
+                                                           const float* __restrict__ fcw, const float* __restrict__ fcb,
+                                                           float* __restrict__ probs, float* __restrict__ logits) {
+    __shared__ float red[kHeadThreads / 64][2];
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int rows = len[b] >> n_layers;
     const float inv = 1.0f / (float)rows;
+    auto ld = [&](int t, int ch) -> float {
+        const int64_t idx = ((int64_t)b * P_last + t) * cp + ch;
+        if constexpr (DT != 0)
+            return from16<DT>(reinterpret_cast<const unsigned short*>(yv)[idx]);
+        else
+            return reinterpret_cast<const float*>(yv)[idx];
+    };
     float a0 = 0.f, a1 = 0.f;
-    for (int ch = lane; ch < c; ch += 64) {
+    for (int ch = tid; ch < c; ch += kHeadThreads) {
+        const float w0 = fcw[ch], w1 = fcw[c + ch];
         float s = 0.f;
-        for (int t = 0; t < rows; ++t) {
-            const int64_t idx = ((int64_t)b * P_last + t) * cp + ch;
-            if constexpr (DT != 0)
-                s += from16<DT>(reinterpret_cast<const unsigned short*>(yv)[idx]);
-            else
-                s += reinterpret_cast<const float*>(yv)[idx];
+        int t = 0;
+        for (; t + kHeadRowsUnroll <= rows; t += kHeadRowsUnroll) {
+            float v[kHeadRowsUnroll];
+#pragma unroll
+            for (int k = 0; k < kHeadRowsUnroll; ++k) v[k] = ld(t + k, ch);
+#pragma unroll
+            for (int k = 0; k < kHeadRowsUnroll; ++k) s += v[k];
         }
+        for (; t < rows; ++t) s += ld(t, ch);
         const float m = s * inv;
-        a0 = fmaf(m, fcw[ch], a0);
-        a1 = fmaf(m, fcw[c + ch], a1);
+        a0 = fmaf(m, w0, a0);
+        a1 = fmaf(m, w1, a1);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         a0 += __shfl_xor(a0, d, 64);
         a1 += __shfl_xor(a1, d, 64);
     }
-    if (lane == 0) {
-        const float l0 = a0 + fcb[0], l1 = a1 + fcb[1];
+    if ((tid & 63) == 0) {
+        red[tid >> 6][0] = a0;
+        red[tid >> 6][1] = a1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < kHeadThreads / 64; ++w) {
+            s0 += red[w][0];
+            s1 += red[w][1];
+        }
+        const float l0 = s0 + fcb[0], l1 = s1 + fcb[1];
         const float mx = fmaxf(l0, l1);
         const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
         const float s = e0 + e1;
@@ -174,7 +201,7 @@ int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int
 int launch_head(const void* d_y, int dtype, int cp, int c, int P_last, int n_layers, const int32_t* d_len,
                 int B, const float* d_fcw, const float* d_fcb, float* d_probs, float* d_logits, hipStream_t st) {
     auto fn = dtype == RS_F16 ? head_kernel<2> : dtype == RS_BF16 ? head_kernel<1> : head_kernel<0>;
-    hipLaunchKernelGGL(fn, dim3(B), dim3(64), 0, st, d_y, cp, c, P_last, n_layers, d_len, d_fcw, d_fcb, d_probs,
+    hipLaunchKernelGGL(fn, dim3(B), dim3(kHeadThreads), 0, st, d_y, cp, c, P_last, n_layers, d_len, d_fcw, d_fcb, d_probs,
                        d_logits);
     RS_HIP(hipGetLastError());
     return RS_OK;
