@@ -386,8 +386,13 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
     // Winograd fp32 path: ConvNet layer 0 (one input channel) is folded into the staging of layer 1
     // when the signal rows are laid out at the padded pitch (always true via rs_classify)
     const bool fuse0 = zero_prefix && m->dtype == RS_F32W && ldx == w.P0 && conv_wino_can_fuse0(m->layers[1], w.P0 >> 1);
+    // 16-bit paths: the narrow layers 1 and 2 run the per-wave streaming kernel; on the rs_classify path
+    // layer 0 is folded into layer 1 there as well ("fused preprocess + conv")
+    const bool is16 = m->dtype == RS_BF16 || m->dtype == RS_F16;
+    const bool fuse0h = is16 && zero_prefix && ldx == w.P0 && m->channels[0] <= 32 &&
+                        conv_stream_h16_ok(m->layers[1], w.P0 >> 1);
     int rc = RS_OK;
-    if (!fuse0) rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
+    if (!fuse0 && !fuse0h) rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
     if (rc != RS_OK) return rc;
     prof_mark(m, 1, st);
     int cur = 0;
@@ -404,7 +409,13 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         else if (m->dtype == RS_F32)
             rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
                                  B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
-        else
+        else if (is16 && i <= 2 && conv_stream_h16_ok(L, P_in)) {
+            const bool f0 = fuse0h && i == 1;
+            rc = launch_conv_stream_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, m->dtype == RS_F16, st,
+                                        f0 ? d_x : nullptr, m->d_w0, m->channels[0]);
+            m->last_bm[i] = 16;
+            m->last_bn[i] = round_up(L.c_out, 16);
+        } else
             rc = launch_conv_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, m->d_zero,
                                  m->dtype == RS_F16, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
         if (rc != RS_OK) return rc;

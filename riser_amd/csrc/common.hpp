@@ -18,6 +18,15 @@ int hip_fail(hipError_t e, const char* what);
         if (e__ != hipSuccess) return rs::hip_fail(e__, #call);        \
     } while (0)
 
+// Per-read lengths are read-only for every kernel: loads through the CONSTANT address space compile to
+// scalar loads (s_load, tracked by lgkmcnt) when the index is wave-uniform.  A plain global load of a
+// struct-member pointer becomes a VECTOR load, and its s_waitcnt vmcnt(0) drains every prefetch the
+// wave has in flight.
+typedef const int32_t __attribute__((address_space(4))) * const_len_ptr;
+__device__ __forceinline__ const_len_ptr as_const_len(const int32_t* p) {
+    return (const_len_ptr)(uintptr_t)p;
+}
+
 constexpr int kMaxLayers = 16;
 constexpr int kMaxNormLen = 65536;
 
@@ -58,6 +67,12 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
                      const float* fuse_w0 = nullptr);
 bool conv_wino_can_fuse0(const ConvLayerDev& L, int P_in);
 int conv_wino_max_bn();
+// narrow 16-bit layers (C_in <= 32, C_out <= 48): per-wave streaming kernel, optionally with ConvNet
+// layer 0 folded in (fuse_xs = normalised signals at the padded pitch behind 16 zero bytes)
+bool conv_stream_h16_ok(const ConvLayerDev& L, int P_in);
+int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
+                           int layer_index, int num_cu, bool f16, hipStream_t st, const float* fuse_xs,
+                           const float* fuse_w0, int fuse_c0);
 int conv_h16_max_bn();
 int conv_f32_max_bn();
 int conv_f32_kc_max();

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f32_kernel(const ConvArgs a
             tile_origin(q, tm0, tn0);
             const int b = tm0 / P_in_;
             const int t0 = tm0 - b * P_in_;
-            if (!(t0 + BM <= P_in_ && t0 >= (a.len[b] >> (a.shift_out - 1)))) break;
+            if (!(t0 + BM <= P_in_ && t0 >= (as_const_len(a.len)[b] >> (a.shift_out - 1)))) break;
             // zero-fill the BM/2 x BN output tile (16-byte pieces; rows are cp_out wide)
             const int pieces_per_row = BN / 4;
             for (int f = threadIdx.x; f < (BM / 2) * pieces_per_row; f += blockDim.x) {

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(FUSE0 ? a.xs - 4 : a.x), 0, FUSE0 ? a.xs_bytes + 16u : 0u, 0x00020000);
     const int P_in = 2 * a.P_out;
+    const const_len_ptr clen = as_const_len(a.len);
     f32x4 w0r[4];
     if constexpr (FUSE0) {
 #pragma unroll
@@ -175,8 +176,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
             f_g0 = g0;
             f_base = b_lo * P_in;
             f_gb = f_base + P_in;
-            f_lim_lo = a.len[b_lo < a.n_reads ? b_lo : a.n_reads - 1] >> 1;
-            f_lim_hi = b_lo + 1 < a.n_reads ? a.len[b_lo + 1] >> 1 : 0;
+            f_lim_lo = clen[b_lo < a.n_reads ? b_lo : a.n_reads - 1] >> 1;
+            f_lim_hi = b_lo + 1 < a.n_reads ? clen[b_lo + 1] >> 1 : 0;
             if (b_lo >= a.n_reads) f_lim_lo = 0;
             a_ib = (live && a_act) ? (unsigned)(2 * (g0 + a_row) - 1 + 4) * 4u : kOob;     // g0 + a_row >= -1: offset >= 4
         } else {
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
             tile_origin(q, tm0, tn0);
             const int b = tm0 / a.P_out;
             const int t0 = tm0 - b * a.P_out;
-            if (!(t0 + BMP <= a.P_out && t0 >= (a.len[b] >> a.shift_out))) break;
+            if (!(t0 + BMP <= a.P_out && t0 >= (clen[b] >> a.shift_out))) break;
             const int pieces_per_row = BN / 4;
             for (int f = threadIdx.x; f < BMP * pieces_per_row; f += blockDim.x) {
                 const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 4;

@@ -184,3 +184,32 @@ def test_stream_classifier_matches_direct(dev):
     got2 = sc.classify(torch.from_numpy(sigs).pin_memory(), lens)          # pinned input path
     assert np.array_equal(got2[0], want)
     m.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_h16_streaming_layers_and_layer0_fold(dev, dtype):
+    """16-bit narrow layers: the per-wave streaming kernel (layers 1-2), with and without ConvNet layer 0
+    folded in, must reproduce the tiled 16-bit kernel bit for bit (same MFMA sequence, same roundings),
+    on full-length and mixed-length batches, and stay within the 16-bit tolerance of the oracle."""
+    import os
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    sd = synth.make_state_dict(2)
+    m = Model(sd, synth.Config(), None, "m", dtype=dtype, device=dev)
+    tol = {"f16": 2e-2, "bf16": 1.5e-1}[dtype]
+    for lens in ([16000] * 6, [4096, 16000, 8615, 5000, 12001, 4097, 16383, 9999]):
+        sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=300 + i)[0] for i, n in enumerate(lens)]
+        sig, off, ln, lh = pack_reads(sigs, dev)
+        xs = [ro.mad_normalise(s) for s in sigs]
+        fused = m.classify_raw(sig, off, ln, lh).cpu().numpy()               # layer 0 folded into layer 1
+        stream = m.classify_batch(xs).cpu().numpy()                          # conv0 kernel + streaming layers 1-2
+        os.environ["RS_NO_STREAM_H16"] = "1"
+        try:
+            tiled = m.classify_raw(sig, off, ln, lh).cpu().numpy()           # conv0 kernel + tiled kernel everywhere
+        finally:
+            del os.environ["RS_NO_STREAM_H16"]
+        assert np.array_equal(fused, stream), np.abs(fused - stream).max()
+        assert np.array_equal(fused, tiled), np.abs(fused - tiled).max()
+        want = np.stack([ro.classify(sd, x) for x in xs])
+        assert np.abs(fused - want).max() < tol
+    m.close()
