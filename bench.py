@@ -218,14 +218,11 @@ def main():
                for sd_, t_ in ((1, "mRNA"), (2, "mtRNA"), (3, "globin"))]
         pe = torch.empty((3, B, 2), dtype=torch.float32, device=device)
         dec = torch.empty(B, dtype=torch.uint8, device=device)
-        P0 = ens[0].padded_length(L)
+        from riser_amd.model import classify_raw_ensemble
 
         def ens_step():
-            x = proc.normalise_device(sig, off, ln, B, L, pad_to=P0)
-            for k, mk in enumerate(ens):
-                mk.forward_batch(x, lens, lens_dev=ln, out=pe[k])
-            nv.check(nv.lib().rs_decide(pe.data_ptr(), 3, B, ln.data_ptr(), L, 0.9, nv.RS_ENRICH, dec.data_ptr(),
-                                        torch.cuda.current_stream(device).cuda_stream), "rs_decide")
+            classify_raw_ensemble(ens, sig, off, ln, lens, out=pe, decision=dec, max_len=L, threshold=0.9,
+                                  mode=nv.RS_ENRICH)
         for _ in range(3):
             ens_step()
         torch.cuda.synchronize(device)

@@ -145,6 +145,21 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
                 float* d_probs, float* d_logits, void* stream);
 
 /*
+ * Ensemble form of rs_classify: the model loop of riser/control.py:68-71 for a whole batch.
+ * The reads are normalised ONCE (riser/control.py:63), every model of `models` (same architecture,
+ * e.g. the mRNA / mtRNA / globin stand-ins of one kit) runs its forward pass on the same normalised
+ * signals, and - if d_decision is not NULL - the decision of riser/control.py:75-82 is taken on the
+ * device (see rs_decide for `max_len`, `threshold`, `mode`).
+ *   d_probs     fp32 [n_models, B, 2]
+ *   d_decision  uint8 [B] or NULL
+ * The workspace is shared by the models: rs_workspace_bytes(models[0], B, Lmax).
+ */
+int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d_sig, const int64_t* d_off,
+                         const int32_t* d_len, int B, int Lmin, int Lmax, void* d_ws, size_t ws_bytes,
+                         float* d_probs, uint8_t* d_decision, int max_len, float threshold, int mode,
+                         void* stream);
+
+/*
  * Ensemble decision of riser/control.py:75-82 for B reads and n_models models.
  *   d_probs   fp32 [n_models, B, 2]
  *   max_len   SignalProcessor.get_max_length() (riser/preprocess.py:36-40)

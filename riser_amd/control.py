@@ -26,6 +26,7 @@ import numpy as np
 import torch
 
 from . import _native as nv
+from .model import classify_raw_ensemble
 from .preprocess import pack_reads
 
 _MODE = {"enrich": nv.RS_ENRICH, "deplete": nv.RS_DEPLETE}
@@ -96,15 +97,10 @@ class SequencerControl():
         lens_a = np.asarray(a_len, dtype=np.int32)
         off_d = torch.from_numpy(np.asarray(a_off, dtype=np.int64)).to(dev)
         len_d = torch.from_numpy(lens_a).to(dev)
-        lmax = int(lens_a.max())
-        x = proc.normalise_device(sig, off_d, len_d, B, lmax)
-        probs = torch.empty((len(self.models), B, 2), dtype=torch.float32, device=dev)
-        for m, model in enumerate(self.models):
-            model.forward_batch(x, lens_a, lens_dev=len_d, out=probs[m])
+        # one library call: normalise once, one forward per model, decision on the device
         dec = torch.empty(B, dtype=torch.uint8, device=dev)
-        nv.check(nv.lib().rs_decide(probs.data_ptr(), len(self.models), B, len_d.data_ptr(), max_len,
-                                    float(threshold), _MODE[mode], dec.data_ptr(),
-                                    torch.cuda.current_stream(dev).cuda_stream), "rs_decide")
+        probs = classify_raw_ensemble(self.models, sig, off_d, len_d, lens_a, decision=dec, max_len=max_len,
+                                      threshold=threshold, mode=_MODE[mode])
         probs_h = probs.cpu().numpy()
         dec_h = dec.cpu().numpy()
         out = []

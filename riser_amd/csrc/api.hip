@@ -452,6 +452,51 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
     return forward_impl(m, xn, w.P0, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs, d_logits, stream, true);
 }
 
+int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d_sig, const int64_t* d_off,
+                         const int32_t* d_len, int B, int Lmin, int Lmax, void* d_ws, size_t ws_bytes, float* d_probs,
+                         uint8_t* d_decision, int max_len, float threshold, int mode, void* stream) {
+    if (!models || n_models < 1 || !d_sig || !d_off || !d_len || !d_ws || !d_probs || B < 1) {
+        set_error("rs_classify_ensemble: null argument or empty batch");
+        return RS_ERR_ARG;
+    }
+    rs_model* m0 = models[0];
+    for (int k = 0; k < n_models; ++k)
+        if (!models[k] || models[k]->n_layers != m0->n_layers || models[k]->device != m0->device ||
+            esize(models[k]) != esize(m0)) {
+            set_error("rs_classify_ensemble: model %d is null or differs in depth / device / element size", k);
+            return RS_ERR_ARG;
+        }
+    if (d_decision && mode != RS_ENRICH && mode != RS_DEPLETE) {
+        set_error("rs_classify_ensemble: bad mode");
+        return RS_ERR_ARG;
+    }
+    if (Lmax < (1 << m0->n_layers) || Lmax > kMaxNormLen) {
+        set_error("rs_classify_ensemble: Lmax %d outside [%d, %d]", Lmax, 1 << m0->n_layers, kMaxNormLen);
+        return RS_ERR_LENGTH;
+    }
+    size_t need = 0;
+    for (int k = 0; k < n_models; ++k) need = std::max(need, ws_layout(models[k], B, Lmax).total);
+    if (ws_bytes < need) {
+        set_error("rs_classify_ensemble: workspace %zu < required %zu", ws_bytes, need);
+        return RS_ERR_WORKSPACE;
+    }
+    const WsLayout w = ws_layout(m0, B, Lmax);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* xn = reinterpret_cast<float*>(static_cast<char*>(d_ws) + w.xnorm_off);
+    prof_mark(m0, -1, st);
+    int rc = launch_normalise(d_sig, d_off, d_len, B, Lmax, xn, w.P0, w.P0, nullptr, 0, nullptr, st, /*zero_prefix=*/1);
+    if (rc != RS_OK) return rc;
+    prof_mark(m0, 0, st);
+    for (int k = 0; k < n_models; ++k) {
+        // every model keeps the normalised rows at the head of the workspace and ping-pongs behind them
+        rc = forward_impl(models[k], xn, w.P0, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs + (size_t)k * B * 2, nullptr,
+                          stream, true);
+        if (rc != RS_OK) return rc;
+    }
+    if (d_decision) rc = launch_decide(d_probs, n_models, B, d_len, max_len, threshold, mode, d_decision, st);
+    return rc;
+}
+
 int rs_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len, float threshold,
               int mode, uint8_t* d_out, void* stream) {
     if (B < 0 || n_models < 1 || (B > 0 && (!d_probs || !d_len || !d_out)) ||

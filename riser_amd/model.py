@@ -205,3 +205,25 @@ class Model:
                                logits.data_ptr() if return_logits else None, _stream_ptr(self.device)),
                  "rs_classify")
         return (probs, logits) if return_logits else probs
+
+
+def classify_raw_ensemble(models, sig_dev: torch.Tensor, off_dev: torch.Tensor, len_dev: torch.Tensor,
+                          lens_host: np.ndarray, out: torch.Tensor = None, decision: torch.Tensor = None,
+                          max_len: int = 0, threshold: float = 0.9, mode: int = nv.RS_ENRICH):
+    """The model loop of riser/control.py:63-82 for a whole batch in ONE library call: raw int16 reads on
+    the device are normalised once, every model (same architecture) classifies them, and - when a uint8
+    `decision` tensor [B] is given - the accept / reject / try-again decision is taken on the device.
+    Returns fp32 probabilities [n_models, B, 2] on the device."""
+    m0 = models[0]
+    m0._check_lengths(lens_host)
+    B, lmax = int(lens_host.shape[0]), int(lens_host.max())
+    L = nv.lib()
+    need = max(L.rs_workspace_bytes(m._h, B, lmax) for m in models)
+    ws = m0._ws.get(need)
+    probs = out if out is not None else torch.empty((len(models), B, 2), dtype=torch.float32, device=m0.device)
+    hs = (C.c_void_p * len(models))(*[m._h for m in models])
+    nv.check(L.rs_classify_ensemble(hs, len(models), sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), B,
+                                    int(lens_host.min()), lmax, ws.data_ptr(), ws.numel(), probs.data_ptr(),
+                                    decision.data_ptr() if decision is not None else None, int(max_len),
+                                    float(threshold), int(mode), _stream_ptr(m0.device)), "rs_classify_ensemble")
+    return probs

@@ -9,6 +9,7 @@ import torch
 
 from oracle import riser_oracle as ro
 from oracle import torch_path
+from riser_amd import _native as nv
 from riser_amd import synth
 from riser_amd.fake_client import FakeClient, FakeRead
 
@@ -213,3 +214,31 @@ def test_h16_streaming_layers_and_layer0_fold(dev, dtype):
         want = np.stack([ro.classify(sd, x) for x in xs])
         assert np.abs(fused - want).max() < tol
     m.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32w", "f16"])
+def test_classify_ensemble_entry(dev, dtype):
+    """rs_classify_ensemble (normalise once, N forwards, decision on the device) == N x rs_classify + rs_decide."""
+    from riser_amd.model import Model, classify_raw_ensemble
+    from riser_amd.preprocess import pack_reads
+    models = [Model(synth.make_state_dict(k), synth.Config(), None, t, dtype=dtype, device=dev)
+              for k, t in ((1, "mRNA"), (2, "mtRNA"), (3, "globin"))]
+    lens = [8615, 4096, 6000, 8615, 5123, 7777, 8000]
+    sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=700 + i)[0] for i, n in enumerate(lens)]
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    B = len(lens)
+    for mode in (nv.RS_ENRICH, nv.RS_DEPLETE):
+        dec = torch.empty(B, dtype=torch.uint8, device=dev)
+        probs = classify_raw_ensemble(models, sig, off, ln, lh, decision=dec, max_len=8615, threshold=0.9, mode=mode)
+        want = torch.stack([m.classify_raw(sig, off, ln, lh) for m in models])
+        assert torch.equal(probs, want)
+        dec2 = torch.empty(B, dtype=torch.uint8, device=dev)
+        nv.check(nv.lib().rs_decide(want.contiguous().data_ptr(), 3, B, ln.data_ptr(), 8615, 0.9, mode, dec2.data_ptr(),
+                                    torch.cuda.current_stream(dev).cuda_stream), "rs_decide")
+        assert torch.equal(dec, dec2)
+    # argument checks
+    with pytest.raises(nv.NativeError):
+        other = Model(synth.make_state_dict(1), synth.Config(), None, "x", dtype="f16" if dtype == "f32w" else "f32w", device=dev)
+        classify_raw_ensemble([models[0], other], sig, off, ln, lh)
+    for m in models:
+        m.close()
