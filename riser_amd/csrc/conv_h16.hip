@@ -36,6 +36,7 @@ struct ConvHArgs {
     unsigned short* y;
     const int32_t* len;
     const unsigned short* zero;
+    unsigned x_bytes, w_bytes;   // sizes of the activation buffer and of the packed weights (< 2^31)
     int rows_in;
     int P_out;
     float inv_P_out;
@@ -87,50 +88,65 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
     const int r = lane & 15, g = lane >> 4;
 
     // ---- per-thread staging map ------------------------------------------------------------------
-    int a_lds[A_PER], a_key[A_PER];            // key = row * 4 + slot, -1 if unused
-    int b_lds[B_PER], b_g[B_PER];              // b_g: element offset inside one panel's weights, -1 if unused
-#pragma unroll
-    for (int u = 0; u < A_PER; ++u) {
-        const int f = tid + u * kThreads;
-        const int row = f >> 2, c = f & 3;
-        a_lds[u] = row * 64 + ((c ^ swz(row)) << 4);
-        a_key[u] = f < A_UNITS ? f : -1;
-    }
+    // A unit f = tid + u * 512: slab row f >> 2 (= tid / 4 + 128 u), 16-byte slot f & 3.  The swizzle of a
+    // row depends on (row >> 2) & 1 only, which is the same for every pass u of a thread, so pass u is an
+    // immediate LDS offset.  Global loads are BUFFER loads with 32-bit byte offsets: rows outside the
+    // activation buffer, channel slots beyond cp_in, unused units and the prefetch after the last item
+    // resolve to an out-of-range offset (hardware returns zeros): one add per unit, no 64-bit address
+    // arithmetic, no predicates, no zero page.
+    constexpr unsigned kOob = 0x80000000u;
+    const int a_row0 = tid >> 2, a_c = tid & 3;
+    const int a_lds0 = a_row0 * 64 + ((a_c ^ swz(a_row0)) << 4);               // + u * 128 * 64
+    const unsigned a_tb = ((unsigned)a_row0 * a.cp_in + 8 * a_c) * 2u;         // + item base + u * a_step
+    const unsigned a_step = (unsigned)(128 * a.cp_in) * 2u;
+    int b_lds[B_PER];
+    unsigned b_g[B_PER];                                                        // byte offset inside one panel's weights
 #pragma unroll
     for (int u = 0; u < B_PER; ++u) {
         const int f = tid + u * kThreads;
         const int tap = f / (BN * 4), rem = f - tap * (BN * 4);
         const int n = rem >> 2, c = rem & 3;
         b_lds[u] = A_BYTES + (tap * BN + n) * 64 + ((c ^ swz(n)) << 4);
-        b_g[u] = f < B_UNITS ? (tap * a.n_alloc + n) * 32 + 8 * c : -1;
+        b_g[u] = f < B_UNITS ? (unsigned)((tap * a.n_alloc + n) * 32 + 8 * c) * 2u : kOob;
     }
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, a.w_bytes, 0x00020000);
 
     u32x4 ra[A_PER], rb[B_PER];
     auto load_item = [&](int m0, int n0, int p, bool live) {
-        const unsigned short* xb = a.x + (int64_t)(m0 - 1) * a.cp_in + p * 32;
+        bool a_ok = live && p * 32 + 8 * a_c < a.cp_in;
+#ifdef RS_ABL_NOLOAD
+        a_ok = false;
+        live = false;
+#endif
+        // row -1 (m0 == 0, slab row 0) wraps to an offset >= 2^31: out of range, zeros
+        const unsigned a_ib = a_ok ? a_tb + (unsigned)((m0 - 1) * a.cp_in + p * 32) * 2u : kOob;
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
-            const int key = a_key[u];
-            const int row = key >> 2, c = key & 3;
-            const int gr = m0 - 1 + row;
-            const bool ok = live && key >= 0 && gr >= 0 && gr < a.rows_in && p * 32 + 8 * c < a.cp_in;
-            const unsigned short* src = ok ? xb + (int64_t)row * a.cp_in + 8 * c : a.zero;
-            ra[u] = *reinterpret_cast<const u32x4*>(src);
+            unsigned off = a_ib + (unsigned)u * a_step;
+            if ((u + 1) * 128 > BM + 2) off = (a_row0 + u * 128 < BM + 2) ? off : kOob;
+            ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
         }
-        const unsigned short* wb = a.w + ((int64_t)p * 3 * a.n_alloc + n0) * 32;
+        const unsigned w_ib = live ? (unsigned)((p * 3 * a.n_alloc + n0) * 32) * 2u : kOob;
 #pragma unroll
-        for (int u = 0; u < B_PER; ++u) {
-            const unsigned short* src = (live && b_g[u] >= 0) ? wb + b_g[u] : a.zero;
-            rb[u] = *reinterpret_cast<const u32x4*>(src);
-        }
+        for (int u = 0; u < B_PER; ++u) rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_ib + b_g[u], 0, 0);
     };
     auto store_item = [&](unsigned char* buf) {
+#ifdef RS_ABL_NOLDSW
+#pragma unroll
+        for (int u = 0; u < A_PER; ++u) asm volatile("" ::"v"(ra[u]));
+#pragma unroll
+        for (int u = 0; u < B_PER; ++u) asm volatile("" ::"v"(rb[u]));
+#else
 #pragma unroll
         for (int u = 0; u < A_PER; ++u)
-            if (a_key[u] >= 0) *reinterpret_cast<u32x4*>(buf + a_lds[u]) = ra[u];
+            if (a_row0 + u * 128 < BM + 2) *reinterpret_cast<u32x4*>(buf + a_lds0 + u * 128 * 64) = ra[u];
 #pragma unroll
         for (int u = 0; u < B_PER; ++u)
-            if (b_g[u] >= 0) *reinterpret_cast<u32x4*>(buf + b_lds[u]) = rb[u];
+            if (b_g[u] != kOob) *reinterpret_cast<u32x4*>(buf + b_lds[u]) = rb[u];
+#endif
     };
 
     const int tiles = a.n_mtiles * a.n_ntiles;
@@ -185,7 +201,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
         }
         return q;
     };
-    const int nwg = gridDim.x;
     int o = next_live();
     if (o >= tiles) return;
 
@@ -276,7 +291,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
                             if (col < a.cp_out) {
                                 const float v =
                                     fmaxf(fmaxf(acc[i][j][2 * h], acc[i][j][2 * h + 1]) + bias[j], 0.0f);
+#ifdef RS_ABL_NOSTORE
+                                asm volatile("" ::"v"(v));
+#else
                                 a.y[(int64_t)prow * a.cp_out + col] = valid ? cvt16<F16>(v) : (unsigned short)0;
+#endif
                             }
                         }
                     }
@@ -287,7 +306,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
         }
         if (!has_next) break;
         store_item(lds + (buf ^ 1) * BUF_BYTES);
+#ifndef RS_ABL_NOBARRIER
         __syncthreads();
+#endif
         buf ^= 1;
         o = no;
         p = np;
@@ -373,6 +394,13 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
     a.y = static_cast<unsigned short*>(d_y);
     a.len = d_len;
     a.zero = static_cast<const unsigned short*>(d_zero);
+    const int64_t xb = rows64 * L.cp_in * 2, wb = (int64_t)L.plan.nch * 3 * L.plan.n_alloc * 32 * 2;
+    if (xb >= 0x80000000LL || wb >= 0x80000000LL) {
+        set_error("conv_h16: activation buffer exceeds the 2 GiB buffer-load window, split the batch");
+        return RS_ERR_ARG;
+    }
+    a.x_bytes = (unsigned)xb;
+    a.w_bytes = (unsigned)wb;
     a.rows_in = (int)rows64;
     a.P_out = P_in / 2;
     a.inv_P_out = 1.0f / (float)a.P_out;
