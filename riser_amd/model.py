@@ -130,6 +130,15 @@ class Model:
         nv.check(nv.lib().rs_profile_read(self._h, ms.ctypes.data, C.byref(calls)), "rs_profile_read")
         return ms, calls.value
 
+    def max_batch(self, lmax: int) -> int:
+        """Largest batch one library call accepts for reads of up to lmax samples: the conv kernels
+        address every activation buffer through a 2 GiB buffer-resource window (32-bit offsets with
+        hardware bounds checking).  Bigger batches are split transparently by the methods below."""
+        p0 = self.padded_length(lmax)
+        per_read = max((p0 >> (i + 1)) * (-(-c // 8) * 8) * 4 for i, c in enumerate(self.channels))
+        per_read = max(per_read, p0 * 4)
+        return max(1, (2 ** 31 - 2 ** 16) // per_read)
+
     def _check_lengths(self, lens_host: np.ndarray):
         if lens_host.size == 0:
             raise ValueError("empty batch")
@@ -175,6 +184,17 @@ class Model:
         lmax = int(lens_host.max())
         if lmax > ldx:
             raise ValueError("a length exceeds the row pitch")
+        mb = self.max_batch(lmax)
+        if B > mb:                                                     # split: reads are independent
+            probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
+            logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
+            for s0 in range(0, B, mb):
+                s1 = min(B, s0 + mb)
+                r = self.forward_batch(x[s0:s1], lens_host[s0:s1], None if lens_dev is None else lens_dev[s0:s1],
+                                       return_logits, out=probs[s0:s1])
+                if return_logits:
+                    logits[s0:s1] = r[1]
+            return (probs, logits) if return_logits else probs
         if lens_dev is None:
             lens_dev = torch.from_numpy(np.ascontiguousarray(lens_host, dtype=np.int32)).to(self.device)
         L = nv.lib()
@@ -194,6 +214,17 @@ class Model:
         self._check_lengths(lens_host)
         B = int(lens_host.shape[0])
         lmax = int(lens_host.max())
+        mb = self.max_batch(lmax)
+        if B > mb:                                                     # split: reads are independent
+            probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
+            logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
+            for s0 in range(0, B, mb):
+                s1 = min(B, s0 + mb)
+                r = self.classify_raw(sig_dev, off_dev[s0:s1], len_dev[s0:s1], lens_host[s0:s1], out=probs[s0:s1],
+                                      return_logits=return_logits)
+                if return_logits:
+                    logits[s0:s1] = r[1]
+            return (probs, logits) if return_logits else probs
         L = nv.lib()
         need = L.rs_workspace_bytes(self._h, B, lmax)
         ws = self._ws.get(need)
@@ -217,6 +248,16 @@ def classify_raw_ensemble(models, sig_dev: torch.Tensor, off_dev: torch.Tensor, 
     m0 = models[0]
     m0._check_lengths(lens_host)
     B, lmax = int(lens_host.shape[0]), int(lens_host.max())
+    mb = min(m.max_batch(lmax) for m in models)
+    if B > mb:                                                         # split: reads are independent
+        probs = out if out is not None else torch.empty((len(models), B, 2), dtype=torch.float32, device=m0.device)
+        for s0 in range(0, B, mb):
+            s1 = min(B, s0 + mb)
+            part = classify_raw_ensemble(models, sig_dev, off_dev[s0:s1].contiguous(), len_dev[s0:s1].contiguous(),
+                                         lens_host[s0:s1], decision=None if decision is None else decision[s0:s1],
+                                         max_len=max_len, threshold=threshold, mode=mode)
+            probs[:, s0:s1] = part
+        return probs
     L = nv.lib()
     need = max(L.rs_workspace_bytes(m._h, B, lmax) for m in models)
     ws = m0._ws.get(need)

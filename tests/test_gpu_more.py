@@ -242,3 +242,28 @@ def test_classify_ensemble_entry(dev, dtype):
         classify_raw_ensemble([models[0], other], sig, off, ln, lh)
     for m in models:
         m.close()
+
+
+def test_oversized_batches_are_split(dev, monkeypatch):
+    """batches beyond the 2 GiB buffer window of one library call are split by the host classes: force the
+    split with a tiny limit and compare with the unsplit call (reads are independent: bit-identical)."""
+    from riser_amd.model import Model, classify_raw_ensemble
+    from riser_amd.preprocess import pack_reads
+    m = Model(synth.make_state_dict(1), synth.Config(), None, "m", device=dev)
+    assert 2000 < m.max_batch(16000) < 4000
+    lens = [4096, 8615, 5000, 7000, 8000, 6024, 4100, 8192, 4500, 6666, 7777]
+    sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=900 + i)[0] for i, n in enumerate(lens)]
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    xs = [ro.mad_normalise(s) for s in sigs]
+    want_raw = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+    want_b, want_l = m.classify_batch(xs, return_logits=True)
+    want_e = classify_raw_ensemble([m, m], sig, off, ln, lh).cpu().numpy()
+    monkeypatch.setattr(Model, "max_batch", lambda self, lmax: 4)
+    got_raw, got_rl = m.classify_raw(sig, off, ln, lh, return_logits=True)
+    got_b, got_l = m.classify_batch(xs, return_logits=True)
+    dec = torch.empty(len(lens), dtype=torch.uint8, device=dev)
+    got_e = classify_raw_ensemble([m, m], sig, off, ln, lh, decision=dec, max_len=8615).cpu().numpy()
+    assert np.array_equal(got_raw.cpu().numpy(), want_raw)
+    assert torch.equal(got_b, want_b) and torch.equal(got_l, want_l) and torch.equal(got_rl, want_l)
+    assert np.array_equal(got_e, want_e)
+    m.close()
