@@ -134,23 +134,50 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
     if (zero_prefix && out32 && blockIdx.x == 0 && threadIdx.x < 4) out32[(int)threadIdx.x - 4] = 0.0f;
     unsigned* hist = reinterpret_cast<unsigned*>(smem);
     Scratch* sc = reinterpret_cast<Scratch*>(smem + kBins * 4);
-    int16_t* sx = reinterpret_cast<int16_t*>(smem + kBins * 4 + 512);
+    int16_t* sx0 = reinterpret_cast<int16_t*>(smem + kBins * 4 + 512);       // 16-byte aligned
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int n = min(len[b], lmax);                  // len > Lmax violates the contract; never overrun LDS
     const int16_t* src = sig + off[b];
+    // element i of the read lives at sx[i]; sx is offset so that it has the same 16-byte phase as src
+    int16_t* sx = sx0 + (int)((reinterpret_cast<uintptr_t>(src) >> 1) & 7);
     float* o32 = out32 ? out32 + (int64_t)b * ld32 : nullptr;
     double* o64 = out64 ? out64 + (int64_t)b * ld64 : nullptr;
 
     // ---- stage the read into LDS, min / max on the way ------------------------------------
+    // 16-byte loads over the 16-byte-aligned body of the read (the LDS copy is shifted by the same
+    // phase, so aligned global chunks are aligned LDS chunks), element loads for the ragged ends
     int mn = 32767, mx = -32768;
-    for (int i = tid; i < n; i += kThreads) {
-        const int v = src[i];
-        sx[i] = (int16_t)v;
-        mn = min(mn, v);
-        mx = max(mx, v);
+    {
+        const int phase = (int)((reinterpret_cast<uintptr_t>(src) >> 1) & 7);     // elements past a 16-byte boundary
+        const int head = min(n, (8 - phase) & 7);                                 // elements before the first aligned chunk
+        const int n_vec = (n - head) >> 3;
+        for (int i = tid; i < head; i += kThreads) {
+            const int v = src[i];
+            sx[i] = (int16_t)v;
+            mn = min(mn, v);
+            mx = max(mx, v);
+        }
+        const uint4* src4 = reinterpret_cast<const uint4*>(src + head);
+        for (int c = tid; c < n_vec; c += kThreads) {
+            const uint4 q = src4[c];
+            *reinterpret_cast<uint4*>(sx + head + 8 * c) = q;
+            const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int lo = (int)(int16_t)(w[k] & 0xffffu), hi = (int)(int16_t)(w[k] >> 16);
+                mn = min(mn, min(lo, hi));
+                mx = max(mx, max(lo, hi));
+            }
+        }
+        for (int i = head + 8 * n_vec + tid; i < n; i += kThreads) {
+            const int v = src[i];
+            sx[i] = (int16_t)v;
+            mn = min(mn, v);
+            mx = max(mx, v);
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -215,10 +242,23 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
             if (o32) o32[j] = (float)v;
             if (o64) o64[j] = v;
         };
+        // The non-outlier values are (t / 2) / denom for the integers |t| < dthr.  When only the fp32
+        // output is wanted and the threshold is small (it is ~7 * 1.4826 * MAD: a few hundred for
+        // nanopore signal), each distinct quotient is computed once - same fp64 division, same rounding
+        // to fp32 - into the histogram's LDS, and the per-sample work becomes a look-up.
+        float* lut = reinterpret_cast<float*>(hist);
+        const bool use_lut = o32 && !o64 && dthr <= kBins / 2;
+        if (use_lut) {
+            for (int k = tid; k < 2 * dthr; k += kThreads) lut[k] = (float)(((double)(k - dthr) * 0.5) / denom);
+            __syncthreads();
+        }
         for (int i = tid; i < n; i += kThreads) {
             const int t = dev2(i);
             if (abs(t) < dthr) {
-                put(i, ((double)t * 0.5) / denom);
+                if (use_lut)
+                    o32[i] = lut[t + dthr];
+                else
+                    put(i, ((double)t * 0.5) / denom);
                 continue;
             }
             if (i > 0 && abs(dev2(i - 1)) >= dthr) continue;     // inside a run: its head writes it
@@ -254,7 +294,7 @@ int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* 
         set_error("rs_normalise: read length %d outside [1, %d]", Lmax, kMaxNormLen);
         return RS_ERR_LENGTH;
     }
-    const size_t lds = (size_t)kBins * 4 + 512 + (size_t)round_up(Lmax, 8) * 2;
+    const size_t lds = (size_t)kBins * 4 + 512 + (size_t)round_up(Lmax + 8, 8) * 2;
     static bool attr_set = false;
     if (!attr_set) {
         RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(normalise_kernel),
