@@ -214,6 +214,13 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x /* fp32 [B, L] */, int B, i
                       float* d_probs, float* d_logits, void* stream);
 
 /*
+ * Test hook: every following forward pass of `m` also copies the output buffer of conv layer `layer`
+ * (1 <= layer < n_layers; position-major [B * (P0 >> (layer + 1)), cp_out], fp32 or 16-bit) into d_dst
+ * (at most `bytes`).  d_dst = NULL switches it off.  Used by the layer-wise parity tests.
+ */
+int rs_debug_capture_layer(rs_model* m, int layer, void* d_dst, size_t bytes);
+
+/*
  * Stage timing with HIP events on the launch stream (used by bench.py's roofline leg).
  * While enabled, rs_forward / rs_classify record one event before their first launch and
  * one after every kernel launch, on the caller's stream; no synchronisation is added.

@@ -89,6 +89,8 @@ def lib():
     L.rs_seqnet_workspace_bytes.argtypes = [vp, i32, i32]
     L.rs_seqnet_forward.restype = i32
     L.rs_seqnet_forward.argtypes = [vp, vp, i32, i32, vp, sz, vp, vp, vp]
+    L.rs_debug_capture_layer.restype = i32
+    L.rs_debug_capture_layer.argtypes = [vp, i32, vp, sz]
     L.rs_profile_enable.restype = i32
     L.rs_profile_enable.argtypes = [vp, i32]
     L.rs_profile_read.restype = i32

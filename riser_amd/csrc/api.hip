@@ -31,6 +31,10 @@ int hip_fail(hipError_t e, const char* what) {
 using namespace rs;
 
 struct rs_model {
+    // test hook (rs_debug_capture_layer): copy the output buffer of conv layer dbg_layer to dbg_dst
+    void* dbg_dst = nullptr;
+    size_t dbg_bytes = 0;
+    int dbg_layer = -1;
     int device = 0;
     int dtype = RS_F32;
     int n_layers = 0;
@@ -402,7 +406,12 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         // a tile of >= 64 rows can only be all padding if some read leaves >= 64 rows of its slot
         // unused at this layer; Lmin == 0 means "unknown": keep the test
         const int check_dead = (Lmin <= 0 || (w.P0 >> i) - (Lmin >> i) >= 64) ? 1 : 0;
-        if (m->dtype == RS_F32W)
+        if (m->dtype == RS_F32W && fuse0 && i == 1 && conv_stream_f32_ok(L, m->channels[0], P_in)) {
+            rc = launch_conv_stream_f32(L, d_x, m->d_w0, m->channels[0], static_cast<float*>(buf[cur ^ 1]), d_len, B, P_in,
+                                        m->num_cu, st);
+            m->last_bm[i] = 32;
+            m->last_bn[i] = round_up(L.c_out, 16);
+        } else if (m->dtype == RS_F32W)
             rc = launch_conv_wino(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
                                   B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i],
                                   (fuse0 && i == 1) ? d_x : nullptr, m->d_w0);
@@ -420,6 +429,10 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                                  m->dtype == RS_F16, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
         if (rc != RS_OK) return rc;
         prof_mark(m, 1 + i, st);
+        if (m->dbg_dst && m->dbg_layer == i) {
+            const size_t nb = std::min(m->dbg_bytes, (size_t)B * (P_in / 2) * L.cp_out * esize(m));
+            RS_HIP(hipMemcpyAsync(m->dbg_dst, buf[cur ^ 1], nb, hipMemcpyDeviceToDevice, st));
+        }
         cur ^= 1;
     }
     rc = launch_head(buf[cur], act_dtype(m), m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
@@ -515,6 +528,17 @@ int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
         return RS_ERR_ARG;
     }
     return launch_polya(d_sig, d_off, d_len, B, d_end, static_cast<hipStream_t>(stream));
+}
+
+int rs_debug_capture_layer(rs_model* m, int layer, void* d_dst, size_t bytes) {
+    if (!m) {
+        set_error("rs_debug_capture_layer: null model");
+        return RS_ERR_ARG;
+    }
+    m->dbg_layer = layer;
+    m->dbg_dst = d_dst;
+    m->dbg_bytes = bytes;
+    return RS_OK;
 }
 
 int rs_profile_enable(rs_model* m, int on) {

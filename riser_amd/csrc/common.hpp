@@ -66,6 +66,10 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
                      hipStream_t st, int* bm_out, int* bn_out, const float* fuse_xs = nullptr,
                      const float* fuse_w0 = nullptr);
 bool conv_wino_can_fuse0(const ConvLayerDev& L, int P_in);
+// fp32 Winograd, layers 0 + 1 of the shipped net as one LDS-free streaming kernel (conv_stream_f32.hip)
+bool conv_stream_f32_ok(const ConvLayerDev& L1, int c0, int P_in1);
+int launch_conv_stream_f32(const ConvLayerDev& L1, const float* d_xs, const float* d_w0, int c0, float* d_y,
+                           const int32_t* d_len, int B, int P_in1, int num_cu, hipStream_t st);
 int conv_wino_max_bn();
 // narrow 16-bit layers (C_in <= 32, C_out <= 48): per-wave streaming kernel, optionally with ConvNet
 // layer 0 folded in (fuse_xs = normalised signals at the padded pitch behind 16 zero bytes)

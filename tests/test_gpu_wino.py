@@ -109,3 +109,24 @@ def test_wino_fused_raw_and_full_batch(dev):
     idx = [0, 17, 255, 511]
     want = ro.classify_reads(synth.make_state_dict(1), [sigs[i] for i in idx])
     assert np.abs(pw[idx] - want).max() < PROB_TOL
+
+
+def test_wino_layer01_variants_bit_identical(dev):
+    """layers 0 + 1 of the fp32 Winograd path exist in three forms - conv0 kernel + tiled kernel (rs_forward),
+    tiled kernel with layer 0 folded into its staging, and the LDS-free streaming kernel (both on the
+    rs_classify path) - which must agree bit for bit on full-length and mixed-length batches."""
+    from riser_amd.preprocess import pack_reads
+    m = get_model(3, dev)
+    for lens in ([16000] * 5, [4096, 16000, 8615, 5000, 12001, 4097, 16383, 9999, 4100]):
+        sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=400 + i)[0] for i, n in enumerate(lens)]
+        sig, off, ln, lh = pack_reads(sigs, dev)
+        xs = [ro.mad_normalise(s) for s in sigs]
+        stream = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+        unfused = m.classify_batch(xs).cpu().numpy()
+        os.environ["RS_NO_STREAM_F32"] = "1"
+        try:
+            folded = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+        finally:
+            del os.environ["RS_NO_STREAM_F32"]
+        assert np.array_equal(stream, unfused), np.abs(stream - unfused).max()
+        assert np.array_equal(folded, unfused), np.abs(folded - unfused).max()
