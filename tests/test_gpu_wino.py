@@ -130,3 +130,39 @@ def test_wino_layer01_variants_bit_identical(dev):
             del os.environ["RS_NO_STREAM_F32"]
         assert np.array_equal(stream, unfused), np.abs(stream - unfused).max()
         assert np.array_equal(folded, unfused), np.abs(folded - unfused).max()
+
+
+@pytest.mark.parametrize("dtype", ["f32w", "f32"])
+def test_layerwise_activations_vs_oracle(dev, dtype):
+    """every conv block's output buffer (rs_debug_capture_layer) against the oracle's activations: valid rows
+    within fp32 round-off, every padding row of every read's slot exactly zero (the next layer's 'same'
+    padding depends on it)."""
+    from riser_amd import _native as nv
+    from riser_amd.preprocess import pack_reads
+    m = get_model(2, dev, dtype)
+    sd = synth.make_state_dict(2)
+    lens = [16000, 5000, 4097]
+    sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=600 + i)[0] for i, n in enumerate(lens)]
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    want = []
+    for s in sigs:
+        x = ro.mad_normalise(s).astype(np.float32)[None, :]
+        _, layers = ro.convnet_forward(sd, x, acc=np.float64, return_layers=True)
+        want.append(layers)
+    P0 = m.padded_length(max(lens))
+    info = m.layer_info()
+    for i in range(1, m.n_layers):
+        P_out, cp = P0 >> (i + 1), info[i]["cp_out"]
+        cap = torch.full((len(lens) * P_out, cp), float("nan"), dtype=torch.float32, device=dev)
+        nv.check(nv.lib().rs_debug_capture_layer(m._h, i, cap.data_ptr(), cap.numel() * 4), "capture")
+        m.classify_raw(sig, off, ln, lh)
+        got = cap.cpu().numpy().reshape(len(lens), P_out, cp)
+        for b, n in enumerate(lens):
+            ref = want[b][i][0].T                                   # [L_out, C]
+            L_out, C = ref.shape
+            assert L_out == n >> (i + 1)
+            scale = max(1.0, float(np.abs(ref).max()))
+            assert np.abs(got[b, :L_out, :C] - ref).max() < 2e-4 * scale, (i, b)
+            assert not got[b, L_out:, :].any(), (i, b)              # padding rows of the slot
+            assert not got[b, :, C:].any(), (i, b)                  # padding channels
+    nv.check(nv.lib().rs_debug_capture_layer(m._h, -1, None, 0), "capture off")
