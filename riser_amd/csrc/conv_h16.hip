@@ -17,6 +17,10 @@
 // Channels are padded to 8 in HBM (16-byte rows pieces) and to 32 in K (zero weights).
 #include "common.hpp"
 
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include <algorithm>
 
 namespace rs {
@@ -332,6 +336,7 @@ const Shape kShapes[] = {
     RS_SHAPE(4, 2, 4, 5), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 4, 7), RS_SHAPE(4, 2, 2, 8),
     RS_SHAPE(2, 4, 2, 2), RS_SHAPE(2, 4, 2, 4), RS_SHAPE(2, 4, 1, 4),
 };
+constexpr int kNumAutoShapes = 18;
 #undef RS_SHAPE
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
@@ -346,7 +351,7 @@ size_t lds_bytes(const Shape& s) {
 const Shape* choose_shape(int64_t rows, int n16, int n_panels, int num_cu) {
     const Shape* best = nullptr;
     double best_cost = 1e300;
-    for (int k = 0; k < kNumShapes; ++k) {
+    for (int k = 0; k < kNumAutoShapes; ++k) {
         const Shape& s = kShapes[k];
         if (lds_bytes(s) > 160 * 1024) continue;
         const int bm = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
@@ -382,6 +387,15 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
     }
     const int n16 = round_up(L.c_out, 16) / 16;
     const Shape* s = choose_shape(rows64, n16, L.plan.nch, num_cu);
+    if (const char* force = getenv("RS_FORCE_SHAPE_H16")) {         // tuning aid: "layer:wm,wn,mt,nt;..."
+        int l, wm, wn, mt, nt;
+        for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
+            if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
+                for (int k = 0; k < kNumShapes; ++k)
+                    if (kShapes[k].wm == wm && kShapes[k].wn == wn && kShapes[k].mt == mt && kShapes[k].nt == nt &&
+                        lds_bytes(kShapes[k]) <= 160 * 1024)
+                        s = &kShapes[k];
+    }
     if (!s) {
         set_error("conv_h16: no tile shape fits");
         return RS_ERR_ARG;

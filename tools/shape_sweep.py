@@ -26,7 +26,7 @@ def run():
 base, info = run()
 print("B", B, "default:", " ".join("L%d[%dx%d]=%.3f" % (i, info[i]["bm"], info[i]["bn"], base[1 + i]) for i in layers))
 for sh in shapes:
-    os.environ["RS_FORCE_SHAPE_WINO" if DT == "f32w" else "RS_FORCE_SHAPE_F32"] = ";".join("%d:%d,%d,%d,%d" % ((l,) + sh) for l in layers)
+    os.environ["RS_FORCE_SHAPE_WINO" if DT == "f32w" else "RS_FORCE_SHAPE_H16" if DT in ("f16", "bf16") else "RS_FORCE_SHAPE_F32"] = ";".join("%d:%d,%d,%d,%d" % ((l,) + sh) for l in layers)
     ms, info = run()
     bm, bn = sh[0]*16*sh[2]*ROWMUL, sh[1]*16*sh[3]
     print("%-12s %4dx%-4d" % (sh, bm, bn), " ".join(("L%d=%.3f" % (i, ms[1 + i])) if (info[i]["bm"], info[i]["bn"]) == (bm, bn) else ("L%d=  -  " % i) for i in layers))
