@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reads", type=int, default=18000)
 ap.add_argument("--len", type=int, default=16000)
 ap.add_argument("--sub-batch", type=int, default=1024)
-ap.add_argument("--dtype", default="f32")
+ap.add_argument("--dtype", default="f32w")
 ap.add_argument("--pinned", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)

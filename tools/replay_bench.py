@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--batches", type=int, default=40)
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--models", type=int, default=1)
-    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--dtype", default="f32w")
     ap.add_argument("--kit", default="RNA004")
     ap.add_argument("--mode", default="enrich")
     args = ap.parse_args()
