@@ -160,3 +160,27 @@ def test_fake_client_contract():
     assert ch == 1 and rd.id == "a" and rd.number == 3 and np.array_equal(c.get_raw_signal(rd), np.arange(10))
     c.get_read_batch()
     assert not c.is_running()
+
+
+def test_winograd_f23_identity_matches_direct_block():
+    """the algebra the default fp32 kernels rely on (csrc/conv_wino.hip): a conv3 + ReLU + MaxPool(2,2) block
+    evaluated as Winograd F(2,3) over pooled positions - 4 products per input channel and output pair
+    instead of 6 - equals the oracle's direct block (float64: to round-off; float32: to a few ulp)."""
+    rng = np.random.default_rng(11)
+    for (B, C, L, Co) in ((2, 5, 37, 7), (1, 20, 64, 30), (3, 3, 9, 4)):
+        x = rng.standard_normal((B, C, L))
+        w = rng.standard_normal((Co, C, 3)) / np.sqrt(3 * C)
+        b = rng.standard_normal(Co) * 0.1
+        Lo = L // 2
+        xp = np.zeros((B, C, 2 * Lo + 3))
+        xp[:, :, 1:L + 1] = x                                    # xp[j] = x[j - 1]; zeros are the 'same' padding
+        d0, d1, d2, d3 = (xp[:, :, k:k + 2 * Lo:2] for k in range(4))      # x[2T-1], x[2T], x[2T+1], x[2T+2]
+        v = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+        u = (w[:, :, 0], (w[:, :, 0] + w[:, :, 1] + w[:, :, 2]) / 2, (w[:, :, 0] - w[:, :, 1] + w[:, :, 2]) / 2, w[:, :, 2])
+        for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+            m = [np.matmul(u[j].astype(dt), v[j].astype(dt)) for j in range(4)]
+            y0, y1 = m[0] + m[1] + m[2], m[1] - m[2] - m[3]
+            got = np.maximum(np.maximum(y0, y1) + b.astype(dt)[None, :, None], 0)
+            want = ro.conv_block(x.astype(dt), w.astype(dt), b.astype(dt), acc=dt)
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max())
