@@ -152,19 +152,19 @@ def main():
     for i in range(1, model.n_layers):
         ms = float(stage_ms[1 + i]) / max(calls, 1)
         P_in = model.padded_length(L) >> i
-        rows = B * (P_in // 2 if lib_dtype == "f32w" else P_in)          # GEMM rows: pooled rows for Winograd
+        rows = B * -(-P_in // info[i]["gemm_row_div"])                   # GEMM rows: groups of 2 / 4 conv rows for Winograd
         executed_flop += 2.0 * rows * info[i]["n_pad"] * info[i]["k_pad"]
         per_layer.append({"layer": i, "ms": round(ms, 4),
                           "tflops": round(flops[i] * B / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
                           "tile": [info[i]["bm"], info[i]["bn"], info[i]["kc"]]})
     executed_tf = executed_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    kname = {"f32w": "conv_wino_kernel (Winograd F(2,3), f32-input MFMA)", "f32": "conv_f32_kernel (direct, f32-input MFMA)"}.get(
+    kname = {"f32w": "conv_wino_kernel / conv_wino4_kernel (Winograd F(2,3) layers 1-5, F(4,3) layers 6-11, f32-input MFMA)", "f32": "conv_f32_kernel (direct, f32-input MFMA)"}.get(
         lib_dtype, "conv_h16_kernel (%s MFMA)" % lib_dtype)
     roofline = {"bound": "mfma", "kernel": kname + ", 11 launches/step, layers 1-11",
                 "achieved": round(achieved_tf, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / peak, 4), "traffic": traffic,
                 "achieved_note": "algorithmic FLOPs of the direct convolution (SURVEY.md 8(d): 582.95 MFLOP per chunk in "
-                                 "layers 1-11) / measured time; Winograd F(2,3) issues 2/3 of them on the matrix pipe",
+                                 "layers 1-11) / measured time; Winograd F(2,3) issues 2/3 of them on the matrix pipe, F(4,3) 1/2",
                 "executed_mfma_tflops": round(executed_tf, 2), "executed_mfma_frac": round(executed_tf / peak, 4),
                 "avg_launch_ms": round(conv_ms / (model.n_layers - 1), 4),
                 "stage_ms": {"normalise": round(float(stage_ms[0]) / max(calls, 1), 4),
@@ -181,7 +181,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"mRNA RNA004 model, batch={B} x {L}-sample (4 s) int16 chunks resident in HBM, "
                                f"MAD-normalise + 12-layer ConvNet forward + softmax, {args.dtype}",
-                   "conv_algorithm": {"f32w": "winograd_f23_fp32", "f32": "direct_fp32"}.get(lib_dtype, "direct_" + lib_dtype),
+                   "conv_algorithm": {"f32w": "winograd_f23_f43_fp32", "f32": "direct_fp32"}.get(lib_dtype, "direct_" + lib_dtype),
                    "batch_per_gpu": B, "chunk_samples": L, "sharding": "reads by id across GPUs, no collectives"},
         "p50_batch_latency_ms": round(p50, 3), "p99_batch_latency_ms": round(p99, 3),
         "latency_note": "host wall time per 512-read batch incl. H2D of int16 signals from pinned memory and D2H of probabilities",

@@ -131,8 +131,9 @@ int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
 int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmin, int Lmax,
                void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream);
 
-/* Row pitch (in samples) the conv stack uses for reads of at most Lmax samples:
- * the smallest multiple of 2^n_layers that is >= Lmax + 1.  rs_normalise's pad_to. */
+/* Row pitch (in samples) the conv stack uses for reads of at most Lmax samples: the smallest multiple of
+ * 2^n_layers (2^(n_layers + 1) when the last layer runs the F(4,3) lowering, as in the default fp32 mode of the
+ * shipped net) that is >= Lmax + 1.  rs_normalise's pad_to. */
 int rs_padded_length(const rs_model* m, int Lmax);
 
 /*
@@ -188,6 +189,7 @@ typedef struct rs_layer_info {
     int32_t k_pad;              /* padded reduction length (3 * padded input channels) */
     int32_t n_pad;              /* padded output channels the MFMA tiles cover */
     int32_t bm, bn, kc;         /* workgroup tile (rows x couts) and channel chunk of the last launch (0 if never run) */
+    int32_t gemm_row_div;       /* conv rows per GEMM row: 1 direct lowering, 2 Winograd F(2,3), 4 Winograd F(4,3) */
 } rs_layer_info;
 int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out);
 

@@ -22,6 +22,7 @@ SYMBOLS = (
     "rs_last_error", "rs_version", "rs_device_count", "rs_model_create", "rs_model_destroy",
     "rs_workspace_bytes", "rs_normalise", "rs_forward", "rs_padded_length", "rs_classify",
     "rs_classify_ensemble", "rs_decide", "rs_polya_end", "rs_model_layer_info", "rs_profile_enable", "rs_profile_read",
+    "rs_debug_capture_layer",
     "rs_seqnet_create", "rs_seqnet_destroy", "rs_seqnet_workspace_bytes", "rs_seqnet_forward",
 )
 
@@ -33,7 +34,7 @@ class SeqOp(C.Structure):
 
 class LayerInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("c_in", "c_out", "cp_in", "cp_out", "k_pad", "n_pad", "bm", "bn", "kc")]
+                ("c_in", "c_out", "cp_in", "cp_out", "k_pad", "n_pad", "bm", "bn", "kc", "gemm_row_div")]
 
 
 class NativeError(RuntimeError):

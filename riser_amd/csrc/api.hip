@@ -4,6 +4,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -38,6 +39,7 @@ struct rs_model {
     int device = 0;
     int dtype = RS_F32;
     int n_layers = 0;
+    int pad_shift = 0;                    // row pitch of the signals is a multiple of 1 << pad_shift (>= n_layers)
     int n_classes = 2;
     int channels[kMaxLayers] = {0};
     int cp[kMaxLayers] = {0};             // padded row width of layer i's OUTPUT buffer
@@ -106,6 +108,41 @@ ConvPlan plan_static_wino(int cp_in, int c_out) {
     return p;
 }
 
+// F(4,3): chunks of 16 or 20 channels (LDS capacity); 6 * kc / 4 slots per chunk
+ConvPlan plan_static_wino4(int cp_in, int c_out) {
+    ConvPlan p{};
+    double best_cost = -1;
+    for (int kc = 16; kc <= 20; kc += 4) {
+        const int nch = (cp_in + kc - 1) / kc;
+        const double cost = nch * (1.5 * kc + 2.0);
+        if (best_cost < 0 || cost < best_cost - 1e-9) {
+            best_cost = cost;
+            p.kc = kc;
+            p.nch = nch;
+        }
+    }
+    p.n_alloc = round_up(c_out, 16) + conv_wino4_max_bn();
+    return p;
+}
+
+// which layers of an RS_F32W model run F(4,3) instead of F(2,3): by default the wide ones (>= 128 input
+// channels: layers 6-11 of the shipped net, where the matrix pipe is the bound: measured -12 ... -16 % on
+// layers 6-9, -10 % on layer 11, -3 % on layer 10; +8 % on layer 4).  RS_WINO4 = comma list of layer indices
+// overrides it when the model is created ("" or "none" = F(2,3) everywhere).
+bool use_wino4(int layer, int c_in) {
+    if (const char* e = getenv("RS_WINO4")) {
+        for (const char* q = e; *q;) {
+            char* end = nullptr;
+            const long v = strtol(q, &end, 10);
+            if (end == q) break;
+            if (v == layer) return true;
+            q = *end ? end + 1 : end;
+        }
+        return false;
+    }
+    return c_in >= 128;
+}
+
 struct WsLayout {
     size_t xnorm_off, bufa_off, bufb_off, total;
     int P0;
@@ -113,7 +150,7 @@ struct WsLayout {
 
 WsLayout ws_layout(const rs_model* m, int B, int Lmax) {
     WsLayout w{};
-    const int unit = 1 << m->n_layers;
+    const int unit = 1 << m->pad_shift;
     w.P0 = round_up(Lmax + 1, unit);
     size_t buf = 0;
     for (int i = 0; i < m->n_layers; ++i) {
@@ -247,6 +284,25 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             float* dw = nullptr;
             rc = upload(&dw, wp);
             L.d_w = dw;
+        } else if (dtype == RS_F32W && use_wino4(i, L.c_in)) {
+            // Winograd F(4,3) filter transform U = G g (fp64, rounded once); packed [n_alloc][nch][6][kc]
+            L.wino_m = 4;
+            L.plan = plan_static_wino4(L.cp_in, L.c_out);
+            const ConvPlan& p = L.plan;
+            std::vector<float> wp((size_t)p.n_alloc * p.nch * 6 * p.kc, 0.0f);
+            for (int n = 0; n < L.c_out; ++n)
+                for (int ci = 0; ci < L.c_in; ++ci) {
+                    const int c = ci / p.kc, cc = ci - c * p.kc;
+                    const float* g = &conv_w[i][((size_t)n * L.c_in + ci) * 3];
+                    const double g0 = g[0], g1 = g[1], g2 = g[2];
+                    const double u[6] = {g0 / 4.0, -(g0 + g1 + g2) / 6.0, -(g0 - g1 + g2) / 6.0,
+                                         g0 / 24.0 + g1 / 12.0 + g2 / 6.0, g0 / 24.0 - g1 / 12.0 + g2 / 6.0, g2};
+                    for (int j = 0; j < 6; ++j)
+                        wp[(((size_t)n * p.nch + c) * 6 + j) * p.kc + cc] = (float)u[j];
+                }
+            float* dw = nullptr;
+            rc = upload(&dw, wp);
+            L.d_w = dw;
         } else if (dtype == RS_F32W) {
             // Winograd F(2,3) filter transform (fp64, rounded once): U0 = g0, U1 = (g0+g1+g2)/2,
             // U2 = (g0-g1+g2)/2, U3 = g2; packed [n_alloc][nch][4][kc]
@@ -288,6 +344,12 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         for (int n = 0; n < L.c_out; ++n) bp[n] = conv_b[i][n];
         if (rc == RS_OK) rc = upload(&L.d_bias, bp);
     }
+    // every read's slot must start on a Winograd group boundary in every F(4,3) layer (P0 >> i divisible by 4):
+    // then the grouping of a read's rows - and with it every rounding - is the same wherever the read sits in a
+    // batch and whatever the batch's longest read is (results are bit-identical across batch compositions)
+    m->pad_shift = n_layers;
+    for (int i = 1; i < n_layers; ++i)
+        if (m->layers[i].wino_m == 4) m->pad_shift = std::max(m->pad_shift, i + 2);
     if (rc == RS_OK) rc = upload(&m->d_zero, std::vector<float>(64, 0.0f));
     if (rc == RS_OK) {
         const int cl = channels[n_layers - 1];
@@ -324,7 +386,7 @@ int rs_model_destroy(rs_model* m) {
 
 int rs_padded_length(const rs_model* m, int Lmax) {
     if (!m || Lmax < 1) return 0;
-    return round_up(Lmax + 1, 1 << m->n_layers);
+    return round_up(Lmax + 1, 1 << m->pad_shift);
 }
 
 size_t rs_workspace_bytes(const rs_model* m, int B, int Lmax) {
@@ -411,7 +473,10 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                                         m->num_cu, st);
             m->last_bm[i] = 32;
             m->last_bn[i] = round_up(L.c_out, 16);
-        } else if (m->dtype == RS_F32W)
+        } else if (m->dtype == RS_F32W && L.wino_m == 4)
+            rc = launch_conv_wino4(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len, B,
+                                   P_in, i, m->num_cu, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
+        else if (m->dtype == RS_F32W)
             rc = launch_conv_wino(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
                                   B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i],
                                   (fuse0 && i == 1) ? d_x : nullptr, m->d_w0);
@@ -475,7 +540,7 @@ int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d
     rs_model* m0 = models[0];
     for (int k = 0; k < n_models; ++k)
         if (!models[k] || models[k]->n_layers != m0->n_layers || models[k]->device != m0->device ||
-            esize(models[k]) != esize(m0)) {
+            esize(models[k]) != esize(m0) || models[k]->pad_shift != m0->pad_shift) {
             set_error("rs_classify_ensemble: model %d is null or differs in depth / device / element size", k);
             return RS_ERR_ARG;
         }
@@ -586,16 +651,18 @@ int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out) {
         out->cp_in = 1;
         out->k_pad = 3;
         out->n_pad = m->cp[0];
+        out->gemm_row_div = 1;
         return RS_OK;
     }
     const ConvLayerDev& L = m->layers[layer];
     out->c_in = L.c_in;
     out->cp_in = L.cp_in;
-    out->k_pad = (m->dtype == RS_F32W ? 4 : 3) * L.plan.kc * L.plan.nch;
+    out->k_pad = (m->dtype == RS_F32W ? (L.wino_m == 4 ? 6 : 4) : 3) * L.plan.kc * L.plan.nch;
     out->n_pad = m->last_bn[layer] ? round_up(round_up(L.c_out, 16), m->last_bn[layer]) : round_up(L.c_out, 16);
     out->bm = m->last_bm[layer];
     out->bn = m->last_bn[layer];
     out->kc = L.plan.kc;
+    out->gemm_row_div = m->dtype == RS_F32W ? L.wino_m : 1;
     return RS_OK;
 }
 

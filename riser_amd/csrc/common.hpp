@@ -49,6 +49,7 @@ struct ConvPlan {
 };
 
 struct ConvLayerDev {
+    int wino_m = 2;           // RS_F32W: output pairs per Winograd tile (2: F(2,3), conv_wino.hip; 4: F(4,3), conv_wino4.hip)
     int c_in, c_out, cp_in, cp_out;
     ConvPlan plan;            // packing of d_w follows plan.kc / plan.nch / plan.n_pad
     void* d_w;                // packed weights [n_alloc][nch][3][kc] (f32 or bf16)
@@ -65,6 +66,9 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
                      int B, int P_in, int layer_index, int num_cu, const float* d_zero, int check_dead,
                      hipStream_t st, int* bm_out, int* bn_out, const float* fuse_xs = nullptr,
                      const float* fuse_w0 = nullptr);
+int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
+                      int layer_index, int num_cu, int check_dead, hipStream_t st, int* bm_out, int* bn_out);
+int conv_wino4_max_bn();
 bool conv_wino_can_fuse0(const ConvLayerDev& L, int P_in);
 // fp32 Winograd, layers 0 + 1 of the shipped net as one LDS-free streaming kernel (conv_stream_f32.hip)
 bool conv_stream_f32_ok(const ConvLayerDev& L1, int c0, int P_in1);

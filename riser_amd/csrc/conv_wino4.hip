@@ -1,0 +1,486 @@
+// K3w4 (fp32, Winograd F(4,3)): ConvNet block i >= 1 for the wide late layers.
+//
+//   Conv1d(C_in -> C_out, k=3, stride 1, zero 'same' padding, bias) -> ReLU -> MaxPool1d(2,2)
+//   (riser/nets/cnn.py:52-65, depth 1)
+//
+// F(4,3) produces FOUR consecutive conv outputs y[4G .. 4G+3] (two pooling pairs) from the six inputs
+// d0..d5 = x[4G-1 .. 4G+4] with 6 multiplications per input channel instead of 12 (F(2,3): 8), i.e. half
+// the matrix-pipe work of the direct lowering:
+//     V = B^T d    B^T = [ 4  0 -5  0  1  0 ]      U = G g    G = [ 1/4    0     0  ]      y = A^T (U . V)
+//                        [ 0 -4 -4  1  1  0 ]                     [-1/6  -1/6  -1/6 ]      A^T = [ 1 1  1 1  1 0 ]
+//                        [ 0  4 -4 -1  1  0 ]                     [-1/6   1/6  -1/6 ]            [ 0 1 -1 2 -2 0 ]
+//                        [ 0 -2 -1  2  1  0 ]                     [ 1/24  1/12  1/6 ]            [ 0 1  1 4  4 0 ]
+//                        [ 0  2 -1 -2  1  0 ]                     [ 1/24 -1/12  1/6 ]            [ 0 1 -1 8 -8 1 ]
+//                        [ 0  4  0 -5  0  1 ]                     [  0     0     1  ]
+// (Lavin & Gray's transform set).  The layer is SIX GEMMs M_j[G][n] = sum_c V_j[G][c] * U_j[n][c] over
+// groups G of four input rows; the epilogue forms y0..y3, the two pooled values max(y0,y1), max(y2,y3),
+// + bias, ReLU, length mask, and stores two 16-byte pieces per lane and sub-tile.
+// fp32 throughout; measured on the CPU in numpy the probabilities stay within 9e-6 of an fp64 evaluation
+// (direct fp32: 6e-6), see tests/test_oracle_golden.py and tests/test_gpu_wino.py.
+//
+// Structure, data layout, staging (buffer loads, pass-major unit map), tile walk and MFMA orientation are
+// those of conv_wino.hip; what differs: the input slab is split into FOUR planes by (row mod 4) so that the
+// six inputs of group G are rows G, G+1 of the planes (unit lane stride, pitch KC + 2: conflict-free
+// ds_read_b32), the weight slab has six components, a slot = (k-step, component) carries MT * NT MFMAs
+// with MT * NT <= 5 (6 x 4 accumulator registers per 16 x 16 sub-tile), and LDS capacity limits the channel
+// chunk to 16 or 20.  Used for the layers where the matrix pipe is the bound (chosen in rs_model_create).
+#include "common.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <utility>
+
+namespace rs {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+struct Wino4Args {
+    const float* x;
+    const float* w;        // packed [n_alloc][nch][6][kc] (U0..U5), zero rows beyond c_out
+    const float* bias;     // [n_alloc]
+    float* y;
+    const int32_t* len;
+    unsigned x_bytes, w_bytes, y_bytes, y_row_bytes, len_bytes, bias_bytes;
+    int rows_in;           // B * P_in
+    int rows_out;          // B * P_out (pooled rows)
+    int n_groups;          // ceil(rows_in / 4)
+    int P_out;
+    float inv_P_out;
+    int cp_in, cp_out;
+    int nch;
+    int shift_out;
+    int n_mtiles, n_ntiles;
+    int check_dead;
+};
+
+template <int WM, int WN, int MT, int NT, int KCT>
+__global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
+    static_assert(WM * WN == 8, "8 waves per workgroup (2 per SIMD)");
+    static_assert(KCT == 16 || KCT == 20, "channel chunk");
+    constexpr int kThreads = 512;
+    constexpr int NC = 6;                               // Winograd components
+    constexpr int BG = WM * 16 * MT;                    // groups (of 4 conv rows = 2 pooled rows) per tile
+    constexpr int BN = WN * 16 * NT;
+    constexpr int S = KCT + 2;
+    constexpr int KQ = KCT / 4;
+    constexpr int PL = (BG + 1) * S;                    // one plane (input rows = p mod 4)
+    constexpr int A_ELEMS = 4 * PL;
+    constexpr int BUF = A_ELEMS + NC * BN * S;
+    constexpr int RPT = (kThreads / KQ) & ~3;           // slab rows per staging pass, a multiple of 4
+    constexpr int A_ROWS = 4 * BG + 2;
+    constexpr int A_PER = (A_ROWS + RPT - 1) / RPT;
+    constexpr int NPP = kThreads / (NC * KQ);
+    constexpr int B_PER = (BN + NPP - 1) / NPP;
+    constexpr unsigned kOob = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int r = lane & 15, kq = lane >> 4;
+
+    // ---- staging map (see conv_wino.hip) -----------------------------------------------------------------
+    // slab row s (global input row 4*m0g - 1 + s) lives in plane s & 3 at index s >> 2; a thread's rows
+    // a_row + u * RPT keep their plane because RPT is a multiple of 4
+    const int a_row = tid / KQ, a_c4 = tid - a_row * KQ;
+    const bool a_act = a_row < RPT;
+    const int b_n = tid / (NC * KQ), b_rem = tid - b_n * (NC * KQ);
+    const bool b_act = b_n < NPP;
+    const int a_st = (a_row & 3) * PL + (a_row >> 2) * S + 4 * a_c4;                     // + u * (RPT/4) * S
+    const int b_st = A_ELEMS + ((b_rem / KQ) * BN + b_n) * S + 4 * (b_rem % KQ);         // + u * NPP * S
+    const unsigned a_tb = (unsigned)(a_row * a.cp_in + 4 * a_c4) * 4u;
+    const unsigned b_tb = (unsigned)(b_n * a.nch * NC * KCT + 4 * b_rem) * 4u;
+    const unsigned a_step = (unsigned)(RPT * a.cp_in) * 4u;
+    const unsigned b_step = (unsigned)(NPP * a.nch * NC * KCT) * 4u;
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_len =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.len), 0, a.len_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_bias =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias_bytes, 0x00020000);
+    const const_len_ptr clen = as_const_len(a.len);
+
+    u32x4 ra[A_PER], rb[B_PER];
+    unsigned a_ib = kOob, b_ib = kOob;
+    auto item_offsets = [&](int m0g, int n0, int c, bool live) {
+        const bool a_ok = live && a_act && c * KCT + 4 * a_c4 < a.cp_in;
+        a_ib = a_ok ? a_tb + (unsigned)((4 * m0g - 1) * a.cp_in + c * KCT) * 4u : kOob;   // row -1 wraps out of range
+        b_ib = (live && b_act) ? b_tb + (unsigned)((n0 * a.nch + c) * NC * KCT) * 4u : kOob;
+    };
+    auto load_unit = [&](auto U) {
+        constexpr int u = decltype(U)::value;
+        if constexpr (u < A_PER) {
+            unsigned off = a_ib + (unsigned)u * a_step;
+            if constexpr ((u + 1) * RPT > A_ROWS) off = (a_row + u * RPT < A_ROWS) ? off : kOob;
+            ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+        } else {
+            constexpr int v = u - A_PER;
+            unsigned off = b_ib + (unsigned)v * b_step;
+            if constexpr ((v + 1) * NPP > BN) off = (b_n + v * NPP < BN) ? off : kOob;
+            rb[v] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
+        }
+    };
+    auto store_unit = [&](auto U, float* buf) {
+        constexpr int u = decltype(U)::value;
+        if constexpr (u < A_PER) {
+            bool act = a_act;
+            if constexpr ((u + 1) * RPT > A_ROWS) act = act && (a_row + u * RPT < A_ROWS);
+            if (act) {
+                uint2* d = reinterpret_cast<uint2*>(buf + a_st + u * (RPT / 4) * S);
+                d[0] = make_uint2(ra[u].x, ra[u].y);
+                d[1] = make_uint2(ra[u].z, ra[u].w);
+            }
+        } else {
+            constexpr int v = u - A_PER;
+            bool act = b_act;
+            if constexpr ((v + 1) * NPP > BN) act = act && (b_n + v * NPP < BN);
+            if (act) {
+                uint2* d = reinterpret_cast<uint2*>(buf + b_st + v * NPP * S);
+                d[0] = make_uint2(rb[v].x, rb[v].y);
+                d[1] = make_uint2(rb[v].z, rb[v].w);
+            }
+        }
+    };
+
+    // ---- tile walk (conv_wino.hip), tiles counted in groups ----------------------------------------------
+    const int tiles = a.n_mtiles * a.n_ntiles;
+    auto tile_origin = [&](int q, int& tm0, int& tn0) {
+        const int nt_ = a.n_ntiles == 1 ? 0 : q / a.n_mtiles;
+        const int mi = q - nt_ * a.n_mtiles;
+        tm0 = mi * BG;
+        tn0 = nt_ * BN;
+    };
+    const int nwg_ = gridDim.x;
+    const int blk_ = (nwg_ & 7) == 0 ? nwg_ >> 3 : nwg_;
+    const int blk_base_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x & 7) * blk_ : 0;
+    int slot_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int round_base_ = 0;
+    auto order_index = [&]() {
+        const int q = round_base_ + blk_base_ + slot_;
+        round_base_ += nwg_;
+        if (a.check_dead) {
+            slot_ += 5 % blk_;
+            if (slot_ >= blk_) slot_ -= blk_;
+        }
+        return q;
+    };
+    auto next_live = [&]() {
+        int q = order_index();
+        while (a.check_dead && q < tiles) {
+            int tm0, tn0;
+            tile_origin(q, tm0, tn0);
+            const int pr0 = 2 * tm0;                                  // first pooled row of the tile
+            const int b = pr0 / a.P_out;
+            const int t0 = pr0 - b * a.P_out;
+            if (!(b < a.rows_out / a.P_out && t0 + 2 * BG <= a.P_out && t0 >= (clen[b] >> a.shift_out))) break;
+            const int pieces_per_row = BN / 4;
+            for (int f = threadIdx.x; f < 2 * BG * pieces_per_row; f += blockDim.x) {
+                const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 4;
+                const int prow = pr0 + rr, col = tn0 + cc;
+                if (prow < a.rows_out && col < a.cp_out)
+                    *reinterpret_cast<float4*>(a.y + (int64_t)prow * a.cp_out + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            q = order_index();
+        }
+        return q;
+    };
+    int o = next_live();
+    if (o >= tiles) return;
+
+    f32x4 acc[MT][NT][NC];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int c = 0;
+    int m0, n0;
+    tile_origin(o, m0, n0);
+    item_offsets(m0, n0, 0, true);
+    static_for<A_PER + B_PER>([&](auto U) { load_unit(U); });
+    static_for<A_PER + B_PER>([&](auto U) { store_unit(U, lds); });
+    __syncthreads();
+    int buf = 0;
+
+    const int a_rd = (wm * 16 * MT + r) * S + kq;                  // + (k & 3) * PL + (i * 16 + (k >> 2)) * S + c0
+    const int b_rd = A_ELEMS + (wn * 16 * NT + r) * S + kq;        // + (comp * BN + j * 16) * S + c0
+
+    while (true) {
+        int nc = c + 1, no = o;
+        if (nc == a.nch) {
+            nc = 0;
+            no = next_live();
+        }
+        const bool has_next = no < tiles;
+        int nm0 = m0, nn0 = n0;
+        if (has_next && nc == 0) tile_origin(no, nm0, nn0);
+        const float* Ab = lds + buf * BUF + a_rd;
+        const float* Bb = lds + buf * BUF + b_rd;
+        float* nbuf = lds + (buf ^ 1) * BUF;
+        item_offsets(nm0, nn0, nc, has_next);
+
+        constexpr int NSLOTS = NC * KQ;                // slot = (k-step, component): MT * NT MFMAs
+        constexpr int UNITS = A_PER + B_PER;
+        constexpr int DIST = 6;                        // slots between a unit's load and its LDS write
+        constexpr int SPAN = NSLOTS - DIST;
+        float dr[MT][6];                               // raw inputs d0..d5 of the lane's groups (next k-step)
+        float uf[2][NT];                               // weight fragments, double-buffered per slot
+        float v[MT][NC];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dr[i][k] = Ab[(k & 3) * PL + (i * 16 + (k >> 2)) * S];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) uf[0][j] = Bb[j * 16 * S];
+        static_for<NSLOTS>([&](auto SL) {
+            constexpr int sl = decltype(SL)::value;
+            constexpr int st = sl / NC, comp = sl % NC;
+            if constexpr (comp == 0) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {                     // V = B^T d
+                    const float d0 = dr[i][0], d1 = dr[i][1], d2 = dr[i][2], d3 = dr[i][3], d4 = dr[i][4],
+                                d5 = dr[i][5];
+                    const float p = fmaf(-4.0f, d2, d4), q = fmaf(-4.0f, d1, d3);
+                    const float s2 = d4 - d2, t2 = d3 - d1;
+                    v[i][0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+                    v[i][1] = p + q;
+                    v[i][2] = p - q;
+                    v[i][3] = fmaf(2.0f, t2, s2);
+                    v[i][4] = fmaf(-2.0f, t2, s2);
+                    v[i][5] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+                }
+            }
+            if constexpr (comp == 1 && st + 1 < KQ) {
+                constexpr int c0 = 4 * (st + 1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) dr[i][k] = Ab[(k & 3) * PL + (i * 16 + (k >> 2)) * S + c0];
+            }
+            if constexpr (sl + 1 < NSLOTS) {
+                constexpr int nst = (sl + 1) / NC, ncomp = (sl + 1) % NC;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) uf[(sl + 1) & 1][j] = Bb[(ncomp * BN + j * 16) * S + 4 * nst];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j][comp] =
+                        __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl & 1][j], v[i][comp], acc[i][j][comp], 0, 0, 0);
+            {
+                constexpr int n_rd = (sl + 1 < NSLOTS ? NT : 0) + ((comp == 1 && st + 1 < KQ) ? 3 * MT : 0);
+                constexpr int n_pair = n_rd < MT * NT ? n_rd : MT * NT;
+                static_for<n_pair>([&](auto) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                });
+                if constexpr (MT * NT - n_pair > 0) __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - n_pair, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<UNITS>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                if constexpr ((u * SPAN) / UNITS == sl) load_unit(U);
+                if constexpr ((u * SPAN) / UNITS + DIST == sl) {
+                    if (has_next) store_unit(U, nbuf);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+
+        if (c == a.nch - 1) {
+            // ---- epilogue: y = A^T m, two pooled rows per group, bias + ReLU + length mask, 16-byte stores -----
+            const int pr0 = 2 * m0;
+            const int b0 = pr0 / a.P_out;
+            const int p0 = pr0 - b0 * a.P_out;
+            unsigned rowoff_[MT][2];
+            bool valid_[MT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int loc = 2 * ((wm * MT + i) * 16 + r) + h;
+                    const int t = p0 + loc;
+                    const int e = (int)(((float)t + 0.5f) * a.inv_P_out);      // t < P_out + 2 * BG < 2^16: exact
+                    const int pin = t - e * a.P_out;
+                    const unsigned lv = __builtin_amdgcn_raw_buffer_load_b32(rs_len, (unsigned)(b0 + e) * 4u, 0, 0);
+                    rowoff_[i][h] = (unsigned)(pr0 + loc) * a.y_row_bytes;    // rows past the end: out of range
+                    valid_[i][h] = pin < (int)(lv >> a.shift_out);
+                }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = n0 + (wn * NT + j) * 16 + 4 * kq;
+                const unsigned coloff = col < a.cp_out ? (unsigned)col * 4u : kOob;
+                const f32x4 bi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, (unsigned)col * 4u, 0, 0));
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    f32x4 o0, o1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float m0_ = acc[i][j][0][q], m1 = acc[i][j][1][q], m2 = acc[i][j][2][q],
+                                    m3 = acc[i][j][3][q], m4 = acc[i][j][4][q], m5 = acc[i][j][5][q];
+                        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                        const float y0 = (m0_ + s12) + s34;
+                        const float y1 = fmaf(2.0f, d34, d12);
+                        const float y2 = fmaf(4.0f, s34, s12);
+                        const float y3 = fmaf(8.0f, d34, d12) + m5;
+                        o0[q] = valid_[i][0] ? fmaxf(fmaxf(y0, y1) + bi[q], 0.0f) : 0.0f;
+                        o1[q] = valid_[i][1] ? fmaxf(fmaxf(y2, y3) + bi[q], 0.0f) : 0.0f;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rs_y, rowoff_[i][0] + coloff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rs_y, rowoff_[i][1] + coloff, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();
+        buf ^= 1;
+        o = no;
+        c = nc;
+        m0 = nm0;
+        n0 = nn0;
+    }
+}
+
+using KernelFn = void (*)(const Wino4Args);
+
+struct Shape {
+    int wm, wn, mt, nt;
+    KernelFn fn[2];        // chunk = 16, 20
+};
+
+#define RS_SHAPE(WM, WN, MT, NT) \
+    {WM, WN, MT, NT, {conv_wino4_kernel<WM, WN, MT, NT, 16>, conv_wino4_kernel<WM, WN, MT, NT, 20>}}
+const Shape kShapes[] = {
+    RS_SHAPE(8, 1, 1, 2), RS_SHAPE(8, 1, 1, 3), RS_SHAPE(8, 1, 1, 4), RS_SHAPE(8, 1, 1, 5),
+    RS_SHAPE(4, 2, 1, 2), RS_SHAPE(4, 2, 1, 3), RS_SHAPE(4, 2, 1, 4), RS_SHAPE(4, 2, 2, 2),
+    RS_SHAPE(2, 4, 1, 2), RS_SHAPE(2, 4, 1, 3), RS_SHAPE(2, 4, 1, 4), RS_SHAPE(2, 4, 2, 2),
+};
+#undef RS_SHAPE
+constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
+
+size_t lds_bytes(const Shape& s, int kc) {
+    const int bg = s.wm * 16 * s.mt, bn = s.wn * 16 * s.nt;
+    return 2 * (size_t)(4 * (bg + 1) + 6 * bn) * (kc + 2) * sizeof(float);
+}
+
+const Shape* choose_shape(int64_t groups, int n16, int kc, int nch, int num_cu, double* cost_out) {
+    const Shape* best = nullptr;
+    double best_cost = 1e300;
+    for (int k = 0; k < kNumShapes; ++k) {
+        const Shape& s = kShapes[k];
+        if (lds_bytes(s, kc) > 160 * 1024) continue;
+        const int bg = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
+        const int64_t mtiles = (groups + bg - 1) / bg;
+        const int64_t ntiles = (n16 + bnt - 1) / bnt;
+        const int64_t tiles = mtiles * ntiles;
+        const int64_t rounds = (tiles + num_cu - 1) / num_cu;
+        const double slots = 6.0 * kc / 4.0;
+        const double staged = ((4.0 * bg + 2) + 6.0 * bnt * 16) * kc * 4.0;
+        const double item = slots * (2.0 * s.mt * s.nt * 32.0 + 6.0 * (s.mt + s.nt)) + 900.0 + 0.06 * staged;
+        const double tile = nch * item + 1500.0 + 90.0 * s.mt * s.nt;
+        const double cost = (double)rounds * tile;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = &s;
+        }
+    }
+    if (cost_out) *cost_out = best_cost;
+    return best;
+}
+
+}  // namespace
+
+int conv_wino4_max_bn() { return 256; }
+
+int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
+                      int layer_index, int num_cu, int check_dead, hipStream_t st, int* bm_out, int* bn_out) {
+    const ConvPlan& p = L.plan;
+    if (p.kc != 16 && p.kc != 20) {
+        set_error("conv_wino4: unsupported channel chunk %d", p.kc);
+        return RS_ERR_ARG;
+    }
+    const int64_t rows64 = (int64_t)B * P_in;
+    const int64_t xb = rows64 * L.cp_in * 4, wb = (int64_t)p.n_alloc * p.nch * 6 * p.kc * 4,
+                  yb = rows64 / 2 * L.cp_out * 4;
+    if (rows64 > 0x7fffffff || xb >= 0x80000000LL || wb >= 0x80000000LL || yb >= 0x80000000LL) {
+        set_error("conv_wino4: batch too large for the 2 GiB buffer window, split it");
+        return RS_ERR_ARG;
+    }
+    const int n16 = round_up(L.c_out, 16) / 16;
+    const int64_t groups = (rows64 + 3) / 4;
+    const Shape* s = choose_shape(groups, n16, p.kc, p.nch, num_cu, nullptr);
+    if (const char* force = getenv("RS_FORCE_SHAPE_WINO4")) {       // tuning aid: "layer:wm,wn,mt,nt;..."
+        int l, wm, wn, mt, nt;
+        for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
+            if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
+                for (int k = 0; k < kNumShapes; ++k)
+                    if (kShapes[k].wm == wm && kShapes[k].wn == wn && kShapes[k].mt == mt && kShapes[k].nt == nt &&
+                        lds_bytes(kShapes[k], p.kc) <= 160 * 1024)
+                        s = &kShapes[k];
+    }
+    if (!s) {
+        set_error("conv_wino4: no tile shape fits (kc=%d)", p.kc);
+        return RS_ERR_ARG;
+    }
+    const int BG = s->wm * 16 * s->mt, BN = s->wn * 16 * s->nt;
+    Wino4Args a;
+    a.x = d_x;
+    a.w = static_cast<const float*>(L.d_w);
+    a.bias = L.d_bias;
+    a.y = d_y;
+    a.len = d_len;
+    a.x_bytes = (unsigned)xb;
+    a.w_bytes = (unsigned)wb;
+    a.y_bytes = (unsigned)yb;
+    a.y_row_bytes = (unsigned)L.cp_out * 4u;
+    a.len_bytes = (unsigned)B * 4u;
+    a.bias_bytes = (unsigned)p.n_alloc * 4u;
+    a.rows_in = (int)rows64;
+    a.rows_out = (int)(rows64 / 2);
+    a.n_groups = (int)groups;
+    a.P_out = P_in / 2;
+    a.inv_P_out = 1.0f / (float)a.P_out;
+    a.cp_in = L.cp_in;
+    a.cp_out = L.cp_out;
+    a.nch = p.nch;
+    a.shift_out = layer_index + 1;
+    a.n_mtiles = (a.n_groups + BG - 1) / BG;
+    a.n_ntiles = (n16 * 16 + BN - 1) / BN;
+    a.check_dead = check_dead;
+    const size_t lds = lds_bytes(*s, p.kc);
+    KernelFn fn = s->fn[p.kc == 16 ? 0 : 1];
+    RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, a);
+    RS_HIP(hipGetLastError());
+    if (bm_out) *bm_out = 4 * BG;           // reported in conv rows, like the other kernels
+    if (bn_out) *bn_out = BN;
+    return RS_OK;
+}
+
+}  // namespace rs

@@ -166,3 +166,47 @@ def test_layerwise_activations_vs_oracle(dev, dtype):
             assert not got[b, L_out:, :].any(), (i, b)              # padding rows of the slot
             assert not got[b, :, C:].any(), (i, b)                  # padding channels
     nv.check(nv.lib().rs_debug_capture_layer(m._h, -1, None, 0), "capture off")
+
+
+def test_winograd_f43_layers(dev, monkeypatch):
+    """the F(4,3) lowering of the wide late layers (csrc/conv_wino4.hip; RS_WINO4 selects the layers when the model
+    is created): probabilities within the fp32 bar of the oracle and of the all-F(2,3) model, labels identical,
+    on a full-length batch, a mixed-length batch and a single read; activations of an F(4,3) layer within
+    round-off of the oracle."""
+    from riser_amd import _native as nv
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    sd = synth.make_state_dict(1)
+    monkeypatch.setenv("RS_WINO4", "none")                        # reference model: F(2,3) on every layer
+    base = Model(sd, synth.Config(), None, "m", dtype="f32w", device=dev)
+    monkeypatch.setenv("RS_WINO4", "4,5,6,7,8,9,10,11")          # more layers than the default (6-11)
+    m = Model(sd, synth.Config(), None, "m", dtype="f32w", device=dev)
+    monkeypatch.delenv("RS_WINO4")
+    for lens in ([16000] * 8, [4096, 16000, 8615, 5000, 12001, 4097, 16383, 9999, 4100], [6024]):
+        sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=800 + i)[0] for i, n in enumerate(lens)]
+        sig, off, ln, lh = pack_reads(sigs, dev)
+        got = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+        ref = base.classify_raw(sig, off, ln, lh).cpu().numpy()
+        want = ro.classify_reads(sd, sigs)
+        assert np.abs(got - want).max() < 1e-4, np.abs(got - want).max()
+        assert np.abs(got - ref).max() < 1e-4
+        assert np.array_equal(got[:, 1] > 0.9, want[:, 1] > 0.9)
+    # one captured F(4,3) layer against the oracle's activations (valid rows, zero padding)
+    lens = [16000, 5000]
+    sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=820 + i)[0] for i, n in enumerate(lens)]
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    i = 8
+    P_out, cp = m.padded_length(16000) >> (i + 1), m.layer_info()[i]["cp_out"]
+    cap = torch.full((len(lens) * P_out, cp), float("nan"), dtype=torch.float32, device=dev)
+    nv.check(nv.lib().rs_debug_capture_layer(m._h, i, cap.data_ptr(), cap.numel() * 4), "capture")
+    m.classify_raw(sig, off, ln, lh)
+    got = cap.cpu().numpy().reshape(len(lens), P_out, cp)
+    for b, s in enumerate(sigs):
+        x = ro.mad_normalise(s).astype(np.float32)[None, :]
+        _, layers = ro.convnet_forward(sd, x, acc=np.float64, return_layers=True)
+        refl = layers[i][0].T
+        L_out, C = refl.shape
+        assert np.abs(got[b, :L_out, :C] - refl).max() < 2e-4 * max(1.0, float(np.abs(refl).max()))
+        assert not got[b, L_out:, :].any() and not got[b, :, C:].any()
+    m.close()
+    base.close()
