@@ -109,13 +109,28 @@ ConvPlan plan_static_wino(int cp_in, int c_out) {
 }
 
 // F(4,3): chunks of 16 or 20 channels (LDS capacity); 6 * kc / 4 slots per chunk
-ConvPlan plan_static_wino4(int cp_in, int c_out) {
+// tuning aid: RS_PLAN_KC = "layer:kc;layer:kc" forces the channel chunk of a layer when the model is created
+int forced_kc(int layer) {
+    if (const char* e = getenv("RS_PLAN_KC")) {
+        int l, kc;
+        for (const char* q = e; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
+            if (sscanf(q, "%d:%d", &l, &kc) == 2 && l == layer) return kc;
+    }
+    return 0;
+}
+
+// The chunk (16 or 20 channels; LDS capacity) fixes the weight packing, but also which tile shapes fit in LDS
+// (80-channel-wide tiles need chunks of 16), so it is chosen with the launch planner's own cost estimate at a
+// nominal batch (512 reads of 16000 samples, BASELINE config 2).
+ConvPlan plan_static_wino4(int cp_in, int c_out, int layer, int num_cu) {
     ConvPlan p{};
     double best_cost = -1;
+    const int64_t groups = (int64_t)512 * (16384 >> layer) / 4;
     for (int kc = 16; kc <= 20; kc += 4) {
+        if (forced_kc(layer) && kc != forced_kc(layer)) continue;
         const int nch = (cp_in + kc - 1) / kc;
-        const double cost = nch * (1.5 * kc + 2.0);
-        if (best_cost < 0 || cost < best_cost - 1e-9) {
+        const double cost = conv_wino4_plan_cost(groups, round_up(c_out, 16) / 16, kc, nch, num_cu);
+        if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             p.kc = kc;
             p.nch = nch;
@@ -287,7 +302,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         } else if (dtype == RS_F32W && use_wino4(i, L.c_in)) {
             // Winograd F(4,3) filter transform U = G g (fp64, rounded once); packed [n_alloc][nch][6][kc]
             L.wino_m = 4;
-            L.plan = plan_static_wino4(L.cp_in, L.c_out);
+            L.plan = plan_static_wino4(L.cp_in, L.c_out, i, m->num_cu);
             const ConvPlan& p = L.plan;
             std::vector<float> wp((size_t)p.n_alloc * p.nch * 6 * p.kc, 0.0f);
             for (int n = 0; n < L.c_out; ++n)

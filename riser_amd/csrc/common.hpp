@@ -69,6 +69,7 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
 int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
                       int layer_index, int num_cu, int check_dead, hipStream_t st, int* bm_out, int* bn_out);
 int conv_wino4_max_bn();
+double conv_wino4_plan_cost(int64_t groups, int n16, int kc, int nch, int num_cu);
 bool conv_wino_can_fuse0(const ConvLayerDev& L, int P_in);
 // fp32 Winograd, layers 0 + 1 of the shipped net as one LDS-free streaming kernel (conv_stream_f32.hip)
 bool conv_stream_f32_ok(const ConvLayerDev& L1, int c0, int P_in1);

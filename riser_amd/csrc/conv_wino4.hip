@@ -415,6 +415,14 @@ const Shape* choose_shape(int64_t groups, int n16, int kc, int nch, int num_cu, 
 
 int conv_wino4_max_bn() { return 256; }
 
+// planner's estimate (SIMD cycles) of one launch with the best tile shape for this chunk size: lets
+// rs_model_create pick the channel chunk (which fixes the weight packing) with the tile shapes it enables in mind
+double conv_wino4_plan_cost(int64_t groups, int n16, int kc, int nch, int num_cu) {
+    double cost = 1e300;
+    choose_shape(groups, n16, kc, nch, num_cu, &cost);
+    return cost;
+}
+
 int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
                       int layer_index, int num_cu, int check_dead, hipStream_t st, int* bm_out, int* bn_out) {
     const ConvPlan& p = L.plan;
