@@ -140,10 +140,11 @@ ConvPlan plan_static_wino4(int cp_in, int c_out, int layer, int num_cu) {
     return p;
 }
 
-// which layers of an RS_F32W model run F(4,3) instead of F(2,3): by default the wide ones (>= 128 input
-// channels: layers 6-11 of the shipped net, where the matrix pipe is the bound: measured -12 ... -16 % on
-// layers 6-9, -10 % on layer 11, -3 % on layer 10; +8 % on layer 4).  RS_WINO4 = comma list of layer indices
-// overrides it when the model is created ("" or "none" = F(2,3) everywhere).
+// which layers of an RS_F32W model run F(4,3) instead of F(2,3): by default the wide ones (>= 96 input
+// channels: layers 5-11 of the shipped net, where the matrix pipe is the bound: measured -8 % on layer 5,
+// -12 ... -20 % on layers 6-10, -5 % on layer 11; +15 % on layer 4, whose tiles are dominated by staging and
+// epilogue).  RS_WINO4 = comma list of layer indices overrides it when the model is created ("none" = F(2,3)
+// everywhere).
 bool use_wino4(int layer, int c_in) {
     if (const char* e = getenv("RS_WINO4")) {
         for (const char* q = e; *q;) {
@@ -155,7 +156,7 @@ bool use_wino4(int layer, int c_in) {
         }
         return false;
     }
-    return c_in >= 128;
+    return c_in >= 96;
 }
 
 struct WsLayout {
