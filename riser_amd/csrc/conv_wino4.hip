@@ -33,6 +33,10 @@
 #include <algorithm>
 #include <utility>
 
+#ifndef RS_UF_AHEAD
+#define RS_UF_AHEAD 1
+#endif
+
 namespace rs {
 namespace {
 
@@ -124,6 +128,10 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
         const bool a_ok = live && a_act && c * KCT + 4 * a_c4 < a.cp_in;
         a_ib = a_ok ? a_tb + (unsigned)((4 * m0g - 1) * a.cp_in + c * KCT) * 4u : kOob;   // row -1 wraps out of range
         b_ib = (live && b_act) ? b_tb + (unsigned)((n0 * a.nch + c) * NC * KCT) * 4u : kOob;
+#ifdef RS_ABL_NOLOAD                                    // timing experiment only: every staging load out of range
+        a_ib = kOob;
+        b_ib = kOob;
+#endif
     };
     auto load_unit = [&](auto U) {
         constexpr int u = decltype(U)::value;
@@ -143,6 +151,10 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
         if constexpr (u < A_PER) {
             bool act = a_act;
             if constexpr ((u + 1) * RPT > A_ROWS) act = act && (a_row + u * RPT < A_ROWS);
+#ifdef RS_ABL_NOLDSW
+            asm volatile("" ::"v"(ra[u].x), "v"(ra[u].y), "v"(ra[u].z), "v"(ra[u].w));
+            act = false;
+#endif
             if (act) {
                 uint2* d = reinterpret_cast<uint2*>(buf + a_st + u * (RPT / 4) * S);
                 d[0] = make_uint2(ra[u].x, ra[u].y);
@@ -152,6 +164,10 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
             constexpr int v = u - A_PER;
             bool act = b_act;
             if constexpr ((v + 1) * NPP > BN) act = act && (b_n + v * NPP < BN);
+#ifdef RS_ABL_NOLDSW
+            asm volatile("" ::"v"(rb[v].x), "v"(rb[v].y), "v"(rb[v].z), "v"(rb[v].w));
+            act = false;
+#endif
             if (act) {
                 uint2* d = reinterpret_cast<uint2*>(buf + b_st + v * NPP * S);
                 d[0] = make_uint2(rb[v].x, rb[v].y);
@@ -244,14 +260,27 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
         constexpr int DIST = 6;                        // slots between a unit's load and its LDS write
         constexpr int SPAN = NSLOTS - DIST;
         float dr[MT][6];                               // raw inputs d0..d5 of the lane's groups (next k-step)
-        float uf[2][NT];                               // weight fragments, double-buffered per slot
+        constexpr int AH = RS_UF_AHEAD;                // slots of look-ahead of the weight-fragment reads
+        float uf[AH + 1][NT];                          // weight fragments, ring over the slots in flight
         float v[MT][NC];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int k = 0; k < 6; ++k) dr[i][k] = Ab[(k & 3) * PL + (i * 16 + (k >> 2)) * S];
+        static_for<AH>([&](auto SL) {
+            constexpr int sl = decltype(SL)::value;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) uf[0][j] = Bb[j * 16 * S];
+            for (int j = 0; j < NT; ++j) uf[sl][j] = Bb[((sl % NC) * BN + j * 16) * S + 4 * (sl / NC)];
+        });
+#ifdef RS_ABL_NOFRAG                                    // timing experiment only: no fragment reads after the item's first
+#pragma unroll
+        for (int j = 0; j < NT; ++j) uf[AH][j] = uf[0][j];
+#define RS_FRAG_A(dst, expr) asm volatile("" : "+v"(dst))
+#define RS_FRAG_B(dst, expr) asm volatile("" : "+v"(dst))
+#else
+#define RS_FRAG_A(dst, expr) dst = (expr)
+#define RS_FRAG_B(dst, expr) dst = (expr)
+#endif
         static_for<NSLOTS>([&](auto SL) {
             constexpr int sl = decltype(SL)::value;
             constexpr int st = sl / NC, comp = sl % NC;
@@ -260,6 +289,9 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
                 for (int i = 0; i < MT; ++i) {                     // V = B^T d
                     const float d0 = dr[i][0], d1 = dr[i][1], d2 = dr[i][2], d3 = dr[i][3], d4 = dr[i][4],
                                 d5 = dr[i][5];
+#ifdef RS_ABL_NOXFORM                                      // timing experiment only
+                    v[i][0] = d0, v[i][1] = d1, v[i][2] = d2, v[i][3] = d3, v[i][4] = d4, v[i][5] = d5;
+#else
                     const float p = fmaf(-4.0f, d2, d4), q = fmaf(-4.0f, d1, d3);
                     const float s2 = d4 - d2, t2 = d3 - d1;
                     v[i][0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
@@ -268,6 +300,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
                     v[i][3] = fmaf(2.0f, t2, s2);
                     v[i][4] = fmaf(-2.0f, t2, s2);
                     v[i][5] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+#endif
                 }
             }
             if constexpr (comp == 1 && st + 1 < KQ) {
@@ -275,21 +308,22 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) dr[i][k] = Ab[(k & 3) * PL + (i * 16 + (k >> 2)) * S + c0];
+                    for (int k = 0; k < 6; ++k) RS_FRAG_A(dr[i][k], Ab[(k & 3) * PL + (i * 16 + (k >> 2)) * S + c0]);
             }
-            if constexpr (sl + 1 < NSLOTS) {
-                constexpr int nst = (sl + 1) / NC, ncomp = (sl + 1) % NC;
+            if constexpr (sl + AH < NSLOTS) {
+                constexpr int nst = (sl + AH) / NC, ncomp = (sl + AH) % NC;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) uf[(sl + 1) & 1][j] = Bb[(ncomp * BN + j * 16) * S + 4 * nst];
+                for (int j = 0; j < NT; ++j)
+                    RS_FRAG_B(uf[(sl + AH) % (AH + 1)][j], Bb[(ncomp * BN + j * 16) * S + 4 * nst]);
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j][comp] =
-                        __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl & 1][j], v[i][comp], acc[i][j][comp], 0, 0, 0);
+                        __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl % (AH + 1)][j], v[i][comp], acc[i][j][comp], 0, 0, 0);
             {
-                constexpr int n_rd = (sl + 1 < NSLOTS ? NT : 0) + ((comp == 1 && st + 1 < KQ) ? 3 * MT : 0);
+                constexpr int n_rd = (sl + AH < NSLOTS ? NT : 0) + ((comp == 1 && st + 1 < KQ) ? 3 * MT : 0);
                 constexpr int n_pair = n_rd < MT * NT ? n_rd : MT * NT;
                 static_for<n_pair>([&](auto) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -347,15 +381,21 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
                         o0[q] = valid_[i][0] ? fmaxf(fmaxf(y0, y1) + bi[q], 0.0f) : 0.0f;
                         o1[q] = valid_[i][1] ? fmaxf(fmaxf(y2, y3) + bi[q], 0.0f) : 0.0f;
                     }
+#ifdef RS_ABL_NOSTORE
+                    asm volatile("" ::"v"(o0[0]), "v"(o0[1]), "v"(o0[2]), "v"(o0[3]), "v"(o1[0]), "v"(o1[1]), "v"(o1[2]), "v"(o1[3]));
+#else
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rs_y, rowoff_[i][0] + coloff, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rs_y, rowoff_[i][1] + coloff, 0, 0);
+#endif
 #pragma unroll
                     for (int q = 0; q < NC; ++q) acc[i][j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
         if (!has_next) break;
+#ifndef RS_ABL_NOBARRIER                                // timing experiment only
         __syncthreads();
+#endif
         buf ^= 1;
         o = no;
         c = nc;

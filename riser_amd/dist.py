@@ -27,7 +27,8 @@ def init(backend: str | None = None, device: torch.device | None = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # RS_DIST_BACKEND=gloo rehearses the multi-rank path with several ranks sharing one GPU
+        backend = backend or os.environ.get("RS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
@@ -58,7 +59,7 @@ def shard_indices(read_ids, rank: int, world_size: int) -> np.ndarray:
 
 def barrier(device=None):
     if dist.is_initialized():
-        if device is not None and device.type == "cuda":
+        if device is not None and device.type == "cuda" and dist.get_backend() == "nccl":
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()
