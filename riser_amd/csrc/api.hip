@@ -143,9 +143,10 @@ ConvPlan plan_static_wino4(int cp_in, int c_out, int layer, int num_cu) {
 // which layers of an RS_F32W model run F(4,3) instead of F(2,3): by default the wide ones (>= 96 input
 // channels: layers 5-11 of the shipped net, where the matrix pipe is the bound: measured -8 % on layer 5,
 // -12 ... -20 % on layers 6-10, -5 % on layer 11; +15 % on layer 4, whose tiles are dominated by staging and
-// epilogue).  RS_WINO4 = comma list of layer indices overrides it when the model is created ("none" = F(2,3)
-// everywhere).
-bool use_wino4(int layer, int c_in) {
+// epilogue), plus narrower layers whose output channels fill the 80-wide F(4,3) tile exactly (16 * 5 | padded
+// C_out: layer 3 of the shipped net, 45 -> 67 channels, measured -8 %).  RS_WINO4 = comma list of layer indices
+// overrides it when the model is created ("none" = F(2,3) everywhere).
+bool use_wino4(int layer, int c_in, int c_out) {
     if (const char* e = getenv("RS_WINO4")) {
         for (const char* q = e; *q;) {
             char* end = nullptr;
@@ -156,7 +157,7 @@ bool use_wino4(int layer, int c_in) {
         }
         return false;
     }
-    return c_in >= 96;
+    return c_in >= 96 || (c_in >= 32 && (round_up(c_out, 16) / 16) % 5 == 0);
 }
 
 struct WsLayout {
@@ -300,7 +301,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             float* dw = nullptr;
             rc = upload(&dw, wp);
             L.d_w = dw;
-        } else if (dtype == RS_F32W && use_wino4(i, L.c_in)) {
+        } else if (dtype == RS_F32W && use_wino4(i, L.c_in, L.c_out)) {
             // Winograd F(4,3) filter transform U = G g (fp64, rounded once); packed [n_alloc][nch][6][kc]
             L.wino_m = 4;
             L.plan = plan_static_wino4(L.cp_in, L.c_out, i, m->num_cu);

@@ -262,7 +262,21 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
         float dr[MT][6];                               // raw inputs d0..d5 of the lane's groups (next k-step)
         constexpr int AH = RS_UF_AHEAD;                // slots of look-ahead of the weight-fragment reads
         float uf[AH + 1][NT];                          // weight fragments, ring over the slots in flight
-        float v[MT][NC];
+        float v[2][MT][NC];                            // transformed inputs: this k-step / the next one
+        auto xform = [&](float (&o)[NC], const float (&d)[6]) {   // V = B^T d
+#ifdef RS_ABL_NOXFORM                                    // timing experiment only
+            o[0] = d[0], o[1] = d[1], o[2] = d[2], o[3] = d[3], o[4] = d[4], o[5] = d[5];
+#else
+            const float p = fmaf(-4.0f, d[2], d[4]), q = fmaf(-4.0f, d[1], d[3]);
+            const float s2 = d[4] - d[2], t2 = d[3] - d[1];
+            o[0] = fmaf(4.0f, d[0], fmaf(-5.0f, d[2], d[4]));
+            o[1] = p + q;
+            o[2] = p - q;
+            o[3] = fmaf(2.0f, t2, s2);
+            o[4] = fmaf(-2.0f, t2, s2);
+            o[5] = fmaf(4.0f, d[1], fmaf(-5.0f, d[3], d[5]));
+#endif
+        };
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -272,6 +286,8 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) uf[sl][j] = Bb[((sl % NC) * BN + j * 16) * S + 4 * (sl / NC)];
         });
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xform(v[0][i], dr[i]);      // first k-step of the item: exposed once
 #ifdef RS_ABL_NOFRAG                                    // timing experiment only: no fragment reads after the item's first
 #pragma unroll
         for (int j = 0; j < NT; ++j) uf[AH][j] = uf[0][j];
@@ -284,32 +300,18 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
         static_for<NSLOTS>([&](auto SL) {
             constexpr int sl = decltype(SL)::value;
             constexpr int st = sl / NC, comp = sl % NC;
-            if constexpr (comp == 0) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {                     // V = B^T d
-                    const float d0 = dr[i][0], d1 = dr[i][1], d2 = dr[i][2], d3 = dr[i][3], d4 = dr[i][4],
-                                d5 = dr[i][5];
-#ifdef RS_ABL_NOXFORM                                      // timing experiment only
-                    v[i][0] = d0, v[i][1] = d1, v[i][2] = d2, v[i][3] = d3, v[i][4] = d4, v[i][5] = d5;
-#else
-                    const float p = fmaf(-4.0f, d2, d4), q = fmaf(-4.0f, d1, d3);
-                    const float s2 = d4 - d2, t2 = d3 - d1;
-                    v[i][0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
-                    v[i][1] = p + q;
-                    v[i][2] = p - q;
-                    v[i][3] = fmaf(2.0f, t2, s2);
-                    v[i][4] = fmaf(-2.0f, t2, s2);
-                    v[i][5] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
-#endif
-                }
-            }
-            if constexpr (comp == 1 && st + 1 < KQ) {
+            // the raw rows of the next k-step are read in slot 1 and transformed in slots 3 (+ 4 for MT = 2),
+            // one VALU group behind each MFMA, so that the transform hides in the MFMA shadow
+            constexpr bool rd_next = comp == 1 && st + 1 < KQ;
+            constexpr bool xf_next = comp >= 3 && comp - 3 < MT && st + 1 < KQ;
+            if constexpr (rd_next) {
                 constexpr int c0 = 4 * (st + 1);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int k = 0; k < 6; ++k) RS_FRAG_A(dr[i][k], Ab[(k & 3) * PL + (i * 16 + (k >> 2)) * S + c0]);
             }
+            if constexpr (xf_next) xform(v[(st + 1) & 1][comp - 3], dr[comp - 3]);
             if constexpr (sl + AH < NSLOTS) {
                 constexpr int nst = (sl + AH) / NC, ncomp = (sl + AH) % NC;
 #pragma unroll
@@ -320,16 +322,23 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j][comp] =
-                        __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl % (AH + 1)][j], v[i][comp], acc[i][j][comp], 0, 0, 0);
+                    acc[i][j][comp] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl % (AH + 1)][j], v[st & 1][i][comp],
+                                                                           acc[i][j][comp], 0, 0, 0);
             {
-                constexpr int n_rd = (sl + AH < NSLOTS ? NT : 0) + ((comp == 1 && st + 1 < KQ) ? 3 * MT : 0);
-                constexpr int n_pair = n_rd < MT * NT ? n_rd : MT * NT;
-                static_for<n_pair>([&](auto) {
+                constexpr int n_mf = MT * NT;
+                constexpr int n_rd = (sl + AH < NSLOTS ? NT : 0) + (rd_next ? 3 * MT : 0);
+                constexpr int n_va = xf_next ? 12 : 0;
+                static_for<n_mf>([&](auto M) {
+                    constexpr int m = decltype(M)::value;
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if constexpr (m < n_rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    constexpr int va0 = n_va * m / n_mf, va1 = n_va * (m + 1) / n_mf;
+                    if constexpr (va1 > va0) __builtin_amdgcn_sched_group_barrier(0x002, va1 - va0, 0);
                 });
-                if constexpr (MT * NT - n_pair > 0) __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - n_pair, 0);
+            }
+            if constexpr (xf_next) {                   // pin the transformed values to this slot (they are pure
+                float(&o)[NC] = v[(st + 1) & 1][comp - 3];   // functions of dr: the compiler would sink them to their use)
+                asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]));
             }
             __builtin_amdgcn_sched_barrier(0);
             static_for<UNITS>([&](auto U) {
@@ -439,7 +448,12 @@ const Shape* choose_shape(int64_t groups, int n16, int kc, int nch, int num_cu, 
         const int64_t rounds = (tiles + num_cu - 1) / num_cu;
         const double slots = 6.0 * kc / 4.0;
         const double staged = ((4.0 * bg + 2) + 6.0 * bnt * 16) * kc * 4.0;
-        const double item = slots * (2.0 * s.mt * s.nt * 32.0 + 6.0 * (s.mt + s.nt)) + 900.0 + 0.06 * staged;
+        // per slot: MFMAs of the two waves of a SIMD, fragment reads, 1/6 of the k-step's input transform (12 VALU
+        // per MT, not hidden behind the MFMAs); per item: fixed cost, staging, and the activation slab's trip from
+        // L2 / Infinity Cache (the weight slab is an L2 hit).  Calibrated on tools/shape_sweep.py (B = 512).
+        const double xslab = (4.0 * bg + 2) * kc * 4.0;
+        const double item = slots * (2.0 * s.mt * s.nt * 32.0 + 6.0 * (s.mt + s.nt) + 12.0 * s.mt) + 900.0 +
+                            0.06 * staged + 0.02 * xslab;
         const double tile = nch * item + 1500.0 + 90.0 * s.mt * s.nt;
         const double cost = (double)rounds * tile;
         if (cost < best_cost) {
