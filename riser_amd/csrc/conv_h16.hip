@@ -50,6 +50,7 @@ struct ConvHArgs {
     int shift_out;
     int n_mtiles, n_ntiles;
     int check_dead;        // 0: every read is long enough that no tile can be all padding (skip the test)
+    int gm, gn, n_mb, q_total;   // tile order: gm x gn rectangles per XCD block (gm == 0: n-major), order indices in all
 };
 
 template <bool F16>
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
 #endif
     };
 
-    const int tiles = a.n_mtiles * a.n_ntiles;
+    const int tiles = a.q_total;
     // ---- tile walk with dead-tile elimination ---------------------------------------------------
     // order index q -> (n tile, row tile), n-major.  Round k of the walk gives workgroup w the
     // order index k*nwg + slot_k(w): within its XCD's contiguous block of the round the slot is
@@ -163,12 +164,26 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
     // lie beyond their read's length has an all-zero output: it is zero-filled here, without
     // loads, MFMAs or pipeline slots, when the walk steps over it.  Such a tile lies inside one
     // read's slot (a tile containing a read start always has valid rows): one uniform look-up.
+    // With gm > 0 (conv_wino4.hip) the contiguous block of order indices an XCD takes per round is a rectangle
+    // of gm row tiles x gn channel tiles: the workgroups sharing an L2 re-use gm activation slabs and gn weight
+    // slabs per panel; rectangles overhanging the tile grid contain invalid indices, skipped in next_live.
     const int P_in_ = 2 * a.P_out;
-    auto tile_origin = [&](int q, int& tm0, int& tn0) {
-        const int nt_ = a.n_ntiles == 1 ? 0 : q / a.n_mtiles;
-        const int mi = q - nt_ * a.n_mtiles;
+    auto tile_origin = [&](int q, int& tm0, int& tn0) -> bool {
+        int mi, nt_;
+        if (a.gm == 0) {
+            nt_ = a.n_ntiles == 1 ? 0 : q / a.n_mtiles;
+            mi = q - nt_ * a.n_mtiles;
+        } else {
+            const int rect = a.gm * a.gn;
+            const int bq = q / rect, w = q - bq * rect;
+            const int ln = w / a.gm, lm = w - ln * a.gm;
+            const int nb = bq / a.n_mb, mb = bq - nb * a.n_mb;
+            mi = mb * a.gm + lm;
+            nt_ = nb * a.gn + ln;
+        }
         tm0 = mi * BM;
         tn0 = nt_ * BN;
+        return mi < a.n_mtiles && nt_ < a.n_ntiles;
     };
     const int nwg_ = gridDim.x;
     // incremental form of: round k -> k*nwg + xcd*blk + ((j + 5k) mod blk)
@@ -187,19 +202,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
     };
     auto next_live = [&]() {                                       // order index of this workgroup's next live tile
         int q = order_index();
-        while (a.check_dead && q < tiles) {
+        while (q < tiles) {
             int tm0, tn0;
-            tile_origin(q, tm0, tn0);
-            const int b = tm0 / P_in_;
-            const int t0 = tm0 - b * P_in_;
-            if (!(t0 + BM <= P_in_ && t0 >= (as_const_len(a.len)[b] >> (a.shift_out - 1)))) break;
-            // zero-fill the BM/2 x BN output tile (16-byte pieces; rows are cp_out wide)
-            const int pieces_per_row = BN / 8;
-            for (int f = threadIdx.x; f < (BM / 2) * pieces_per_row; f += blockDim.x) {
-                const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 8;
-                const int prow = (tm0 >> 1) + rr, col = tn0 + cc;
-                if (2 * prow < a.rows_in && col < a.cp_out)
-                    *reinterpret_cast<uint4*>(a.y + (int64_t)prow * a.cp_out + col) = make_uint4(0u, 0u, 0u, 0u);
+            const bool valid = tile_origin(q, tm0, tn0);
+            if (valid) {
+                if (!a.check_dead) break;
+                const int b = tm0 / P_in_;
+                const int t0 = tm0 - b * P_in_;
+                if (!(t0 + BM <= P_in_ && t0 >= (as_const_len(a.len)[b] >> (a.shift_out - 1)))) break;
+                // zero-fill the BM/2 x BN output tile (16-byte pieces; rows are cp_out wide)
+                const int pieces_per_row = BN / 8;
+                for (int f = threadIdx.x; f < (BM / 2) * pieces_per_row; f += blockDim.x) {
+                    const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 8;
+                    const int prow = (tm0 >> 1) + rr, col = tn0 + cc;
+                    if (2 * prow < a.rows_in && col < a.cp_out)
+                        *reinterpret_cast<uint4*>(a.y + (int64_t)prow * a.cp_out + col) = make_uint4(0u, 0u, 0u, 0u);
+                }
             }
             q = order_index();
         }
@@ -431,6 +449,31 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
                                160 * 1024));
     const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+    // tile order: rectangles of gm x gn tiles per XCD block when the grid fills the chip (see conv_wino4.hip)
+    a.gm = a.gn = a.n_mb = 0;
+    a.q_total = (int)tiles;
+    static const int rect_off = getenv("RS_NO_RECT_ORDER") ? 1 : 0;
+    if (!rect_off && (int64_t)grid == num_cu && num_cu % 8 == 0 && a.n_ntiles > 1) {
+        const int rect = num_cu / 8;
+        const int64_t rounds = (tiles + num_cu - 1) / num_cu;
+        const double x_t = BM, w_t = 3.0 * BN;                   // slab rows per K channel
+        double best = 1e300;
+        for (int gn = 1; gn <= rect; ++gn) {
+            if (rect % gn) continue;
+            const int gm = rect / gn;
+            const int64_t n_mb = (a.n_mtiles + gm - 1) / gm, n_nb = (a.n_ntiles + gn - 1) / gn;
+            const int64_t q_total = n_mb * n_nb * rect;
+            if ((q_total + num_cu - 1) / num_cu != rounds) continue;             // never pay an extra round
+            const double fetch = (double)(n_mb * n_nb) * (gm * x_t + gn * w_t);
+            if (fetch < best) {
+                best = fetch;
+                a.gm = gm;
+                a.gn = gn;
+                a.n_mb = (int)n_mb;
+                a.q_total = (int)q_total;
+            }
+        }
+    }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes(*s), st, a);
     RS_HIP(hipGetLastError());
     if (bm_out) *bm_out = BM;

@@ -69,6 +69,7 @@ struct Wino4Args {
     int shift_out;
     int n_mtiles, n_ntiles;
     int check_dead;
+    int gm, gn, n_mb, q_total;   // tile order: gm x gn rectangles per XCD block (gm == 0: n-major), order indices in all
 };
 
 template <int WM, int WN, int MT, int NT, int KCT>
@@ -177,12 +178,28 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
     };
 
     // ---- tile walk (conv_wino.hip), tiles counted in groups ----------------------------------------------
-    const int tiles = a.n_mtiles * a.n_ntiles;
-    auto tile_origin = [&](int q, int& tm0, int& tn0) {
-        const int nt_ = a.n_ntiles == 1 ? 0 : q / a.n_mtiles;
-        const int mi = q - nt_ * a.n_mtiles;
+    // Order index q -> tile.  A round hands XCD x (= blockIdx & 7) the contiguous block of nwg / 8 indices
+    // x * blk ...: with gm > 0 such a block is a RECTANGLE of gm row tiles x gn channel tiles, so the workgroups
+    // that share an L2 re-use gm activation slabs and gn weight slabs per K chunk instead of streaming nwg / 8
+    // different activation slabs against one weight slab (host: launch_conv_wino4 picks gm x gn by the bytes the
+    // XCD pulls over the fabric).  Rectangles overhanging the tile grid contain invalid indices, skipped here.
+    const int tiles = a.q_total;
+    auto tile_origin = [&](int q, int& tm0, int& tn0) -> bool {
+        int mi, nt_;
+        if (a.gm == 0) {
+            nt_ = a.n_ntiles == 1 ? 0 : q / a.n_mtiles;
+            mi = q - nt_ * a.n_mtiles;
+        } else {
+            const int rect = a.gm * a.gn;
+            const int bq = q / rect, w = q - bq * rect;
+            const int ln = w / a.gm, lm = w - ln * a.gm;
+            const int nb = bq / a.n_mb, mb = bq - nb * a.n_mb;
+            mi = mb * a.gm + lm;
+            nt_ = nb * a.gn + ln;
+        }
         tm0 = mi * BG;
         tn0 = nt_ * BN;
+        return mi < a.n_mtiles && nt_ < a.n_ntiles;
     };
     const int nwg_ = gridDim.x;
     const int blk_ = (nwg_ & 7) == 0 ? nwg_ >> 3 : nwg_;
@@ -200,19 +217,22 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
     };
     auto next_live = [&]() {
         int q = order_index();
-        while (a.check_dead && q < tiles) {
+        while (q < tiles) {
             int tm0, tn0;
-            tile_origin(q, tm0, tn0);
-            const int pr0 = 2 * tm0;                                  // first pooled row of the tile
-            const int b = pr0 / a.P_out;
-            const int t0 = pr0 - b * a.P_out;
-            if (!(b < a.rows_out / a.P_out && t0 + 2 * BG <= a.P_out && t0 >= (clen[b] >> a.shift_out))) break;
-            const int pieces_per_row = BN / 4;
-            for (int f = threadIdx.x; f < 2 * BG * pieces_per_row; f += blockDim.x) {
-                const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 4;
-                const int prow = pr0 + rr, col = tn0 + cc;
-                if (prow < a.rows_out && col < a.cp_out)
-                    *reinterpret_cast<float4*>(a.y + (int64_t)prow * a.cp_out + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool valid = tile_origin(q, tm0, tn0);
+            if (valid) {
+                if (!a.check_dead) break;
+                const int pr0 = 2 * tm0;                                  // first pooled row of the tile
+                const int b = pr0 / a.P_out;
+                const int t0 = pr0 - b * a.P_out;
+                if (!(b < a.rows_out / a.P_out && t0 + 2 * BG <= a.P_out && t0 >= (clen[b] >> a.shift_out))) break;
+                const int pieces_per_row = BN / 4;
+                for (int f = threadIdx.x; f < 2 * BG * pieces_per_row; f += blockDim.x) {
+                    const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 4;
+                    const int prow = pr0 + rr, col = tn0 + cc;
+                    if (prow < a.rows_out && col < a.cp_out)
+                        *reinterpret_cast<float4*>(a.y + (int64_t)prow * a.cp_out + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             q = order_index();
         }
@@ -532,12 +552,37 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
     a.n_mtiles = (a.n_groups + BG - 1) / BG;
     a.n_ntiles = (n16 * 16 + BN - 1) / BN;
     a.check_dead = check_dead;
+    const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+    // tile order: rectangles of gm x gn tiles per XCD block when the grid fills the chip (see the kernel)
+    a.gm = a.gn = a.n_mb = 0;
+    a.q_total = (int)tiles;
+    static const int rect_off = getenv("RS_NO_RECT_ORDER") ? 1 : 0;
+    if (!rect_off && (int64_t)grid == num_cu && num_cu % 8 == 0 && a.n_ntiles > 1) {
+        const int rect = num_cu / 8;
+        const int64_t rounds = (tiles + num_cu - 1) / num_cu;
+        const double x_t = 4.0 * BG, w_t = 6.0 * BN;            // slab rows per K channel (bytes / (4 * cp_in))
+        double best = 1e300;
+        for (int gn = 1; gn <= rect; ++gn) {
+            if (rect % gn) continue;
+            const int gm = rect / gn;
+            const int64_t n_mb = (a.n_mtiles + gm - 1) / gm, n_nb = (a.n_ntiles + gn - 1) / gn;
+            const int64_t q_total = n_mb * n_nb * rect;
+            if ((q_total + num_cu - 1) / num_cu != rounds) continue;             // never pay an extra round
+            const double fetch = (double)(n_mb * n_nb) * (gm * x_t + gn * w_t);
+            if (fetch < best) {
+                best = fetch;
+                a.gm = gm;
+                a.gn = gn;
+                a.n_mb = (int)n_mb;
+                a.q_total = (int)q_total;
+            }
+        }
+    }
     const size_t lds = lds_bytes(*s, p.kc);
     KernelFn fn = s->fn[p.kc == 16 ? 0 : 1];
     RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
-    const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
-    const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, a);
     RS_HIP(hipGetLastError());
     if (bm_out) *bm_out = 4 * BG;           // reported in conv rows, like the other kernels
