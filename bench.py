@@ -158,7 +158,10 @@ def main():
                           "tflops": round(flops[i] * B / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
                           "tile": [info[i]["bm"], info[i]["bn"], info[i]["kc"]]})
     executed_tf = executed_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    kname = {"f32w": "conv_wino_kernel / conv_wino4_kernel (Winograd F(2,3) layers 1-4, F(4,3) layers 5-11, f32-input MFMA)", "f32": "conv_f32_kernel (direct, f32-input MFMA)"}.get(
+    f23 = [str(i) for i in range(1, model.n_layers) if info[i]["gemm_row_div"] == 2]
+    f43 = [str(i) for i in range(1, model.n_layers) if info[i]["gemm_row_div"] == 4]
+    kname = {"f32w": "conv_stream_f32_kernel / conv_wino_kernel / conv_wino4_kernel (Winograd F(2,3) layers %s, F(4,3) layers %s, "
+                     "f32-input MFMA)" % (",".join(f23), ",".join(f43)), "f32": "conv_f32_kernel (direct, f32-input MFMA)"}.get(
         lib_dtype, "conv_h16_kernel (%s MFMA)" % lib_dtype)
     roofline = {"bound": "mfma", "kernel": kname + ", 11 launches/step, layers 1-11",
                 "achieved": round(achieved_tf, 2), "peak": peak, "unit": "TFLOP/s",

@@ -22,16 +22,8 @@
 #include <string.h>
 
 #include <algorithm>
-#include <utility>
 
-#ifndef RS_H16_SPREAD
-#define RS_H16_SPREAD 1
-#endif
-#ifndef RS_H16_MIN_BLOCKS
-#define RS_H16_MIN_BLOCKS 1
-#endif
-
-// Diagnostic build only (-DRS_ITEM_STAMPS): per-phase s_memtime sums of the item loop (conv_f32.hip)
+// Diagnostic build only (-DRS_ITEM_STAMPS, tools/h16_stamps.py): per-phase s_memtime sums of the item loop
 #ifdef RS_ITEM_STAMPS
 #include <vector>
 #define RS_STAMP(k)                                                                  \
@@ -54,16 +46,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-template <int... I, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
-}
 
 constexpr int kThreads = 512;
 
@@ -75,7 +57,6 @@ struct ConvHArgs {
     const int32_t* len;
     const unsigned short* zero;
     unsigned x_bytes, w_bytes;   // sizes of the activation buffer and of the packed weights (< 2^31)
-    unsigned y_bytes, y_row_bytes, len_bytes, bias_bytes;
     int rows_in;
     int P_out;
     float inv_P_out;
@@ -110,7 +91,7 @@ __device__ __forceinline__ unsigned short cvt16(float f) {
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 
 template <int WM, int WN, int MT, int NT, bool F16>
-__global__ __launch_bounds__(kThreads, RS_H16_MIN_BLOCKS) void conv_h16_kernel(const ConvHArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a) {
     static_assert(WM * WN == 8, "8 waves per workgroup");
     constexpr int BM = WM * 16 * MT;
     constexpr int BN = WN * 16 * NT;
@@ -155,12 +136,6 @@ __global__ __launch_bounds__(kThreads, RS_H16_MIN_BLOCKS) void conv_h16_kernel(c
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, a.w_bytes, 0x00020000);
 
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_len =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.len), 0, a.len_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_bias =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias_bytes, 0x00020000);
-
     u32x4 ra[A_PER], rb[B_PER];
     auto load_item = [&](int m0, int n0, int p, bool live) {
         bool a_ok = live && p * 32 + 8 * a_c < a.cp_in;
@@ -179,40 +154,6 @@ __global__ __launch_bounds__(kThreads, RS_H16_MIN_BLOCKS) void conv_h16_kernel(c
         const unsigned w_ib = live ? (unsigned)((p * 3 * a.n_alloc + n0) * 32) * 2u : kOob;
 #pragma unroll
         for (int u = 0; u < B_PER; ++u) rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_ib + b_g[u], 0, 0);
-    };
-    // unit-wise forms (main loop): offsets of the item once, then one load / one LDS write per call
-    unsigned a_ib_ = kOob, w_ib_ = kOob;
-    auto item_offsets = [&](int m0, int n0, int p, bool live) {
-        bool a_ok = live && p * 32 + 8 * a_c < a.cp_in;
-#ifdef RS_ABL_NOLOAD
-        a_ok = false;
-        live = false;
-#endif
-        a_ib_ = a_ok ? a_tb + (unsigned)((m0 - 1) * a.cp_in + p * 32) * 2u : kOob;
-        w_ib_ = live ? (unsigned)((p * 3 * a.n_alloc + n0) * 32) * 2u : kOob;
-    };
-    auto load_unit = [&](auto U) {
-        constexpr int u = decltype(U)::value;
-        if constexpr (u < A_PER) {
-            unsigned off = a_ib_ + (unsigned)u * a_step;
-            if constexpr ((u + 1) * 128 > BM + 2) off = (a_row0 + u * 128 < BM + 2) ? off : kOob;
-            ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
-        } else {
-            rb[u - A_PER] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_ib_ + b_g[u - A_PER], 0, 0);
-        }
-    };
-    auto store_unit = [&](auto U, unsigned char* buf) {
-        constexpr int u = decltype(U)::value;
-#ifdef RS_ABL_NOLDSW
-        if constexpr (u < A_PER) asm volatile("" ::"v"(ra[u]));
-        else asm volatile("" ::"v"(rb[u - A_PER]));
-#else
-        if constexpr (u < A_PER) {
-            if (a_row0 + u * 128 < BM + 2) *reinterpret_cast<u32x4*>(buf + a_lds0 + u * 128 * 64) = ra[u];
-        } else {
-            if (b_g[u - A_PER] != kOob) *reinterpret_cast<u32x4*>(buf + b_lds[u - A_PER]) = rb[u - A_PER];
-        }
-#endif
     };
     auto store_item = [&](unsigned char* buf) {
 #ifdef RS_ABL_NOLDSW
@@ -339,44 +280,6 @@ __global__ __launch_bounds__(kThreads, RS_H16_MIN_BLOCKS) void conv_h16_kernel(c
         const bool has_next = no < tiles;
         int nm0 = m0, nn0 = n0;
         if (has_next && np == 0) tile_origin(no, nm0, nn0);
-#if RS_H16_SPREAD
-        // Staging spread over the MFMA stream (as in conv_wino.hip): the item is cut into 3 * MT slots of NT MFMAs;
-        // the next item's global loads issue one unit at a time behind the slots of the first half, its LDS writes
-        // behind the slots of the second half, so the L1 address path and the LDS write port work in the shadow
-        // of the matrix pipe instead of in two bursts around the barrier (stamped: 856 + 1012 of 5300 cycles per
-        // item on layer 9).
-        item_offsets(nm0, nn0, np, has_next);
-        const unsigned char* cur = lds + buf * BUF_BYTES;
-        unsigned char* nxt = lds + (buf ^ 1) * BUF_BYTES;
-        RS_STAMP(0);
-        constexpr int UNITS = A_PER + B_PER;
-        constexpr int NSL = 3 * MT, HALF = NSL / 2;
-        u32x4 af[2], bf[NT];                               // A fragment of this slot / the next one, B fragments of the tap
-        af[0] = *reinterpret_cast<const u32x4*>(cur + a_rd[0]);
-        static_for<NSL>([&](auto SL) {
-            constexpr int sl = decltype(SL)::value;
-            constexpr int tap = sl / MT, i = sl % MT;
-            if constexpr (i == 0) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    bf[j] = *reinterpret_cast<const u32x4*>(cur + b_rd + (tap * BN + j * 16) * 64);
-            }
-            if constexpr (sl + 1 < NSL)
-                af[(sl + 1) & 1] =
-                    *reinterpret_cast<const u32x4*>(cur + a_rd[(sl + 1) / MT] + ((sl + 1) % MT) * 16 * 64);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(bf[j], af[sl & 1], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<UNITS>([&](auto U) {
-                constexpr int u = decltype(U)::value;
-                if constexpr ((u * HALF) / UNITS == sl) load_unit(U);
-                if constexpr ((u * (NSL - HALF)) / UNITS + HALF == sl) {
-                    if (has_next) store_unit(U, nxt);
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-#else
         load_item(nm0, nn0, np, has_next);
         __builtin_amdgcn_sched_barrier(0);
         RS_STAMP(0);                                               // bookkeeping + prefetch issue
@@ -393,77 +296,59 @@ __global__ __launch_bounds__(kThreads, RS_H16_MIN_BLOCKS) void conv_h16_kernel(c
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(bf[j], af[i], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i], bf[j], acc[i][j]);
         }
-#endif
 
         RS_STAMP(1);                                               // fragment reads + MFMAs
         if (p == a.n_panels - 1) {
-            // ---- epilogue: MaxPool(2,2) + bias + ReLU + length mask in registers, 8-byte stores ----------
-            // The MFMAs take the WEIGHT fragment as their first operand, so a lane's accumulator holds four
-            // consecutive channels (4g .. 4g+3 of sub-tile j) of ONE position (lane & 15 of sub-tile i): the
-            // pooling partner is the neighbouring lane (DPP quad_perm [1,0,3,2]), after which both lanes of a pair
-            // hold the pooled row - the even lane stores sub-tile j's four channels, the odd lane sub-tile j+1's:
-            // every lane issues one 8-byte buffer store per (i, pair of j); rows past the buffer, channels past
-            // cp_out and the odd lanes of an unpaired last j resolve to an out-of-range offset (dropped).
+            // ---- epilogue: bias + ReLU + MaxPool(2,2) in registers, masked store ------------------
+            float bias[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bias[j] = a.bias[n0 + (wn * NT + j) * 16 + r];
             const int pr0 = m0 >> 1;
             const int b0 = pr0 / a.P_out;
             const int p0 = pr0 - b0 * a.P_out;
-            const bool odd = (r & 1) != 0;
-            unsigned rowoff_[MT];
-            bool valid_[MT];
+            int prow_[MT][2], lim_[MT][2], pin_[MT][2];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int row = m0 + (wm * MT + i) * 16 + r;               // conv row of this lane
-                const int prow = row >> 1;
-                const int t = p0 + (prow - pr0);
-                const int e = (int)(((float)t + 0.5f) * a.inv_P_out);      // t < P_out + BM / 2 < 2^16: exact
-                const int pin = t - e * a.P_out;
-                const unsigned lv = __builtin_amdgcn_raw_buffer_load_b32(rs_len, (unsigned)(b0 + e) * 4u, 0, 0);
-                valid_[i] = pin < (int)(lv >> a.shift_out);                // reads past the batch: length 0
-                rowoff_[i] = row < a.rows_in ? (unsigned)prow * a.y_row_bytes : kOob;   // (never ADD two sentinels)
-            }
+                const int row = m0 + (wm * MT + i) * 16 + 4 * g;
 #pragma unroll
-            for (int j0 = 0; j0 < NT; j0 += 2) {
-                const bool has_pair = j0 + 1 < NT;
-                const int jj = j0 + ((odd && has_pair) ? 1 : 0);
-                const int col = n0 + (wn * NT + jj) * 16 + 4 * g;
-                const unsigned coloff = (col < a.cp_out && (has_pair || !odd)) ? (unsigned)col * 2u : kOob;
-                const f32x4 bi = __builtin_bit_cast(
-                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, (unsigned)col * 4u, 0, 0));
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    unsigned short h[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float xe = acc[i][j0][k];
-                        const float me = fmaxf(xe, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
-                                                       __builtin_bit_cast(int, xe), 0xB1, 0xF, 0xF, true)));
-                        float m = me;
-                        if (j0 + 1 < NT) {
-                            const float xo = acc[i][j0 + 1 < NT ? j0 + 1 : j0][k];
-                            const float mo = fmaxf(xo, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
-                                                           __builtin_bit_cast(int, xo), 0xB1, 0xF, 0xF, true)));
-                            m = odd ? mo : me;
-                        }
-                        const float v = fmaxf(m + bi[k], 0.0f);
-                        h[k] = valid_[i] ? cvt16<F16>(v) : (unsigned short)0;
-                    }
-                    u32x2 o;
-                    o.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
-                    o.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
-#ifdef RS_ABL_NOSTORE
-                    asm volatile("" ::"v"(o.x), "v"(o.y));
-#else
-                    __builtin_amdgcn_raw_buffer_store_b64(
-                        o, rs_y, (rowoff_[i] | coloff) & kOob ? kOob : rowoff_[i] + coloff, 0, 0);
-#endif
+                for (int h = 0; h < 2; ++h) {
+                    const int prow = (row >> 1) + h;
+                    const bool in = 2 * prow < a.rows_in;
+                    const int t = p0 + (prow - pr0);
+                    const int e = (int)(((float)t + 0.5f) * a.inv_P_out);
+                    const int b = in ? b0 + e : 0;
+                    prow_[i][h] = in ? prow : -1;
+                    pin_[i][h] = t - e * a.P_out;
+                    lim_[i][h] = a.len[b];
                 }
             }
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int prow = prow_[i][h];
+                    if (prow >= 0) {
+                        const bool valid = pin_[i][h] < (lim_[i][h] >> a.shift_out);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const int col = n0 + (wn * NT + j) * 16 + r;
+                            if (col < a.cp_out) {
+                                const float v =
+                                    fmaxf(fmaxf(acc[i][j][2 * h], acc[i][j][2 * h + 1]) + bias[j], 0.0f);
+#ifdef RS_ABL_NOSTORE
+                                asm volatile("" ::"v"(v));
+#else
+                                a.y[(int64_t)prow * a.cp_out + col] = valid ? cvt16<F16>(v) : (unsigned short)0;
+#endif
+                            }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
         RS_STAMP(2);                                               // epilogue (on a tile's last panel)
 #ifdef RS_ITEM_STAMPS
@@ -476,9 +361,7 @@ __global__ __launch_bounds__(kThreads, RS_H16_MIN_BLOCKS) void conv_h16_kernel(c
         }
 #endif
         if (!has_next) break;
-#if !RS_H16_SPREAD
         store_item(lds + (buf ^ 1) * BUF_BYTES);
-#endif
         RS_STAMP(3);                                               // vmcnt wait + LDS store
 #ifndef RS_ABL_NOBARRIER
         __syncthreads();
@@ -586,10 +469,6 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
     }
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
-    a.y_bytes = (unsigned)(rows64 / 2 * L.cp_out * 2);
-    a.y_row_bytes = (unsigned)L.cp_out * 2u;
-    a.len_bytes = (unsigned)B * 4u;
-    a.bias_bytes = (unsigned)L.plan.n_alloc * 4u;
     a.rows_in = (int)rows64;
     a.P_out = P_in / 2;
     a.inv_P_out = 1.0f / (float)a.P_out;
