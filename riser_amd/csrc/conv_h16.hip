@@ -88,17 +88,28 @@ __device__ __forceinline__ unsigned short cvt16(float f) {
         return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 
-__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
+// KS = 16-byte k-steps per tap = panel width / 32 channels.  64-byte rows (KS = 1): slot ^ 2 * ((row >> 2) & 1);
+// 128-byte rows (KS = 2): slot ^ (row & 7) - both found by search over the ds_read_b128 lane groups of gfx950
+// ({0-3,12-15,20-27}, ...) to be conflict-free for all three tap shifts (and both k-steps) at once.
+template <int KS>
+__device__ __forceinline__ int swz(int row) {
+    return KS == 1 ? ((row >> 2) & 1) << 1 : (row & 7);
+}
 
-template <int WM, int WN, int MT, int NT, bool F16>
+template <int WM, int WN, int MT, int NT, bool F16, int KS>
 __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a) {
     static_assert(WM * WN == 8, "8 waves per workgroup");
+    static_assert(KS == 1 || KS == 2, "panels of 32 or 64 channels");
     constexpr int BM = WM * 16 * MT;
     constexpr int BN = WN * 16 * NT;
-    constexpr int A_BYTES = (BM + 2) * 64;
-    constexpr int BUF_BYTES = A_BYTES + 3 * BN * 64;
-    constexpr int A_UNITS = (BM + 2) * 4;
-    constexpr int B_UNITS = 3 * BN * 4;
+    constexpr int ROWB = 64 * KS;                       // LDS row: one panel of one position / output channel
+    constexpr int SLOTS = 4 * KS;                       // 16-byte slots per row
+    constexpr int RPP = kThreads / SLOTS;               // slab rows per staging pass
+    constexpr int PANEL = 32 * KS;
+    constexpr int A_BYTES = (BM + 2) * ROWB;
+    constexpr int BUF_BYTES = A_BYTES + 3 * BN * ROWB;
+    constexpr int A_UNITS = (BM + 2) * SLOTS;
+    constexpr int B_UNITS = 3 * BN * SLOTS;
     constexpr int A_PER = (A_UNITS + kThreads - 1) / kThreads;
     constexpr int B_PER = (B_UNITS + kThreads - 1) / kThreads;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -117,19 +128,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
     // resolve to an out-of-range offset (hardware returns zeros): one add per unit, no 64-bit address
     // arithmetic, no predicates, no zero page.
     constexpr unsigned kOob = 0x80000000u;
-    const int a_row0 = tid >> 2, a_c = tid & 3;
-    const int a_lds0 = a_row0 * 64 + ((a_c ^ swz(a_row0)) << 4);               // + u * 128 * 64
+    const int a_row0 = tid / SLOTS, a_c = tid % SLOTS;
+    const int a_lds0 = a_row0 * ROWB + ((a_c ^ swz<KS>(a_row0)) << 4);         // + u * RPP * ROWB (RPP % 8 == 0)
     const unsigned a_tb = ((unsigned)a_row0 * a.cp_in + 8 * a_c) * 2u;         // + item base + u * a_step
-    const unsigned a_step = (unsigned)(128 * a.cp_in) * 2u;
+    const unsigned a_step = (unsigned)(RPP * a.cp_in) * 2u;
     int b_lds[B_PER];
     unsigned b_g[B_PER];                                                        // byte offset inside one panel's weights
 #pragma unroll
     for (int u = 0; u < B_PER; ++u) {
         const int f = tid + u * kThreads;
-        const int tap = f / (BN * 4), rem = f - tap * (BN * 4);
-        const int n = rem >> 2, c = rem & 3;
-        b_lds[u] = A_BYTES + (tap * BN + n) * 64 + ((c ^ swz(n)) << 4);
-        b_g[u] = f < B_UNITS ? (unsigned)((tap * a.n_alloc + n) * 32 + 8 * c) * 2u : kOob;
+        const int tap = f / (BN * SLOTS), rem = f - tap * (BN * SLOTS);
+        const int n = rem / SLOTS, c = rem % SLOTS;
+        b_lds[u] = A_BYTES + (tap * BN + n) * ROWB + ((c ^ swz<KS>(n)) << 4);
+        // weights stay packed in 32-channel panels [panel][tap][n_alloc][32]: slot c of a 64-channel row is slot c & 3 of
+        // panel 2p + (c >> 2); the second half of an odd last panel lies past the buffer (hardware zeros)
+        b_g[u] = f < B_UNITS ? (unsigned)((((c >> 2) * 3 + tap) * a.n_alloc + n) * 32 + 8 * (c & 3)) * 2u : kOob;
     }
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
@@ -138,20 +151,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
 
     u32x4 ra[A_PER], rb[B_PER];
     auto load_item = [&](int m0, int n0, int p, bool live) {
-        bool a_ok = live && p * 32 + 8 * a_c < a.cp_in;
+        bool a_ok = live && p * PANEL + 8 * a_c < a.cp_in;
 #ifdef RS_ABL_NOLOAD
         a_ok = false;
         live = false;
 #endif
         // row -1 (m0 == 0, slab row 0) wraps to an offset >= 2^31: out of range, zeros
-        const unsigned a_ib = a_ok ? a_tb + (unsigned)((m0 - 1) * a.cp_in + p * 32) * 2u : kOob;
+        const unsigned a_ib = a_ok ? a_tb + (unsigned)((m0 - 1) * a.cp_in + p * PANEL) * 2u : kOob;
 #pragma unroll
         for (int u = 0; u < A_PER; ++u) {
             unsigned off = a_ib + (unsigned)u * a_step;
-            if ((u + 1) * 128 > BM + 2) off = (a_row0 + u * 128 < BM + 2) ? off : kOob;
+            if ((u + 1) * RPP > BM + 2) off = (a_row0 + u * RPP < BM + 2) ? off : kOob;
             ra[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
         }
-        const unsigned w_ib = live ? (unsigned)((p * 3 * a.n_alloc + n0) * 32) * 2u : kOob;
+        const unsigned w_ib = live ? (unsigned)((p * KS * 3 * a.n_alloc + n0) * 32) * 2u : kOob;
 #pragma unroll
         for (int u = 0; u < B_PER; ++u) rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_ib + b_g[u], 0, 0);
     };
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
 #else
 #pragma unroll
         for (int u = 0; u < A_PER; ++u)
-            if (a_row0 + u * 128 < BM + 2) *reinterpret_cast<u32x4*>(buf + a_lds0 + u * 128 * 64) = ra[u];
+            if (a_row0 + u * RPP < BM + 2) *reinterpret_cast<u32x4*>(buf + a_lds0 + u * RPP * ROWB) = ra[u];
 #pragma unroll
         for (int u = 0; u < B_PER; ++u)
             if (b_g[u] != kOob) *reinterpret_cast<u32x4*>(buf + b_lds[u]) = rb[u];
@@ -258,13 +271,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
     int buf = 0;
 
     // fragment read addresses: slab row of lane = wm*16*MT + i*16 + r + tap (A), wn*16*NT + j*16 + r (B)
-    int a_rd[3];
+    int a_rd[3][KS], b_rd[KS];
 #pragma unroll
-    for (int tap = 0; tap < 3; ++tap) {
-        const int R = wm * 16 * MT + r + tap;
-        a_rd[tap] = R * 64 + ((g ^ swz(R)) << 4);
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int R = wm * 16 * MT + r + tap;
+            a_rd[tap][ks] = R * ROWB + (((4 * ks + g) ^ swz<KS>(R)) << 4);
+        }
+        b_rd[ks] = A_BYTES + (wn * 16 * NT + r) * ROWB + (((4 * ks + g) ^ swz<KS>(r)) << 4);
     }
-    const int b_rd = A_BYTES + (wn * 16 * NT + r) * 64 + ((g ^ swz(r)) << 4);
 
 #ifdef RS_ITEM_STAMPS
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
@@ -287,16 +303,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
         const unsigned char* cur = lds + buf * BUF_BYTES;
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
-            u32x4 af[MT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4*>(cur + a_rd[tap] + i * 16 * 64);
+            for (int ks = 0; ks < KS; ++ks) {
+                u32x4 af[MT], bf[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                bf[j] = *reinterpret_cast<const u32x4*>(cur + b_rd + (tap * BN + j * 16) * 64);
+                for (int i = 0; i < MT; ++i)
+                    af[i] = *reinterpret_cast<const u32x4*>(cur + a_rd[tap][ks] + i * 16 * ROWB);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int j = 0; j < NT; ++j)
+                    bf[j] = *reinterpret_cast<const u32x4*>(cur + b_rd[ks] + (tap * BN + j * 16) * ROWB);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i], bf[j], acc[i][j]);
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i], bf[j], acc[i][j]);
+            }
         }
 
         RS_STAMP(1);                                               // fragment reads + MFMAs
@@ -379,43 +399,53 @@ using KernelFn = void (*)(const ConvHArgs);
 
 struct Shape {
     int wm, wn, mt, nt;
-    KernelFn fn[2];        // bf16, f16
+    KernelFn fn[2][2];     // [panel of 32 / 64 channels][bf16, f16]; null where the 64-channel slabs do not fit in LDS
 };
 
-#define RS_SHAPE(WM, WN, MT, NT) \
-    {WM, WN, MT, NT, {conv_h16_kernel<WM, WN, MT, NT, false>, conv_h16_kernel<WM, WN, MT, NT, true>}}
+constexpr size_t lds_bytes_of(int bm, int bn, int ks) { return 2 * (size_t)((bm + 2) + 3 * bn) * 64 * ks; }
+
+template <int WM, int WN, int MT, int NT, bool F16>
+constexpr KernelFn wide_panel_kernel() {
+    if constexpr (lds_bytes_of(WM * 16 * MT, WN * 16 * NT, 2) <= 160 * 1024)
+        return conv_h16_kernel<WM, WN, MT, NT, F16, 2>;
+    else
+        return nullptr;
+}
+
+#define RS_SHAPE(WM, WN, MT, NT)                                                                              \
+    {WM, WN, MT, NT,                                                                                          \
+     {{conv_h16_kernel<WM, WN, MT, NT, false, 1>, conv_h16_kernel<WM, WN, MT, NT, true, 1>},                 \
+      {wide_panel_kernel<WM, WN, MT, NT, false>(), wide_panel_kernel<WM, WN, MT, NT, true>()}}}
 const Shape kShapes[] = {
     RS_SHAPE(8, 1, 4, 2), RS_SHAPE(8, 1, 4, 3), RS_SHAPE(8, 1, 2, 5), RS_SHAPE(8, 1, 4, 5), RS_SHAPE(8, 1, 2, 7),
     RS_SHAPE(8, 1, 4, 7), RS_SHAPE(4, 2, 4, 2), RS_SHAPE(4, 2, 4, 3), RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 4, 4),
     RS_SHAPE(4, 2, 4, 5), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 4, 7), RS_SHAPE(4, 2, 2, 8),
     RS_SHAPE(2, 4, 2, 2), RS_SHAPE(2, 4, 2, 4), RS_SHAPE(2, 4, 1, 4),
+    RS_SHAPE(4, 2, 2, 5), RS_SHAPE(2, 4, 4, 2), RS_SHAPE(8, 1, 2, 6), RS_SHAPE(4, 2, 2, 3),   // for the 64-channel panels
 };
-constexpr int kNumAutoShapes = 18;
+constexpr int kNumAutoShapes = 18;     // 32-channel panels choose among the first 18
 #undef RS_SHAPE
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
-size_t lds_bytes(const Shape& s) {
-    const int bm = s.wm * 16 * s.mt, bn = s.wn * 16 * s.nt;
-    return 2 * (size_t)((bm + 2) + 3 * bn) * 64;
-}
+size_t lds_bytes(const Shape& s, int ks) { return lds_bytes_of(s.wm * 16 * s.mt, s.wn * 16 * s.nt, ks); }
 
 // cost model in SIMD cycles: MFMA issue (2 waves share a SIMD, 16 cycles per 16x16x32), LDS
 // fragment traffic (256 B/clk per CU shared by 8 waves), L2->LDS staging per item, fixed
 // per-item and per-tile overheads
-const Shape* choose_shape(int64_t rows, int n16, int n_panels, int num_cu) {
+const Shape* choose_shape(int64_t rows, int n16, int n_panels, int num_cu, int ks) {
     const Shape* best = nullptr;
     double best_cost = 1e300;
-    for (int k = 0; k < kNumAutoShapes; ++k) {
+    for (int k = 0; k < (ks == 1 ? kNumAutoShapes : kNumShapes); ++k) {
         const Shape& s = kShapes[k];
-        if (lds_bytes(s) > 160 * 1024) continue;
+        if (lds_bytes(s, ks) > 160 * 1024 || !s.fn[ks - 1][0]) continue;
         const int bm = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
         const int64_t mtiles = (rows + bm - 1) / bm;
         const int64_t ntiles = (n16 + bnt - 1) / bnt;
         const int64_t tiles = mtiles * ntiles;
         const int64_t rounds = (tiles + num_cu - 1) / num_cu;
-        const double mfma = 3.0 * 2.0 * s.mt * s.nt * 16.0;
-        const double ldsr = 3.0 * 8.0 * (s.mt + s.nt) * 1024.0 / 256.0 * 1.3;
-        const double stage = ((bm + 2) + 3.0 * bnt * 16) * 64.0 / 24.0;      // ~24 B/clk/CU from L2
+        const double mfma = ks * 3.0 * 2.0 * s.mt * s.nt * 16.0;
+        const double ldsr = ks * 3.0 * 8.0 * (s.mt + s.nt) * 1024.0 / 256.0 * 1.3;
+        const double stage = ks * ((bm + 2) + 3.0 * bnt * 16) * 64.0 / 24.0;      // ~24 B/clk/CU from L2
         const double item = std::max(std::max(mfma, ldsr), stage) + 500.0;
         const double tile = n_panels * item + 2000.0 + 30.0 * s.mt * s.nt;
         const double cost = (double)rounds * tile;
@@ -425,6 +455,17 @@ const Shape* choose_shape(int64_t rows, int n16, int n_panels, int num_cu) {
         }
     }
     return best;
+}
+
+// panel width of a layer: RS_H16_PANEL = "64" / "32" forces it for every tiled layer, "l:w;l:w" per layer
+int panel_ks(int layer_index) {
+    if (const char* e = getenv("RS_H16_PANEL")) {
+        if (!strchr(e, ':')) return atoi(e) == 64 ? 2 : 1;
+        int l, w;
+        for (const char* q = e; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
+            if (sscanf(q, "%d:%d", &l, &w) == 2 && l == layer_index) return w == 64 ? 2 : 1;
+    }
+    return 1;
 }
 
 }  // namespace
@@ -440,14 +481,21 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
         return RS_ERR_ARG;
     }
     const int n16 = round_up(L.c_out, 16) / 16;
-    const Shape* s = choose_shape(rows64, n16, L.plan.nch, num_cu);
+    int ks = panel_ks(layer_index);
+    int n_panels = (L.plan.nch + ks - 1) / ks;                      // plan.nch counts 32-channel panels
+    const Shape* s = choose_shape(rows64, n16, n_panels, num_cu, ks);
+    if (!s && ks == 2) {
+        ks = 1;
+        n_panels = L.plan.nch;
+        s = choose_shape(rows64, n16, n_panels, num_cu, ks);
+    }
     if (const char* force = getenv("RS_FORCE_SHAPE_H16")) {         // tuning aid: "layer:wm,wn,mt,nt;..."
         int l, wm, wn, mt, nt;
         for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
             if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
                 for (int k = 0; k < kNumShapes; ++k)
                     if (kShapes[k].wm == wm && kShapes[k].wn == wn && kShapes[k].mt == mt && kShapes[k].nt == nt &&
-                        lds_bytes(kShapes[k]) <= 160 * 1024)
+                        lds_bytes(kShapes[k], ks) <= 160 * 1024 && kShapes[k].fn[ks - 1][0])
                         s = &kShapes[k];
     }
     if (!s) {
@@ -474,13 +522,13 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
     a.inv_P_out = 1.0f / (float)a.P_out;
     a.cp_in = L.cp_in;
     a.cp_out = L.cp_out;
-    a.n_panels = L.plan.nch;
+    a.n_panels = n_panels;
     a.n_alloc = L.plan.n_alloc;
     a.shift_out = layer_index + 1;
     a.n_mtiles = (a.rows_in + BM - 1) / BM;
     a.n_ntiles = (n16 * 16 + BN - 1) / BN;
     a.check_dead = check_dead;
-    KernelFn fn = s->fn[f16 ? 1 : 0];
+    KernelFn fn = s->fn[ks - 1][f16 ? 1 : 0];
     RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
     const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
@@ -488,7 +536,7 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
     // tile order: rectangles of gm x gn tiles per XCD block when the grid fills the chip (see conv_wino4.hip)
     a.gm = a.gn = a.n_mb = 0;
     a.q_total = (int)tiles;
-    static const int rect_off = getenv("RS_NO_RECT_ORDER") ? 1 : 0;
+    const int rect_off = getenv("RS_NO_RECT_ORDER") ? 1 : 0;      // read per launch: tests toggle it
     if (!rect_off && (int64_t)grid == num_cu && num_cu % 8 == 0 && a.n_ntiles > 1) {
         const int rect = num_cu / 8;
         const int64_t rounds = (tiles + num_cu - 1) / num_cu;
@@ -516,7 +564,7 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
     if (!d_stamps) RS_HIP(hipMalloc(&d_stamps, 4 * 8 * 8 * 8));
     a.stamps = d_stamps;
 #endif
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes(*s), st, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes(*s, ks), st, a);
     RS_HIP(hipGetLastError());
 #ifdef RS_ITEM_STAMPS
     {

@@ -27,6 +27,13 @@
 #include <algorithm>
 #include <utility>
 
+#ifndef RS_SF32_BLOCKS
+#define RS_SF32_BLOCKS 2
+#endif
+#ifndef RS_SF32_WAVES
+#define RS_SF32_WAVES 3
+#endif
+
 namespace rs {
 namespace {
 
@@ -64,7 +71,7 @@ struct StreamF32Args {
 };
 
 template <int NT>
-__global__ __launch_bounds__(kWaves * 64, 2) void conv_stream_f32_kernel(const StreamF32Args a) {
+__global__ __launch_bounds__(kWaves * 64, RS_SF32_BLOCKS) void conv_stream_f32_kernel(const StreamF32Args a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, kq = lane >> 4;
@@ -252,7 +259,7 @@ int launch_conv_stream_f32(const ConvLayerDev& L1, const float* d_xs, const floa
     a.n_reads = B;
     a.cp_out = L1.cp_out;
     a.n_sub = (int)((rows_out + 15) / 16);
-    const int waves = num_cu * 3 * kWaves;                       // 3 workgroups of 4 waves per CU (153 VGPRs: 3 waves per SIMD)
+    const int waves = num_cu * RS_SF32_WAVES * kWaves;                       // 3 workgroups of 4 waves per CU (153 VGPRs: 3 waves per SIMD)
     a.sub_per_wave = std::max(8, (a.n_sub + waves - 1) / waves);
     const int n_waves = (a.n_sub + a.sub_per_wave - 1) / a.sub_per_wave;
     const int grid = (n_waves + kWaves - 1) / kWaves;

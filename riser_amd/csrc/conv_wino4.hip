@@ -557,7 +557,7 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
     // tile order: rectangles of gm x gn tiles per XCD block when the grid fills the chip (see the kernel)
     a.gm = a.gn = a.n_mb = 0;
     a.q_total = (int)tiles;
-    static const int rect_off = getenv("RS_NO_RECT_ORDER") ? 1 : 0;
+    const int rect_off = getenv("RS_NO_RECT_ORDER") ? 1 : 0;      // read per launch: tests toggle it
     if (!rect_off && (int64_t)grid == num_cu && num_cu % 8 == 0 && a.n_ntiles > 1) {
         const int rect = num_cu / 8;
         const int64_t rounds = (tiles + num_cu - 1) / num_cu;

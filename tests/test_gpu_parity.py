@@ -383,3 +383,27 @@ def test_full_size_batch_properties(dev):
     assert np.array_equal(full[pick, 1] > 0.9, want[:, 1] > 0.9)
     # the population must be discriminating, or the checks above prove little
     assert (full[:, 1] > 0.9).sum() > 10 and (full[:, 1] < 0.1).sum() > 10
+    # (e) the tile ORDER of the persistent walk (XCD blocks as gm x gn rectangles at this size) must not change a bit:
+    # n-major order (RS_NO_RECT_ORDER) gives identical probabilities, fp32 Winograd and f16
+    from riser_amd.model import Model
+    mh = Model(synth.make_state_dict(1), synth.Config(), None, "m", dtype="f16", device=dev)
+    half = mh.classify_raw(sig, off, ln, lens).cpu().numpy()
+    os.environ["RS_NO_RECT_ORDER"] = "1"
+    try:
+        assert np.array_equal(full, m.classify_raw(sig, off, ln, lens).cpu().numpy())
+        assert np.array_equal(half, mh.classify_raw(sig, off, ln, lens).cpu().numpy())
+    finally:
+        del os.environ["RS_NO_RECT_ORDER"]
+    # (f) 64-channel panels of the 16-bit tiled kernel (RS_H16_PANEL=64: other tile shapes, other accumulation order
+    # across k-steps): same probabilities to fp32-accumulation round-off
+    os.environ["RS_H16_PANEL"] = "64"
+    try:
+        wide = mh.classify_raw(sig, off, ln, lens).cpu().numpy()
+    finally:
+        del os.environ["RS_H16_PANEL"]
+    # (activations are re-rounded to 16 bits after every layer, so round-off differences are amplified to the 16-bit
+    # path's own distance from fp32, ~7e-3)
+    assert np.abs(wide - half).max() < 1e-2
+    assert np.abs(wide - full).max() < 2e-2 and np.abs(half - full).max() < 2e-2
+    assert np.abs(half[pick] - want).max() < 2e-2
+    mh.close()
