@@ -231,6 +231,9 @@ int rs_debug_capture_layer(rs_model* m, int layer, void* d_dst, size_t bytes);
  *   stage 0 = normalise, stage 1 = layer-0 conv, stage 1 + i = conv layer i (i >= 1),
  *   stage n_layers + 1 = GAP/FC/softmax head;
  * *calls receives the number of profiled forward calls.  Recorded events are consumed.
+ * on = 1: one event per launch (an event costs ~4.5 us of stream time: 14 per call).  on = 2: coarse - events only
+ * at the call's start, after normalise + layer 0 (their time lands in stage 1), after the LAST conv layer (the
+ * whole conv stack, layers 1 .. n-1, lands in stage n_layers) and after the head: what bench.py's timed region uses.
  */
 int rs_profile_enable(rs_model* m, int on);
 int rs_profile_read(rs_model* m, float* stage_ms, int32_t* calls);

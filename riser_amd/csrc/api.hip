@@ -53,6 +53,8 @@ struct rs_model {
     int last_bn[kMaxLayers] = {0};
     // stage profiling (rs_profile_*): events recorded on the launch stream
     bool prof_on = false;
+    bool prof_open = false;      // a profiled call has recorded its opening event (rs_classify opens before normalise)
+    int prof_level = 1;          // 1: one event per launch; 2: call start, end of normalise + layer 0, end of the conv stack, head
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_stage;            // stage of event k (-1 = start of a call)
     size_t ev_used = 0;
@@ -185,6 +187,9 @@ WsLayout ws_layout(const rs_model* m, int B, int Lmax) {
 // record an event tagged `stage` (-1 opens a call) on the stream, if profiling is on
 void prof_mark(rs_model* m, int stage, hipStream_t st) {
     if (!m->prof_on) return;
+    // coarse level: an event costs ~4.5 us on the stream; only the boundaries of the conv stack are kept, a skipped
+    // stage's time is added to the next recorded one (normalise -> stage 1, conv layers 1..n-2 -> stage n-1)
+    if (m->prof_level == 2 && (stage == 0 || (stage >= 2 && stage < m->n_layers))) return;
     if (m->ev_used == m->ev_pool.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return;
@@ -194,7 +199,11 @@ void prof_mark(rs_model* m, int stage, hipStream_t st) {
     m->ev_stage[m->ev_used] = stage;
     (void)hipEventRecord(m->ev_pool[m->ev_used], st);
     ++m->ev_used;
-    if (stage < 0) ++m->prof_calls;
+    if (stage < 0) {
+        ++m->prof_calls;
+        m->prof_open = true;
+    }
+    if (stage == m->n_layers + 1) m->prof_open = false;     // the head closes the call
 }
 
 // fp32 -> bf16 / f16 bits, round to nearest even (host side, weight packing)
@@ -465,7 +474,7 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
     char* ws = static_cast<char*>(d_ws);
     void* buf[2] = {ws + w.bufa_off, ws + w.bufb_off};
 
-    if (!m->prof_on || m->ev_used == 0 || m->ev_stage[m->ev_used - 1] != 0) prof_mark(m, -1, st);
+    if (!m->prof_open) prof_mark(m, -1, st);
     // Winograd fp32 path: ConvNet layer 0 (one input channel) is folded into the staging of layer 1
     // when the signal rows are laid out at the padded pitch (always true via rs_classify)
     const bool fuse0 = zero_prefix && m->dtype == RS_F32W && ldx == w.P0 && conv_wino_can_fuse0(m->layers[1], w.P0 >> 1);
@@ -629,6 +638,8 @@ int rs_profile_enable(rs_model* m, int on) {
         return RS_ERR_ARG;
     }
     m->prof_on = on != 0;
+    m->prof_level = on == 2 ? 2 : 1;
+    m->prof_open = false;
     if (!on) {
         m->ev_used = 0;
         m->prof_calls = 0;

@@ -120,8 +120,9 @@ class Model:
             out.append({n: getattr(li, n) for n, _ in nv.LayerInfo._fields_})
         return out
 
-    def profile(self, on: bool):
-        nv.check(nv.lib().rs_profile_enable(self._h, 1 if on else 0), "rs_profile_enable")
+    def profile(self, on, coarse: bool = False):
+        """HIP-event stage timing on the launch stream; coarse = only the conv stack's boundaries (4 events per call)."""
+        nv.check(nv.lib().rs_profile_enable(self._h, (2 if coarse else 1) if on else 0), "rs_profile_enable")
 
     def profile_read(self):
         """-> (stage_ms float32 [n_layers + 2], calls); see rs_profile_read."""
