@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 from riser_amd import dist as rdist          # noqa: E402
 from riser_amd import synth                  # noqa: E402
 
+SETTLE_STEPS = 25
 BATCH = 512
 CHUNK = 16000
 SIG_SEED = 20260103
@@ -89,6 +90,10 @@ def main():
     def step():
         model.classify_raw(sig, off, ln, lens, out=probs)
 
+    # steady state is what the ReadUntil loop runs in: let the shader clock settle (~20 steps = 40 ms after an idle
+    # period) before the W counted warm-up steps, whatever W the caller picked
+    for _ in range(SETTLE_STEPS):
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(device)

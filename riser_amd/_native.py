@@ -49,6 +49,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its bundled HIP runtime must be the one already in the process when libriser_amd.so resolves
+    # libamdhip64 (loaded the other way round, the system runtime comes up beside torch's and sees no device)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NativeError(f"{LIB_PATH} not found: the HIP extension is not built "
                           "(run `python -m riser_amd.build`); riser_amd has no CPU fallback")
