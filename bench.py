@@ -289,7 +289,19 @@ def main():
             torch_path.classify_per_read(cpu_model, sigs[n_done:n_done + 8])
             n_done += 8
         dt = time.perf_counter() - t1
+        # second figure: the same torch-CPU conv stack at batch 64 - what the reference's ops give
+        # when its per-read loop is batched; normalisation stays per read (numpy), as the reference has no batched form
+        from oracle import riser_oracle as ro
+        nb, tb0 = 0, time.perf_counter()
+        while nb < 128 and time.perf_counter() - tb0 < max(4.0, args.cpu_seconds / 2):
+            xs = np.stack([ro.mad_normalise(s) for s in sigs[nb:nb + 64]]).astype(np.float32)
+            torch.softmax(cpu_model.logits(torch.from_numpy(xs)), dim=1)
+            nb += 64
+        dtb = time.perf_counter() - tb0
         out["cpu_baseline"] = {"value": round(n_done / dt, 2), "unit": "chunks/s",
+                               "batched64_value": round(nb / dtb, 2),
+                               "batched64_note": f"{nb} chunks through the same torch-CPU ops at batch 64 (+ per-read numpy "
+                                                 f"normalise), {dtb:.1f} s",
                                "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"first {n_done} of the step's {B} chunks ({L} samples each), one read at a "
                                          f"time: numpy MAD-normalise + torch-CPU conv stack at batch 1 "
