@@ -167,6 +167,39 @@ def test_random_batches_property(dev):
     m.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32w", "f16"])
+def test_large_ragged_batch_tile_order(dev, dtype):
+    """A few hundred reads of mixed lengths: the persistent tile walk runs with XCD blocks as gm x gn rectangles
+    (rectangles may overhang the tile grid: invalid order indices are skipped) AND dead-tile elimination.  Every read
+    must come out bit-identical to its result in a small batch (n-major order, grid below the CU count) and to the
+    n-major order of the same large batch; a sample is checked against the oracle."""
+    import os
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    sd = synth.make_state_dict(2)
+    m = Model(sd, synth.Config(), None, "m", dtype=dtype, device=dev)
+    rng = np.random.default_rng(77)
+    for B in (437, 300):
+        lens = rng.choice([4096, 6024, 8000, 8615, 12000, 16000], size=B).astype(np.int32)
+        lens[0] = 16000
+        sigs = [synth.make_signals(SIG_SEED, 1, int(n), first_read=2000 + i)[0] for i, n in enumerate(lens)]
+        sig, off, ln, lh = pack_reads(sigs, dev)
+        full = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+        os.environ["RS_NO_RECT_ORDER"] = "1"
+        try:
+            assert np.array_equal(full, m.classify_raw(sig, off, ln, lh).cpu().numpy())
+        finally:
+            del os.environ["RS_NO_RECT_ORDER"]
+        idx = np.sort(rng.choice(B, size=23, replace=False))
+        tidx = torch.from_numpy(idx).to(dev)
+        part = m.classify_raw(sig, off[tidx].contiguous(), ln[tidx].contiguous(), lh[idx]).cpu().numpy()
+        assert np.array_equal(part, full[idx])
+        pick = idx[:3]
+        want = ro.classify_reads(sd, [sigs[k] for k in pick])
+        assert np.abs(full[pick] - want).max() < (1e-3 if dtype == "f32w" else 2e-2)
+    m.close()
+
+
 def test_stream_classifier_matches_direct(dev):
     """host-resident reads streamed in sub-batches (copy/compute overlap) == one direct call."""
     from riser_amd.model import Model
