@@ -49,8 +49,8 @@ typedef enum rs_dtype {
     RS_F32 = 0,             /* f32-input MFMA (v_mfma_f32_16x16x4_f32): exact fmaf chains */
     RS_BF16 = 1,            /* bf16 activations/weights, v_mfma_f32_16x16x32_bf16, fp32 accumulate */
     RS_F16 = 2,             /* f16 activations/weights, v_mfma_f32_16x16x32_f16, fp32 accumulate */
-    RS_F32W = 3             /* fp32 throughout, conv lowered to Winograd F(2,3) on the f32-input MFMA: 2/3 of
-                               the multiplications of RS_F32, results within a few ulp of it */
+    RS_F32W = 3             /* fp32 throughout, conv lowered to Winograd F(2,3) / F(4,3) on the f32-input MFMA:
+                               2/3 resp. 1/2 of the multiplications of RS_F32, probabilities within ~1e-5 of it */
 } rs_dtype;
 
 /* decisions of riser/control.py:75-82, as written into rs_decide's output */

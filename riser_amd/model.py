@@ -39,8 +39,8 @@ class Workspace:
 
 class Model:
     def __init__(self, state, config, logger, target, dtype: str = "f32w", device=None):
-        """dtype: "f32w" (default; fp32 end to end, conv layers as Winograd F(2,3) on the f32-input
-        MFMA), "f32" (fp32, direct lowering: exact fmaf chains), "f16" / "bf16" (16-bit
+        """dtype: "f32w" (default; fp32 end to end, conv layers as Winograd F(2,3) / F(4,3) on the
+        f32-input MFMA), "f32" (fp32, direct lowering: exact fmaf chains), "f16" / "bf16" (16-bit
         activations and weights, fp32 accumulate)."""
         self.target = target
         self.logger = logger
