@@ -27,6 +27,7 @@
 // LDS rows are KC+2 floats (= 2 mod 4): the 16 rows x 2 k-groups that a 32-lane half reads
 // with ds_read_b32 then fall in 32 distinct banks.
 #include "common.hpp"
+#include "tile_walk.hpp"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -71,8 +72,7 @@ struct ConvArgs {
     int cp_in, cp_out;
     int kc, nch;
     int shift_out;         // valid output rows of read b: len[b] >> shift_out
-    int n_mtiles, n_ntiles;
-    int check_dead;        // 0: every read is long enough that no tile can be all padding (skip the test)
+    WalkArgs walk;         // tile grid, order and dead-tile flag (tile_walk.hpp)
     unsigned long long* stamps;   // diagnostic (RS_CONV_STAMPS=1): per block {memtime, memrealtime} at entry / exit
 };
 
@@ -201,61 +201,43 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f32_kernel(const ConvArgs a
         }
     };
 
-    // ---- tile walk: round k gives XCD x (= blockIdx % 8) a contiguous block of the n-major tile
-    // order, so the workgroups sharing an L2 stream the same weight slab at the same time -------
-    const int tiles = a.n_mtiles * a.n_ntiles;
-    // ---- tile walk with dead-tile elimination ---------------------------------------------------
-    // order index q -> (n tile, row tile), n-major.  Round k of the walk gives workgroup w the
-    // order index k*nwg + slot_k(w): within its XCD's contiguous block of the round the slot is
-    // ROTATED by 5 per round, because the all-padding tiles of shorter reads sit at fixed positions
-    // of every read's P-row slot (a power-of-two period, like nwg) and a fixed stride would hand
-    // some workgroups nothing but dead tiles.  A tile whose rows all
-    // lie beyond their read's length has an all-zero output: it is zero-filled here, without
-    // loads, MFMAs or pipeline slots, when the walk steps over it.  Such a tile lies inside one
+    // ---- tile walk (tile_walk.hpp) with dead-tile elimination -------------------------------------
+    // A tile whose rows all lie beyond their read's length has an all-zero output: it is zero-filled here,
+    // without loads, MFMAs or pipeline slots, when the walk steps over it.  Such a tile lies inside one
     // read's slot (a tile containing a read start always has valid rows): one uniform look-up.
+    const int tiles = a.walk.q_total;
     const int P_in_ = 2 * a.P_out;
-    auto tile_origin = [&](int q, int& tm0, int& tn0) {
-        const int nt_ = a.n_ntiles == 1 ? 0 : q / a.n_mtiles;
-        const int mi = q - nt_ * a.n_mtiles;
+    auto tile_origin = [&](int q, int& tm0, int& tn0) -> bool {
+        int mi, nt_;
+        const bool ok = walk_tile(a.walk, q, mi, nt_);
         tm0 = mi * BM;
         tn0 = nt_ * BN;
+        return ok;
     };
-    const int nwg_ = gridDim.x;
-    // incremental form of: round k -> k*nwg + xcd*blk + ((j + 5k) mod blk)
-    const int blk_ = (nwg_ & 7) == 0 ? nwg_ >> 3 : nwg_;
-    const int blk_base_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x & 7) * blk_ : 0;
-    int slot_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    int round_base_ = 0;
-    auto order_index = [&]() {
-        const int q = round_base_ + blk_base_ + slot_;
-        round_base_ += nwg_;
-        if (a.check_dead) {                                        // rotate only when dead tiles can exist (costs ~1 %)
-            slot_ += 5 % blk_;
-            if (slot_ >= blk_) slot_ -= blk_;
-        }
-        return q;
-    };
+    TileWalk walk;
+    auto order_index = [&]() { return walk.next_index(a.walk); };
     auto next_live = [&]() {                                       // order index of this workgroup's next live tile
         int q = order_index();
-        while (a.check_dead && q < tiles) {
+        while (q < tiles) {
             int tm0, tn0;
-            tile_origin(q, tm0, tn0);
-            const int b = tm0 / P_in_;
-            const int t0 = tm0 - b * P_in_;
-            if (!(t0 + BM <= P_in_ && t0 >= (as_const_len(a.len)[b] >> (a.shift_out - 1)))) break;
-            // zero-fill the BM/2 x BN output tile (16-byte pieces; rows are cp_out wide)
-            const int pieces_per_row = BN / 4;
-            for (int f = threadIdx.x; f < (BM / 2) * pieces_per_row; f += blockDim.x) {
-                const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 4;
-                const int prow = (tm0 >> 1) + rr, col = tn0 + cc;
-                if (2 * prow < a.rows_in && col < a.cp_out)
-                    *reinterpret_cast<float4*>(a.y + (int64_t)prow * a.cp_out + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile_origin(q, tm0, tn0)) {
+                if (!a.walk.check_dead) break;
+                const int b = tm0 / P_in_;
+                const int t0 = tm0 - b * P_in_;
+                if (!(t0 + BM <= P_in_ && t0 >= (as_const_len(a.len)[b] >> (a.shift_out - 1)))) break;
+                // zero-fill the BM/2 x BN output tile (16-byte pieces; rows are cp_out wide)
+                const int pieces_per_row = BN / 4;
+                for (int f = threadIdx.x; f < (BM / 2) * pieces_per_row; f += blockDim.x) {
+                    const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 4;
+                    const int prow = (tm0 >> 1) + rr, col = tn0 + cc;
+                    if (2 * prow < a.rows_in && col < a.cp_out)
+                        *reinterpret_cast<float4*>(a.y + (int64_t)prow * a.cp_out + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             q = order_index();
         }
         return q;
     };
-    const int nwg = gridDim.x;
     int o = next_live();
     if (o >= tiles) return;
     if (a.stamps && tid == 0) {
@@ -565,15 +547,14 @@ int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const i
     a.kc = p.kc;
     a.nch = p.nch;
     a.shift_out = layer_index + 1;
-    a.n_mtiles = (a.rows_in + BM - 1) / BM;
-    a.n_ntiles = (n16 * 16 + BN - 1) / BN;
-    a.check_dead = check_dead;
     const size_t lds = lds_bytes(*s, p.kc);
     KernelFn fn = s->fn[p.kc == 16 ? 1 : p.kc == 20 ? 2 : p.kc == 24 ? 3 : 0];
     RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
-    const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
+    const int n_mtiles = (a.rows_in + BM - 1) / BM, n_ntiles = (n16 * 16 + BN - 1) / BN;
+    const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, BM, 3.0 * BN, check_dead);
     static unsigned long long* d_stamps = nullptr;
     static const bool want_stamps = getenv("RS_CONV_STAMPS") != nullptr;
     if (want_stamps && !d_stamps) RS_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), 4096 * 4 * 8));

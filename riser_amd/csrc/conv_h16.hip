@@ -16,6 +16,7 @@
 //     above the MFMA block of item k (unconditional loads, zero page for masked units).
 // Channels are padded to 8 in HBM (16-byte rows pieces) and to 32 in K (zero weights).
 #include "common.hpp"
+#include "tile_walk.hpp"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -64,9 +65,7 @@ struct ConvHArgs {
     int n_panels;
     int n_alloc;
     int shift_out;
-    int n_mtiles, n_ntiles;
-    int check_dead;        // 0: every read is long enough that no tile can be all padding (skip the test)
-    int gm, gn, n_mb, q_total;   // tile order: gm x gn rectangles per XCD block (gm == 0: n-major), order indices in all
+    WalkArgs walk;         // tile grid, order and dead-tile flag (tile_walk.hpp)
     unsigned long long* stamps;  // diagnostic builds only
 };
 
@@ -184,59 +183,28 @@ __global__ __launch_bounds__(kThreads, 2) void conv_h16_kernel(const ConvHArgs a
 #endif
     };
 
-    const int tiles = a.q_total;
-    // ---- tile walk with dead-tile elimination ---------------------------------------------------
-    // order index q -> (n tile, row tile), n-major.  Round k of the walk gives workgroup w the
-    // order index k*nwg + slot_k(w): within its XCD's contiguous block of the round the slot is
-    // ROTATED by 5 per round, because the all-padding tiles of shorter reads sit at fixed positions
-    // of every read's P-row slot (a power-of-two period, like nwg) and a fixed stride would hand
-    // some workgroups nothing but dead tiles.  A tile whose rows all
-    // lie beyond their read's length has an all-zero output: it is zero-filled here, without
-    // loads, MFMAs or pipeline slots, when the walk steps over it.  Such a tile lies inside one
-    // read's slot (a tile containing a read start always has valid rows): one uniform look-up.
-    // With gm > 0 (conv_wino4.hip) the contiguous block of order indices an XCD takes per round is a rectangle
-    // of gm row tiles x gn channel tiles: the workgroups sharing an L2 re-use gm activation slabs and gn weight
-    // slabs per panel; rectangles overhanging the tile grid contain invalid indices, skipped in next_live.
+    // ---- tile walk (tile_walk.hpp) with dead-tile elimination -------------------------------------
+    // A tile whose rows all lie beyond their read's length has an all-zero output: it is zero-filled in
+    // next_live, without loads, MFMAs or pipeline slots, when the walk steps over it.  Such a tile lies
+    // inside one read's slot (a tile containing a read start always has valid rows): one uniform look-up.
+    const int tiles = a.walk.q_total;
     const int P_in_ = 2 * a.P_out;
     auto tile_origin = [&](int q, int& tm0, int& tn0) -> bool {
         int mi, nt_;
-        if (a.gm == 0) {
-            nt_ = a.n_ntiles == 1 ? 0 : q / a.n_mtiles;
-            mi = q - nt_ * a.n_mtiles;
-        } else {
-            const int rect = a.gm * a.gn;
-            const int bq = q / rect, w = q - bq * rect;
-            const int ln = w / a.gm, lm = w - ln * a.gm;
-            const int nb = bq / a.n_mb, mb = bq - nb * a.n_mb;
-            mi = mb * a.gm + lm;
-            nt_ = nb * a.gn + ln;
-        }
+        const bool ok = walk_tile(a.walk, q, mi, nt_);
         tm0 = mi * BM;
         tn0 = nt_ * BN;
-        return mi < a.n_mtiles && nt_ < a.n_ntiles;
+        return ok;
     };
-    const int nwg_ = gridDim.x;
-    // incremental form of: round k -> k*nwg + xcd*blk + ((j + 5k) mod blk)
-    const int blk_ = (nwg_ & 7) == 0 ? nwg_ >> 3 : nwg_;
-    const int blk_base_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x & 7) * blk_ : 0;
-    int slot_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    int round_base_ = 0;
-    auto order_index = [&]() {
-        const int q = round_base_ + blk_base_ + slot_;
-        round_base_ += nwg_;
-        if (a.check_dead) {                                        // rotate only when dead tiles can exist (costs ~1 %)
-            slot_ += 5 % blk_;
-            if (slot_ >= blk_) slot_ -= blk_;
-        }
-        return q;
-    };
+    TileWalk walk;
+    auto order_index = [&]() { return walk.next_index(a.walk); };
     auto next_live = [&]() {                                       // order index of this workgroup's next live tile
         int q = order_index();
         while (q < tiles) {
             int tm0, tn0;
             const bool valid = tile_origin(q, tm0, tn0);
             if (valid) {
-                if (!a.check_dead) break;
+                if (!a.walk.check_dead) break;
                 const int b = tm0 / P_in_;
                 const int t0 = tm0 - b * P_in_;
                 if (!(t0 + BM <= P_in_ && t0 >= (as_const_len(a.len)[b] >> (a.shift_out - 1)))) break;
@@ -525,39 +493,13 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
     a.n_panels = n_panels;
     a.n_alloc = L.plan.n_alloc;
     a.shift_out = layer_index + 1;
-    a.n_mtiles = (a.rows_in + BM - 1) / BM;
-    a.n_ntiles = (n16 * 16 + BN - 1) / BN;
-    a.check_dead = check_dead;
+    const int n_mtiles = (a.rows_in + BM - 1) / BM, n_ntiles = (n16 * 16 + BN - 1) / BN;
+    const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, BM, 3.0 * BN, check_dead);
     KernelFn fn = s->fn[ks - 1][f16 ? 1 : 0];
     RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
-    const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
-    const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-    // tile order: rectangles of gm x gn tiles per XCD block when the grid fills the chip (see conv_wino4.hip)
-    a.gm = a.gn = a.n_mb = 0;
-    a.q_total = (int)tiles;
-    const int rect_off = getenv("RS_NO_RECT_ORDER") ? 1 : 0;      // read per launch: tests toggle it
-    if (!rect_off && (int64_t)grid == num_cu && num_cu % 8 == 0 && a.n_ntiles > 1) {
-        const int rect = num_cu / 8;
-        const int64_t rounds = (tiles + num_cu - 1) / num_cu;
-        const double x_t = BM, w_t = 3.0 * BN;                   // slab rows per K channel
-        double best = 1e300;
-        for (int gn = 1; gn <= rect; ++gn) {
-            if (rect % gn) continue;
-            const int gm = rect / gn;
-            const int64_t n_mb = (a.n_mtiles + gm - 1) / gm, n_nb = (a.n_ntiles + gn - 1) / gn;
-            const int64_t q_total = n_mb * n_nb * rect;
-            if ((q_total + num_cu - 1) / num_cu != rounds) continue;             // never pay an extra round
-            const double fetch = (double)(n_mb * n_nb) * (gm * x_t + gn * w_t);
-            if (fetch < best) {
-                best = fetch;
-                a.gm = gm;
-                a.gn = gn;
-                a.n_mb = (int)n_mb;
-                a.q_total = (int)q_total;
-            }
-        }
-    }
     a.stamps = nullptr;
 #ifdef RS_ITEM_STAMPS
     static unsigned long long* d_stamps = nullptr;

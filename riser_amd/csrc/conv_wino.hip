@@ -33,6 +33,7 @@
 // Schedule: persistent 8-wave workgroups, double-buffered LDS, register prefetch of the next
 // item distributed over the MFMA slots of the current one (conv_f32.hip has the rationale).
 #include "common.hpp"
+#include "tile_walk.hpp"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -77,8 +78,7 @@ struct WinoArgs {
     int cp_in, cp_out;
     int nch;
     int shift_out;         // valid output rows of read b: len[b] >> shift_out
-    int n_mtiles, n_ntiles;
-    int check_dead;
+    WalkArgs walk;         // tile grid, order and dead-tile flag (tile_walk.hpp)
     // FUSE0 (layer 1 only): the input rows are not read from x but computed on the fly from the
     // normalised signal - ConvNet layer 0 (C_in = 1: 3 FMAs per output) folded into the staging
     const float* xs;       // normalised signals, flat [B * P0] (row pitch == P0, zero beyond each read's length),
@@ -247,43 +247,34 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
         }
     };
 
-    // ---- tile walk (conv_f32.hip): n-major order, XCD-contiguous blocks per round, rotation and
-    // zero-fill of tiles that lie entirely in a shorter read's padding ----------------------------
-    const int tiles = a.n_mtiles * a.n_ntiles;
-    auto tile_origin = [&](int q, int& tm0, int& tn0) {
-        const int nt_ = a.n_ntiles == 1 ? 0 : q / a.n_mtiles;
-        const int mi = q - nt_ * a.n_mtiles;
+    // ---- tile walk (tile_walk.hpp): XCD-contiguous blocks per round, rotation and zero-fill of tiles that lie
+    // entirely in a shorter read's padding ---------------------------------------------------------------
+    const int tiles = a.walk.q_total;
+    auto tile_origin = [&](int q, int& tm0, int& tn0) -> bool {
+        int mi, nt_;
+        const bool ok = walk_tile(a.walk, q, mi, nt_);
         tm0 = mi * BMP;
         tn0 = nt_ * BN;
+        return ok;
     };
-    const int nwg_ = gridDim.x;
-    const int blk_ = (nwg_ & 7) == 0 ? nwg_ >> 3 : nwg_;
-    const int blk_base_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x & 7) * blk_ : 0;
-    int slot_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    int round_base_ = 0;
-    auto order_index = [&]() {
-        const int q = round_base_ + blk_base_ + slot_;
-        round_base_ += nwg_;
-        if (a.check_dead) {
-            slot_ += 5 % blk_;
-            if (slot_ >= blk_) slot_ -= blk_;
-        }
-        return q;
-    };
+    TileWalk walk;
+    auto order_index = [&]() { return walk.next_index(a.walk); };
     auto next_live = [&]() {
         int q = order_index();
-        while (a.check_dead && q < tiles) {
+        while (q < tiles) {
             int tm0, tn0;
-            tile_origin(q, tm0, tn0);
-            const int b = tm0 / a.P_out;
-            const int t0 = tm0 - b * a.P_out;
-            if (!(t0 + BMP <= a.P_out && t0 >= (clen[b] >> a.shift_out))) break;
-            const int pieces_per_row = BN / 4;
-            for (int f = threadIdx.x; f < BMP * pieces_per_row; f += blockDim.x) {
-                const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 4;
-                const int prow = tm0 + rr, col = tn0 + cc;
-                if (prow < a.rows_out && col < a.cp_out)
-                    *reinterpret_cast<float4*>(a.y + (int64_t)prow * a.cp_out + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile_origin(q, tm0, tn0)) {
+                if (!a.walk.check_dead) break;
+                const int b = tm0 / a.P_out;
+                const int t0 = tm0 - b * a.P_out;
+                if (!(t0 + BMP <= a.P_out && t0 >= (clen[b] >> a.shift_out))) break;
+                const int pieces_per_row = BN / 4;
+                for (int f = threadIdx.x; f < BMP * pieces_per_row; f += blockDim.x) {
+                    const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 4;
+                    const int prow = tm0 + rr, col = tn0 + cc;
+                    if (prow < a.rows_out && col < a.cp_out)
+                        *reinterpret_cast<float4*>(a.y + (int64_t)prow * a.cp_out + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             q = order_index();
         }
@@ -667,15 +658,14 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
     a.cp_out = L.cp_out;
     a.nch = p.nch;
     a.shift_out = layer_index + 1;
-    a.n_mtiles = (a.rows_out + BMP - 1) / BMP;
-    a.n_ntiles = (n16 * 16 + BN - 1) / BN;
-    a.check_dead = check_dead;
     const size_t lds = lds_bytes(*s, p.kc);
     KernelFn fn = fused ? kFusedL1 : s->fn[p.kc == 16 ? 0 : p.kc == 20 ? 1 : 2];
     RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
-    const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
+    const int n_mtiles = (a.rows_out + BMP - 1) / BMP, n_ntiles = (n16 * 16 + BN - 1) / BN;
+    const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 2.0 * BMP, 4.0 * BN, check_dead);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, a);
     RS_HIP(hipGetLastError());
     if (bm_out) *bm_out = 2 * BMP;          // reported in conv rows, like the direct kernels

@@ -25,6 +25,7 @@
 // with MT * NT <= 5 (6 x 4 accumulator registers per 16 x 16 sub-tile), and LDS capacity limits the channel
 // chunk to 16 or 20.  Used for the layers where the matrix pipe is the bound (chosen in rs_model_create).
 #include "common.hpp"
+#include "tile_walk.hpp"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -67,9 +68,7 @@ struct Wino4Args {
     int cp_in, cp_out;
     int nch;
     int shift_out;
-    int n_mtiles, n_ntiles;
-    int check_dead;
-    int gm, gn, n_mb, q_total;   // tile order: gm x gn rectangles per XCD block (gm == 0: n-major), order indices in all
+    WalkArgs walk;         // tile grid, order and dead-tile flag (tile_walk.hpp)
 };
 
 template <int WM, int WN, int MT, int NT, int KCT>
@@ -177,51 +176,24 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
         }
     };
 
-    // ---- tile walk (conv_wino.hip), tiles counted in groups ----------------------------------------------
-    // Order index q -> tile.  A round hands XCD x (= blockIdx & 7) the contiguous block of nwg / 8 indices
-    // x * blk ...: with gm > 0 such a block is a RECTANGLE of gm row tiles x gn channel tiles, so the workgroups
-    // that share an L2 re-use gm activation slabs and gn weight slabs per K chunk instead of streaming nwg / 8
-    // different activation slabs against one weight slab (host: launch_conv_wino4 picks gm x gn by the bytes the
-    // XCD pulls over the fabric).  Rectangles overhanging the tile grid contain invalid indices, skipped here.
-    const int tiles = a.q_total;
+    // ---- tile walk (tile_walk.hpp), tiles counted in groups -----------------------------------------------
+    const int tiles = a.walk.q_total;
     auto tile_origin = [&](int q, int& tm0, int& tn0) -> bool {
         int mi, nt_;
-        if (a.gm == 0) {
-            nt_ = a.n_ntiles == 1 ? 0 : q / a.n_mtiles;
-            mi = q - nt_ * a.n_mtiles;
-        } else {
-            const int rect = a.gm * a.gn;
-            const int bq = q / rect, w = q - bq * rect;
-            const int ln = w / a.gm, lm = w - ln * a.gm;
-            const int nb = bq / a.n_mb, mb = bq - nb * a.n_mb;
-            mi = mb * a.gm + lm;
-            nt_ = nb * a.gn + ln;
-        }
+        const bool ok = walk_tile(a.walk, q, mi, nt_);
         tm0 = mi * BG;
         tn0 = nt_ * BN;
-        return mi < a.n_mtiles && nt_ < a.n_ntiles;
+        return ok;
     };
-    const int nwg_ = gridDim.x;
-    const int blk_ = (nwg_ & 7) == 0 ? nwg_ >> 3 : nwg_;
-    const int blk_base_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x & 7) * blk_ : 0;
-    int slot_ = (nwg_ & 7) == 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    int round_base_ = 0;
-    auto order_index = [&]() {
-        const int q = round_base_ + blk_base_ + slot_;
-        round_base_ += nwg_;
-        if (a.check_dead) {
-            slot_ += 5 % blk_;
-            if (slot_ >= blk_) slot_ -= blk_;
-        }
-        return q;
-    };
+    TileWalk walk;
+    auto order_index = [&]() { return walk.next_index(a.walk); };
     auto next_live = [&]() {
         int q = order_index();
         while (q < tiles) {
             int tm0, tn0;
             const bool valid = tile_origin(q, tm0, tn0);
             if (valid) {
-                if (!a.check_dead) break;
+                if (!a.walk.check_dead) break;
                 const int pr0 = 2 * tm0;                                  // first pooled row of the tile
                 const int b = pr0 / a.P_out;
                 const int t0 = pr0 - b * a.P_out;
@@ -549,36 +521,10 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
     a.cp_out = L.cp_out;
     a.nch = p.nch;
     a.shift_out = layer_index + 1;
-    a.n_mtiles = (a.n_groups + BG - 1) / BG;
-    a.n_ntiles = (n16 * 16 + BN - 1) / BN;
-    a.check_dead = check_dead;
-    const int64_t tiles = (int64_t)a.n_mtiles * a.n_ntiles;
+    const int n_mtiles = (a.n_groups + BG - 1) / BG, n_ntiles = (n16 * 16 + BN - 1) / BN;
+    const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-    // tile order: rectangles of gm x gn tiles per XCD block when the grid fills the chip (see the kernel)
-    a.gm = a.gn = a.n_mb = 0;
-    a.q_total = (int)tiles;
-    const int rect_off = getenv("RS_NO_RECT_ORDER") ? 1 : 0;      // read per launch: tests toggle it
-    if (!rect_off && (int64_t)grid == num_cu && num_cu % 8 == 0 && a.n_ntiles > 1) {
-        const int rect = num_cu / 8;
-        const int64_t rounds = (tiles + num_cu - 1) / num_cu;
-        const double x_t = 4.0 * BG, w_t = 6.0 * BN;            // slab rows per K channel (bytes / (4 * cp_in))
-        double best = 1e300;
-        for (int gn = 1; gn <= rect; ++gn) {
-            if (rect % gn) continue;
-            const int gm = rect / gn;
-            const int64_t n_mb = (a.n_mtiles + gm - 1) / gm, n_nb = (a.n_ntiles + gn - 1) / gn;
-            const int64_t q_total = n_mb * n_nb * rect;
-            if ((q_total + num_cu - 1) / num_cu != rounds) continue;             // never pay an extra round
-            const double fetch = (double)(n_mb * n_nb) * (gm * x_t + gn * w_t);
-            if (fetch < best) {
-                best = fetch;
-                a.gm = gm;
-                a.gn = gn;
-                a.n_mb = (int)n_mb;
-                a.q_total = (int)q_total;
-            }
-        }
-    }
+    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 4.0 * BG, 6.0 * BN, check_dead);
     const size_t lds = lds_bytes(*s, p.kc);
     KernelFn fn = s->fn[p.kc == 16 ? 0 : 1];
     RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
