@@ -387,13 +387,18 @@ def test_full_size_batch_properties(dev):
     # n-major order (RS_NO_RECT_ORDER) gives identical probabilities, fp32 Winograd and f16
     from riser_amd.model import Model
     mh = Model(synth.make_state_dict(1), synth.Config(), None, "m", dtype="f16", device=dev)
+    md = Model(synth.make_state_dict(1), synth.Config(), None, "m", dtype="f32", device=dev)      # direct fp32 lowering
     half = mh.classify_raw(sig, off, ln, lens).cpu().numpy()
+    direct = md.classify_raw(sig, off, ln, lens).cpu().numpy()
+    assert np.abs(direct - full).max() < 1e-4
     os.environ["RS_NO_RECT_ORDER"] = "1"
     try:
         assert np.array_equal(full, m.classify_raw(sig, off, ln, lens).cpu().numpy())
         assert np.array_equal(half, mh.classify_raw(sig, off, ln, lens).cpu().numpy())
+        assert np.array_equal(direct, md.classify_raw(sig, off, ln, lens).cpu().numpy())
     finally:
         del os.environ["RS_NO_RECT_ORDER"]
+    md.close()
     # (f) 64-channel panels of the 16-bit tiled kernel (RS_H16_PANEL=64: other tile shapes, other accumulation order
     # across k-steps): same probabilities to fp32-accumulation round-off
     os.environ["RS_H16_PANEL"] = "64"
