@@ -37,6 +37,12 @@
 #ifndef RS_UF_AHEAD
 #define RS_UF_AHEAD 1
 #endif
+#ifndef RS_W4_DIST
+#define RS_W4_DIST 6
+#endif
+#ifndef RS_W4_PRIO
+#define RS_W4_PRIO 0
+#endif
 
 namespace rs {
 namespace {
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
 
         constexpr int NSLOTS = NC * KQ;                // slot = (k-step, component): MT * NT MFMAs
         constexpr int UNITS = A_PER + B_PER;
-        constexpr int DIST = 6;                        // slots between a unit's load and its LDS write
+        constexpr int DIST = RS_W4_DIST;               // slots between a unit's load and its LDS write
         constexpr int SPAN = NSLOTS - DIST;
         float dr[MT][6];                               // raw inputs d0..d5 of the lane's groups (next k-step)
         constexpr int AH = RS_UF_AHEAD;                // slots of look-ahead of the weight-fragment reads
@@ -310,12 +316,18 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
                 for (int j = 0; j < NT; ++j)
                     RS_FRAG_B(uf[(sl + AH) % (AH + 1)][j], Bb[(ncomp * BN + j * 16) * S + 4 * nst]);
             }
+#if RS_W4_PRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j][comp] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl % (AH + 1)][j], v[st & 1][i][comp],
                                                                            acc[i][j][comp], 0, 0, 0);
+#if RS_W4_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             {
                 constexpr int n_mf = MT * NT;
                 constexpr int n_rd = (sl + AH < NSLOTS ? NT : 0) + (rd_next ? 3 * MT : 0);
