@@ -85,6 +85,45 @@ def test_normalise_random_vs_oracle(proc):
         assert np.array_equal(o, w.astype(np.float64)), (len(s), s[:8])
 
 
+def test_normalise_adversarial_small_arrays(proc):
+    """Many short, adversarial reads in one launch: heavy ties (MAD = 0 and near-0), two-valued signals, outlier
+    runs touching both ends, half-integer medians, extreme int16 values, lengths 1..400 - every one bit-exact
+    (values and dtype rule) against the oracle restatement of riser/preprocess.py:108-147."""
+    rng = np.random.default_rng(20261003)
+    sigs = []
+    for i in range(600):
+        n = int(rng.integers(1, 400))
+        kind = i % 8
+        if kind == 0:
+            s = np.full(n, int(rng.integers(-300, 900)))                          # constant: MAD = 0
+        elif kind == 1:
+            s = rng.choice([500, 501], size=n)                                     # two values, many ties
+        elif kind == 2:
+            s = rng.integers(495, 506, n)
+            s[rng.random(n) < 0.3] = int(rng.integers(1500, 4000))                 # dense spikes: runs of outliers
+        elif kind == 3:
+            s = rng.integers(400, 600, n)
+            k = int(rng.integers(1, 6))
+            s[:k] = 4000                                                           # outlier run at the left end
+            s[-k:] = -2000                                                         # ... and at the right end
+        elif kind == 4:
+            s = rng.choice([-32768, 32767, 0], size=n)
+        elif kind == 5:
+            s = np.sort(rng.integers(0, 50, n))                                    # sorted: median between equal neighbours
+        elif kind == 6:
+            s = rng.integers(500, 503, n)
+            s[rng.integers(0, n)] = 30000                                          # one huge spike, MAD of 0 or 1
+        else:
+            s = (500 + 60 * rng.standard_normal(n)).round()
+        sigs.append(np.asarray(s, dtype=np.int16))
+    outs, stats = proc.mad_normalise_batch(sigs, return_stats=True)
+    for s, o, st in zip(sigs, outs, stats):
+        w = ro.mad_normalise(s)
+        assert np.array_equal(o, np.asarray(w, dtype=np.float64)), (len(s), s[:10])
+        med = np.median(s)
+        assert st[0] == med and st[1] == np.median(np.abs(s - med)), (len(s), st)
+
+
 def test_normalise_max_length_and_errors(proc):
     s = synth.make_signals(3, 1, 65536)[0]
     assert np.array_equal(proc.mad_normalise(s), ro.mad_normalise(s))
