@@ -43,6 +43,9 @@
 #ifndef RS_W4_PRIO
 #define RS_W4_PRIO 0
 #endif
+#ifndef RS_W4_STORE_ALWAYS
+#define RS_W4_STORE_ALWAYS 1
+#endif
 
 namespace rs {
 namespace {
@@ -349,7 +352,12 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
                 constexpr int u = decltype(U)::value;
                 if constexpr ((u * SPAN) / UNITS == sl) load_unit(U);
                 if constexpr ((u * SPAN) / UNITS + DIST == sl) {
+#if RS_W4_STORE_ALWAYS                                  // unconditional: after the last item the writes land in the idle buffer
+                                                        // (nobody reads it any more); saves a branch per unit: -1.2 % (clock-normalised A/B)
+                    store_unit(U, nbuf);
+#else
                     if (has_next) store_unit(U, nbuf);
+#endif
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
