@@ -3,7 +3,7 @@
 
     python tools/ablate_build.py conv_wino4.hip nomem=RS_ABL_NOLOAD,RS_ABL_NOLDSW,RS_ABL_NOSTORE ...
 
-writes riser_amd/lib/libabl_<name>.so; run a tool against it with RISER_AMD_LIB=<path>.
+writes riser_amd/lib/libabl_<name>.so (a flag written @-mllvm or @<raw> is passed to hipcc as is); run a tool against it with RISER_AMD_LIB=<path>.
 """
 import os, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
@@ -17,7 +17,7 @@ def main():
     def one(spec):
         name, flags = spec.split("=", 1)
         obj = os.path.join(B.OBJDIR, "abl_%s_%s" % (name, src.replace(".hip", ".o")))
-        cmd = [B._hipcc(), *B.FLAGS, *["-D" + f for f in flags.split(",") if f], "-c", os.path.join(B.CSRC, src), "-o", obj]
+        cmd = [B._hipcc(), *B.FLAGS, *[(f[1:] if f.startswith("@") else "-D" + f) for f in flags.split(",") if f], "-c", os.path.join(B.CSRC, src), "-o", obj]
         subprocess.run(cmd, check=True)
         lib = os.path.join(B.LIBDIR, "libabl_%s.so" % name)
         link = [o if os.path.basename(o) != src.replace(".hip", ".o") else obj for o in objs]
