@@ -217,6 +217,8 @@ def main():
         variants = {}
         for dt in ("f32", "f16", "bf16"):
             mv = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dt, device=device)
+            if dt in ("f16", "bf16"):
+                mv.autotune(sig, off, ln, lens)      # optional per-geometry tile tuning (fp32: the planner's picks stand)
             pv = torch.empty((B, 2), dtype=torch.float32, device=device)
             for _ in range(max(2, args.warmup)):
                 mv.classify_raw(sig, off, ln, lens, out=pv)

@@ -146,6 +146,19 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
                 float* d_probs, float* d_logits, void* stream);
 
 /*
+ * Optional tile-shape tuning for one batch geometry (not part of the reference; like a BLAS "find" mode).
+ * Runs rs_classify on the given batch and, for every conv layer that runs a tiled kernel, times each feasible
+ * entry of that kernel's tile-shape table in place (HIP events on `stream`, which is synchronised repeatedly);
+ * a shape more than 3 % faster than the launch planner's choice is remembered for launches with the same number of
+ * rows (B x padded length) of that layer.  Results are bit-identical whatever shape runs (the accumulation order
+ * over channels does not depend on the tile shape; 16-bit: on the panel width it does, within fp32 round-off).
+ * d_probs receives the batch's probabilities as rs_classify would produce them; *n_changed (optional) the number
+ * of layers whose choice changed.  Costs a few hundred launches: call once per deployment batch size, not per batch.
+ */
+int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmin,
+                int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, int32_t* n_changed, void* stream);
+
+/*
  * Ensemble form of rs_classify: the model loop of riser/control.py:68-71 for a whole batch.
  * The reads are normalised ONCE (riser/control.py:63), every model of `models` (same architecture,
  * e.g. the mRNA / mtRNA / globin stand-ins of one kit) runs its forward pass on the same normalised

@@ -59,6 +59,8 @@ struct rs_model {
     std::vector<int> ev_stage;            // stage of event k (-1 = start of a call)
     size_t ev_used = 0;
     int prof_calls = 0;
+    bool tuning = false;                  // rs_autotune: time every feasible tile shape of each tiled layer in place
+    int tuned_changed = 0;                // layers whose measured best differs from the planner's choice
 };
 
 namespace {
@@ -494,30 +496,83 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         // a tile of >= 64 rows can only be all padding if some read leaves >= 64 rows of its slot
         // unused at this layer; Lmin == 0 means "unknown": keep the test
         const int check_dead = (Lmin <= 0 || (w.P0 >> i) - (Lmin >> i) >= 64) ? 1 : 0;
-        if (m->dtype == RS_F32W && fuse0 && i == 1 && conv_stream_f32_ok(L, m->channels[0], P_in)) {
-            rc = launch_conv_stream_f32(L, d_x, m->d_w0, m->channels[0], static_cast<float*>(buf[cur ^ 1]), d_len, B, P_in,
-                                        m->num_cu, st);
-            m->last_bm[i] = 32;
-            m->last_bn[i] = round_up(L.c_out, 16);
-        } else if (m->dtype == RS_F32W && L.wino_m == 4)
-            rc = launch_conv_wino4(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len, B,
-                                   P_in, i, m->num_cu, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
-        else if (m->dtype == RS_F32W)
-            rc = launch_conv_wino(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
-                                  B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i],
-                                  (fuse0 && i == 1) ? d_x : nullptr, m->d_w0);
-        else if (m->dtype == RS_F32)
-            rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
-                                 B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
-        else if (is16 && i <= 2 && conv_stream_h16_ok(L, P_in)) {
-            const bool f0 = fuse0h && i == 1;
-            rc = launch_conv_stream_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, m->dtype == RS_F16, st,
-                                        f0 ? d_x : nullptr, m->d_w0, m->channels[0]);
-            m->last_bm[i] = 16;
-            m->last_bn[i] = round_up(L.c_out, 16);
-        } else
-            rc = launch_conv_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, m->d_zero,
-                                 m->dtype == RS_F16, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
+        // kind of kernel this layer runs: 0 streaming (not tuned), 1 F(4,3), 2 F(2,3), 3 direct fp32, 4 tiled 16-bit
+        const bool stream32 = m->dtype == RS_F32W && fuse0 && i == 1 && conv_stream_f32_ok(L, m->channels[0], P_in);
+        const bool stream16 = is16 && i <= 2 && conv_stream_h16_ok(L, P_in);
+        const int kind = (stream32 || stream16) ? 0 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2) : m->dtype == RS_F32 ? 3 : 4;
+        auto launch_layer = [&]() -> int {
+            int rc;
+            if (m->dtype == RS_F32W && fuse0 && i == 1 && conv_stream_f32_ok(L, m->channels[0], P_in)) {
+                rc = launch_conv_stream_f32(L, d_x, m->d_w0, m->channels[0], static_cast<float*>(buf[cur ^ 1]), d_len, B, P_in,
+                                            m->num_cu, st);
+                m->last_bm[i] = 32;
+                m->last_bn[i] = round_up(L.c_out, 16);
+            } else if (m->dtype == RS_F32W && L.wino_m == 4)
+                rc = launch_conv_wino4(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len, B,
+                                       P_in, i, m->num_cu, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
+            else if (m->dtype == RS_F32W)
+                rc = launch_conv_wino(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
+                                      B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i],
+                                      (fuse0 && i == 1) ? d_x : nullptr, m->d_w0);
+            else if (m->dtype == RS_F32)
+                rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
+                                     B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
+            else if (is16 && i <= 2 && conv_stream_h16_ok(L, P_in)) {
+                const bool f0 = fuse0h && i == 1;
+                rc = launch_conv_stream_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, m->dtype == RS_F16, st,
+                                            f0 ? d_x : nullptr, m->d_w0, m->channels[0]);
+                m->last_bm[i] = 16;
+                m->last_bn[i] = round_up(L.c_out, 16);
+            } else
+                rc = launch_conv_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, m->d_zero,
+                                     m->dtype == RS_F16, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
+            return rc;
+        };
+        if (m->tuning && (kind == 1 || kind == 2 || kind == 4)) {
+            // rs_autotune: every feasible entry of the kernel's shape table on THIS layer's real input (the buffers hold the
+            // activations of the batch; re-running a layer rewrites the same output), 1 warm + 3 timed launches each;
+            // a shape replaces the planner's choice only if it is > 3 % faster
+            const int n = kind == 1 ? conv_wino4_num_shapes() : kind == 2 ? conv_wino_num_shapes() : conv_h16_num_shapes();
+            auto ok = [&](int k) {
+                return kind == 1 ? conv_wino4_shape_ok(L, k) : kind == 2 ? conv_wino_shape_ok(L, k) : conv_h16_shape_ok(L, k);
+            };
+            hipEvent_t e0, e1;
+            RS_HIP(hipEventCreate(&e0));
+            RS_HIP(hipEventCreate(&e1));
+            auto timed = [&](int k, float* ms) -> int {
+                L.force_shape = k;
+                int r = launch_layer();
+                if (r == RS_OK) r = hipEventRecord(e0, st) == hipSuccess ? RS_OK : RS_ERR_HIP;
+                for (int rep = 0; rep < 3 && r == RS_OK; ++rep) r = launch_layer();
+                if (r == RS_OK) r = hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess ? RS_OK : RS_ERR_HIP;
+                if (r == RS_OK) r = hipEventElapsedTime(ms, e0, e1) == hipSuccess ? RS_OK : RS_ERR_HIP;
+                L.force_shape = -1;
+                return r;
+            };
+            const int64_t rows = (int64_t)B * P_in;
+            for (size_t t = 0; t < L.tuned.size(); ++t)                       // re-tuning a geometry: forget the old entry
+                if (L.tuned[t].first == rows) L.tuned.erase(L.tuned.begin() + t--);
+            float base_ms = 0.f, best_ms = 1e30f;
+            int best_k = -1;
+            rc = timed(-1, &base_ms);                                          // the planner's own choice
+            for (int k = 0; k < n && rc == RS_OK; ++k) {
+                if (!ok(k)) continue;
+                float ms = 0.f;
+                rc = timed(k, &ms);
+                if (rc == RS_OK && ms < best_ms) {
+                    best_ms = ms;
+                    best_k = k;
+                }
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            if (rc != RS_OK) return rc;
+            if (best_k >= 0 && best_ms < 0.97f * base_ms) {
+                L.tuned.emplace_back(rows, best_k);
+                ++m->tuned_changed;
+            }
+        }
+        rc = launch_layer();
         if (rc != RS_OK) return rc;
         prof_mark(m, 1 + i, st);
         if (m->dbg_dst && m->dbg_layer == i) {
@@ -554,6 +609,23 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
     if (rc != RS_OK) return rc;
     prof_mark(m, 0, static_cast<hipStream_t>(stream));
     return forward_impl(m, xn, w.P0, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs, d_logits, stream, true);
+}
+
+int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmin,
+                int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, int32_t* n_changed, void* stream) {
+    if (!m) {
+        set_error("rs_autotune: null model");
+        return RS_ERR_ARG;
+    }
+    const bool prof = m->prof_on;
+    m->prof_on = false;
+    m->tuning = true;
+    m->tuned_changed = 0;
+    const int rc = rs_classify(m, d_sig, d_off, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs, nullptr, stream);
+    m->tuning = false;
+    m->prof_on = prof;
+    if (n_changed) *n_changed = m->tuned_changed;
+    return rc;
 }
 
 int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d_sig, const int64_t* d_off,

@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <utility>
+#include <vector>
+
 #include "../../include/riser_amd.h"
 
 namespace rs {
@@ -54,7 +57,18 @@ struct ConvLayerDev {
     ConvPlan plan;            // packing of d_w follows plan.kc / plan.nch / plan.n_pad
     void* d_w;                // packed weights [n_alloc][nch][3][kc] (f32 or bf16)
     float* d_bias;            // [n_alloc] fp32, zero padded
+    // rs_autotune: the measured-best entry of the kernel's tile-shape table per launch geometry (GEMM rows of the
+    // launch -> shape index), consulted before the cost model; force_shape >= 0 overrides both while tuning
+    int force_shape = -1;
+    std::vector<std::pair<int64_t, int>> tuned;
 };
+
+inline int tuned_shape(const ConvLayerDev& L, int64_t rows) {
+    if (L.force_shape >= 0) return L.force_shape;
+    for (const auto& t : L.tuned)
+        if (t.first == rows) return t.second;
+    return -1;
+}
 
 int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len,
                     int B, int P_in, int layer_index, int num_cu, const float* d_zero, int check_dead,
@@ -84,6 +98,13 @@ int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, co
                            const float* fuse_w0, int fuse_c0);
 int conv_h16_max_bn();
 int conv_f32_max_bn();
+// tile-shape tables of the tiled kernels (rs_autotune): number of entries, and whether entry k can run layer L
+int conv_wino_num_shapes();
+bool conv_wino_shape_ok(const ConvLayerDev& L, int k);
+int conv_wino4_num_shapes();
+bool conv_wino4_shape_ok(const ConvLayerDev& L, int k);
+int conv_h16_num_shapes();                      // shape index + table size * (panel of 64 ? 1 : 0)
+bool conv_h16_shape_ok(const ConvLayerDev& L, int k);
 int conv_f32_kc_max();
 
 int launch_head(const void* d_y, int dtype, int cp, int c, int P_last, int n_layers,

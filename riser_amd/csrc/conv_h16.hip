@@ -439,6 +439,13 @@ int panel_ks(int layer_index) {
 }  // namespace
 
 int conv_h16_max_bn() { return 256; }
+int conv_h16_num_shapes() { return 2 * kNumShapes; }
+bool conv_h16_shape_ok(const ConvLayerDev&, int k) {
+    if (k < 0 || k >= 2 * kNumShapes) return false;
+    const int ks = k / kNumShapes + 1;
+    const Shape& s = kShapes[k % kNumShapes];
+    return s.fn[ks - 1][0] != nullptr && lds_bytes(s, ks) <= 160 * 1024;
+}
 
 int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
                     int layer_index, int num_cu, const void* d_zero, bool f16, int check_dead, hipStream_t st,
@@ -465,6 +472,11 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
                     if (kShapes[k].wm == wm && kShapes[k].wn == wn && kShapes[k].mt == mt && kShapes[k].nt == nt &&
                         lds_bytes(kShapes[k], ks) <= 160 * 1024 && kShapes[k].fn[ks - 1][0])
                         s = &kShapes[k];
+    }
+    if (const int k = tuned_shape(L, rows64); k >= 0 && conv_h16_shape_ok(L, k)) {
+        s = &kShapes[k % kNumShapes];
+        ks = k / kNumShapes + 1;
+        n_panels = (L.plan.nch + ks - 1) / ks;
     }
     if (!s) {
         set_error("conv_h16: no tile shape fits");

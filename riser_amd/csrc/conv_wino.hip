@@ -574,6 +574,11 @@ const Shape* choose_shape(int64_t rows_out, int n16, int kc, int nch, int num_cu
 }  // namespace
 
 int conv_wino_max_bn() { return 256; }
+int conv_wino_num_shapes() { return kNumShapes; }
+bool conv_wino_shape_ok(const ConvLayerDev& L, int k) {
+    return k >= 0 && k < kNumShapes && (L.plan.kc == 16 || L.plan.kc == 20 || L.plan.kc == 24) &&
+           lds_bytes(kShapes[k], L.plan.kc) <= 160 * 1024;
+}
 
 // layer 0 can be folded into this layer's staging when the layer is the shipped net's layer 1
 // (20 input channels = one 20-channel chunk, <= 32 outputs) and a tile spans at most two reads
@@ -615,6 +620,7 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
         for (int k = 0; k < kNumShapes; ++k)
             if (kShapes[k].wm == 8 && kShapes[k].wn == 1 && kShapes[k].mt == 2 && kShapes[k].nt == 2) s = &kShapes[k];
     }
+    if (const int k = tuned_shape(L, rows64); k >= 0 && conv_wino_shape_ok(L, k)) s = &kShapes[k];
     if (!s) {
         set_error("conv_wino: no tile shape fits (kc=%d)", p.kc);
         return RS_ERR_ARG;

@@ -480,6 +480,10 @@ const Shape* choose_shape(int64_t groups, int n16, int kc, int nch, int num_cu, 
 }  // namespace
 
 int conv_wino4_max_bn() { return 256; }
+int conv_wino4_num_shapes() { return kNumShapes; }
+bool conv_wino4_shape_ok(const ConvLayerDev& L, int k) {
+    return k >= 0 && k < kNumShapes && (L.plan.kc == 16 || L.plan.kc == 20) && lds_bytes(kShapes[k], L.plan.kc) <= 160 * 1024;
+}
 
 // planner's estimate (SIMD cycles) of one launch with the best tile shape for this chunk size: lets
 // rs_model_create pick the channel chunk (which fixes the weight packing) with the tile shapes it enables in mind
@@ -515,6 +519,7 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
                         lds_bytes(kShapes[k], p.kc) <= 160 * 1024)
                         s = &kShapes[k];
     }
+    if (const int k = tuned_shape(L, rows64); k >= 0 && conv_wino4_shape_ok(L, k)) s = &kShapes[k];
     if (!s) {
         set_error("conv_wino4: no tile shape fits (kc=%d)", p.kc);
         return RS_ERR_ARG;

@@ -239,6 +239,27 @@ class Model:
         return (probs, logits) if return_logits else probs
 
 
+def _autotune(self, sig_dev: torch.Tensor, off_dev: torch.Tensor, len_dev: torch.Tensor, lens_host: np.ndarray) -> int:
+    """Time every feasible tile shape of each tiled conv layer on this batch (rs_autotune) and keep the measured best
+    for later batches of the same geometry; returns the number of layers whose choice changed.  Optional: call once per
+    deployment batch size (e.g. before a run); results are bit-identical with or without it."""
+    self._check_lengths(lens_host)
+    B, lmax = int(lens_host.shape[0]), int(lens_host.max())
+    if B > self.max_batch(lmax):
+        raise ValueError("autotune: batch exceeds one library call (Model.max_batch)")
+    L = nv.lib()
+    ws = self._ws.get(L.rs_workspace_bytes(self._h, B, lmax))
+    probs = torch.empty((B, 2), dtype=torch.float32, device=self.device)
+    changed = C.c_int32(0)
+    nv.check(L.rs_autotune(self._h, sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), B, int(lens_host.min()),
+                           lmax, ws.data_ptr(), ws.numel(), probs.data_ptr(), C.byref(changed), _stream_ptr(self.device)),
+             "rs_autotune")
+    return changed.value
+
+
+Model.autotune = _autotune
+
+
 def classify_raw_ensemble(models, sig_dev: torch.Tensor, off_dev: torch.Tensor, len_dev: torch.Tensor,
                           lens_host: np.ndarray, out: torch.Tensor = None, decision: torch.Tensor = None,
                           max_len: int = 0, threshold: float = 0.9, mode: int = nv.RS_ENRICH):

@@ -200,6 +200,33 @@ def test_large_ragged_batch_tile_order(dev, dtype):
     m.close()
 
 
+def test_autotune_keeps_results(dev):
+    """rs_autotune (optional tile-shape tuning per batch geometry): fp32 results stay bit-identical whatever it
+    picks; 16-bit results stay within 16-bit round-off (it may switch a layer to 64-channel panels); other batch
+    geometries keep using the launch planner."""
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    B = 160
+    lens = np.full(B, 12000, dtype=np.int32)
+    lens[::5] = 8000
+    sigs = [synth.make_signals(SIG_SEED, 1, int(n), first_read=900 + i)[0] for i, n in enumerate(lens)]
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    for dtype, tol in (("f32w", 0.0), ("f16", 5e-3)):
+        m = Model(synth.make_state_dict(1), synth.Config(), None, "m", dtype=dtype, device=dev)
+        before = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+        small = m.classify_raw(sig, off[:7].contiguous(), ln[:7].contiguous(), lh[:7]).cpu().numpy()
+        changed = m.autotune(sig, off, ln, lh)
+        assert changed >= 0
+        after = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+        assert np.abs(after - before).max() <= tol, (dtype, changed)
+        assert np.array_equal(after, m.classify_raw(sig, off, ln, lh).cpu().numpy())
+        # another geometry is untouched by the tuned entries
+        assert np.array_equal(small, m.classify_raw(sig, off[:7].contiguous(), ln[:7].contiguous(), lh[:7]).cpu().numpy())
+        m.autotune(sig, off, ln, lh)                                           # re-tuning replaces, never accumulates
+        assert np.abs(m.classify_raw(sig, off, ln, lh).cpu().numpy() - before).max() <= tol
+        m.close()
+
+
 def test_stream_classifier_matches_direct(dev):
     """host-resident reads streamed in sub-batches (copy/compute overlap) == one direct call."""
     from riser_amd.model import Model
