@@ -241,6 +241,8 @@ def main():
         proc = SignalProcessor(Kit.create_from_version("RNA004"), device=device)
         ens = [Model(synth.make_state_dict(sd_), synth.Config(), None, t_, dtype="bf16", device=device)
                for sd_, t_ in ((1, "mRNA"), (2, "mtRNA"), (3, "globin"))]
+        for mk in ens:
+            mk.autotune(sig, off, ln, lens)
         pe = torch.empty((3, B, 2), dtype=torch.float32, device=device)
         dec = torch.empty(B, dtype=torch.uint8, device=device)
         from riser_amd.model import classify_raw_ensemble
@@ -248,7 +250,7 @@ def main():
         def ens_step():
             classify_raw_ensemble(ens, sig, off, ln, lens, out=pe, decision=dec, max_len=L, threshold=0.9,
                                   mode=nv.RS_ENRICH)
-        for _ in range(3):
+        for _ in range(max(3, args.warmup)):
             ens_step()
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
@@ -268,7 +270,8 @@ def main():
         mix_len = torch.from_numpy(mix_lens).to(device)
         mm = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype="f16", device=device)
         pm = torch.empty((B, 2), dtype=torch.float32, device=device)
-        for _ in range(3):
+        mm.autotune(sig, mix_off, mix_len, mix_lens)
+        for _ in range(max(3, args.warmup)):
             mm.classify_raw(sig, mix_off, mix_len, mix_lens, out=pm)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
