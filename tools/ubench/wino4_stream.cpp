@@ -46,6 +46,34 @@ __global__ __launch_bounds__(WAVES * 64) void kstream(float* out, int iters) {
     out[blockIdx.x * WAVES * 64 + threadIdx.x] = s;
 }
 
+// same MFMAs as kstream<1, NT, 0>, but two components interleaved per slot pair (j0c0, j0c1, j1c0, j1c1, ...)
+template <int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void kstream_il(float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    f32x4 acc[NT][6];
+    for (int j = 0; j < NT; ++j) for (int q = 0; q < 6; ++q) acc[j][q] = (f32x4){0, 0, 0, 0};
+    float uf[NT], v[6];
+    for (int j = 0; j < NT; ++j) uf[j] = lane * 0.002f + j;
+    for (int q = 0; q < 6; ++q) v[q] = lane * 0.001f + q;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+            for (int cp = 0; cp < 6; cp += 2) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[j][cp] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[j], v[cp], acc[j][cp], 0, 0, 0);
+                    acc[j][cp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[j], v[cp + 1], acc[j][cp + 1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    float s = 0;
+    for (int j = 0; j < NT; ++j) for (int q = 0; q < 6; ++q) s += acc[j][q][0] + acc[j][q][3];
+    out[blockIdx.x * WAVES * 64 + threadIdx.x] = s;
+}
+
 template <class F>
 double timeit(F launch) {
     hipEvent_t e0, e1;
@@ -78,5 +106,14 @@ int main() {
     run<1, 5, 1, 4>(out, iters, "1x5x6 + transform, 4 waves");
     run<2, 2, 1, 4>(out, iters, "2x2x6 + transform, 4 waves");
     run<1, 5, 1, 12>(out, iters, "1x5x6 + transform, 12 waves");
+    run<5, 1, 0, 8>(out, iters, "5x1x6 regs-only, 8 waves");
+    run<1, 4, 0, 8>(out, iters, "1x4x6 regs-only, 8 waves");
+    run<1, 3, 0, 8>(out, iters, "1x3x6 regs-only, 8 waves");
+    run<1, 5, 0, 4>(out, iters, "1x5x6 regs-only, 4 waves");
+    {
+        const double fl = 256.0 * 8 * iters * 24.0 * 5 * 2.0 * 16 * 16 * 4;
+        double ms = timeit([&] { hipLaunchKernelGGL((kstream_il<5, 8>), dim3(256), dim3(512), 0, 0, out, iters); });
+        printf("%-44s %.3f ms %.1f TF (%.3f of 157.3)\n", "1x5x6 regs-only, components interleaved", ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3);
+    }
     return 0;
 }
