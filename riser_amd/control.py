@@ -31,13 +31,42 @@ from .preprocess import pack_reads
 
 _MODE = {"enrich": nv.RS_ENRICH, "deplete": nv.RS_DEPLETE}
 
+# user-visible behaviour of the reference that a drop-in must keep (riser/control.py:100-103, 125-133, 145-148):
+# the operator warnings, the log lines and the CSV schema
+_WARN_START = ('The sequencing run is being controlled by RISER, reads that are '
+               'not in the target class will be ejected from the pore.')
+_WARN_STOP = 'RISER has stopped running.'
+_CSV_COLUMNS = ("batch_start", "read_id", "channel", "sig_length", "models", "prob_targets", "threshold", "mode",
+                "decision")
+_CACHE_LIMIT = 1000                  # poly(A) cache entries before it is dropped (riser/control.py:96-97)
 
-class SequencerControl():
-    def __init__(self, client, models, processor, logger, out_file):
-        self.client = client
-        self.models = models
-        self.proc = processor
+
+class _MinuteTally:
+    """Counts of the current minute and the once-a-minute progress line (riser/control.py:116-123): the line is
+    written by the first batch that STARTS more than 60 s after the previous report."""
+
+    def __init__(self, logger, now):
         self.logger = logger
+        self.due = now + 60
+        self.assessed = self.accepted = self.rejected = 0
+
+    def add(self, assessed, accepted, rejected):
+        self.assessed += assessed
+        self.accepted += accepted
+        self.rejected += rejected
+
+    def report_if_due(self, batch_start):
+        if batch_start <= self.due:
+            return
+        self.logger.info(f"In the last minute {self.assessed} signals were assessed, {self.accepted} were "
+                         f"accepted and {self.rejected} were rejected")
+        self.assessed = self.accepted = self.rejected = 0
+        self.due = batch_start + 60
+
+
+class SequencerControl:
+    def __init__(self, client, models, processor, logger, out_file):
+        self.client, self.models, self.proc, self.logger = client, models, processor, logger
         self.out_filename = out_file
         self.batch_latencies = []          # host wall time per assessed batch (seconds)
 
@@ -112,91 +141,57 @@ class SequencerControl():
 
     # ------------------------------------------------------------------------------------
     def target(self, mode, duration_h, threshold, unblock_duration=0.1):
+        """The run loop (riser/control.py:99-133): one ReadUntil batch per iteration until the client stops or
+        `duration_h` hours have passed; every assessed read becomes a CSV row, rejects are sent first, then every
+        decided read (rejected, accepted, at maximum length) is reported as finished."""
         if mode not in _MODE:
             raise ValueError(f"mode must be 'enrich' or 'deplete', got {mode!r}")
-        self.client.send_warning(
-            'The sequencing run is being controlled by RISER, reads that are '
-            'not in the target class will be ejected from the pore.')
+        client = self.client
+        client.send_warning(_WARN_START)
+        with open(f"{self.out_filename}.csv", "a") as sink:
+            sink.write(",".join(_CSV_COLUMNS) + "\n")
+            t_begin = time.monotonic()
+            t_stop = t_begin + duration_h * 3600
+            tally = _MinuteTally(self.logger, t_begin)
+            cache = {}
+            while client.is_running() and time.monotonic() < t_stop:
+                cache = self._run_batch(sink, mode, threshold, unblock_duration, cache, tally)
+            client.send_warning(_WARN_STOP)
+            if not client.is_running():
+                self.logger.info("Client has stopped.")
+            if time.monotonic() > t_stop:
+                self.logger.info(f"RISER has timed out after {duration_h} hours as requested.")
 
-        with open(f'{self.out_filename}.csv', 'a') as out_file:
-            self._write_header(out_file)
-            run_start = time.monotonic()
-            progress_time = run_start + 60
-            duration_s = self._hours_to_seconds(duration_h)
-            n_assessed = 0
-            n_rejected = 0
-            n_accepted = 0
-            polyA_cache = {}
-            while self.client.is_running() and time.monotonic() < run_start + duration_s:
-                batch_start = time.monotonic()
-                reads_to_reject = []
-                reads_to_accept = []
-                reads_unclassified = []
-                entries = list(self.client.get_read_batch())
-                records = self.assess_batch(entries, mode, threshold, polyA_cache)
-                for channel, read, sig_len, p_on_targets, decision in records:
-                    n_assessed += 1
-                    if decision == "accept":
-                        reads_to_accept.append((channel, self._get_read_id(read)))
-                    elif decision == "reject":
-                        reads_to_reject.append((channel, self._get_read_id(read)))
-                    elif decision == "no_decision":
-                        reads_unclassified.append((channel, self._get_read_id(read)))
-                    self._write(out_file, batch_start, channel, read.id, sig_len, self.models,
-                                p_on_targets, threshold, mode, decision)
-                if len(polyA_cache) >= 1000:
-                    polyA_cache = {}
-
-                # Send reject requests
-                self.client.reject_reads(reads_to_reject, unblock_duration)
-                n_rejected += len(reads_to_reject)
-
-                # Rejected, accepted and max-length reads need no reassessment
-                done = reads_to_reject + reads_to_accept + reads_unclassified
-                self.client.finish_processing_reads(done)
-                n_accepted += len(reads_to_accept)
-                if records:
-                    self.batch_latencies.append(time.monotonic() - batch_start)
-
-                if batch_start > progress_time:
-                    self.logger.info(f"In the last minute {n_assessed} signals "
-                                     f"were assessed, {n_accepted} were "
-                                     f"accepted and {n_rejected} were rejected")
-                    n_assessed = 0
-                    n_rejected = 0
-                    n_accepted = 0
-                    progress_time = batch_start + 60
-            else:
-                self.client.send_warning('RISER has stopped running.')
-                if not self.client.is_running():
-                    self.logger.info('Client has stopped.')
-                if time.monotonic() > run_start + duration_s:
-                    self.logger.info(f'RISER has timed out after {duration_h} '
-                                     'hours as requested.')
+    def _run_batch(self, sink, mode, threshold, unblock_duration, cache, tally):
+        t0 = time.monotonic()
+        records = self.assess_batch(list(self.client.get_read_batch()), mode, threshold, cache)
+        decided = {"reject": [], "accept": [], "no_decision": []}          # "try_again" reads stay with the client
+        targets = ";".join(m.target for m in self.models)
+        for channel, read, n_samples, p_on, decision in records:
+            if decision in decided:
+                decided[decision].append((channel, self._client_key(read)))
+            probs = ";".join(str(float(p)) for p in p_on)
+            sink.write(f"{t0:.0f},{read.id},{channel},{n_samples},{targets},{probs},{threshold},{mode},{decision}\n")
+        if len(cache) >= _CACHE_LIMIT:
+            cache = {}
+        self.client.reject_reads(decided["reject"], unblock_duration)
+        self.client.finish_processing_reads(decided["reject"] + decided["accept"] + decided["no_decision"])
+        if records:
+            self.batch_latencies.append(time.monotonic() - t0)
+        tally.add(len(records), len(decided["accept"]), len(decided["reject"]))
+        tally.report_if_due(t0)
+        return cache
 
     def start(self):
         self.client.start_streaming_reads()
-        self.logger.info('Live read stream started.')
+        self.logger.info("Live read stream started.")
 
     def finish(self):
         self.client.reset()
-        self.logger.info('Client reset and live read stream ended.')
+        self.logger.info("Client reset and live read stream ended.")
 
-    def _hours_to_seconds(self, hours):
-        return hours * 60 * 60
-
-    def _get_read_id(self, read):
-        # minknow-api <= v5 exposes .number, >= v6 only .id (riser/control.py:137-143)
-        if hasattr(read, "number"):
-            return read.number
-        return read.id
-
-    def _write_header(self, csv_file):
-        csv_file.write('batch_start,read_id,channel,sig_length,models,prob_targets,threshold,mode,decision\n')
-
-    def _write(self, csv_file, batch_start, channel, read, sig_length,
-               models, p_on_targets, threshold, mode, decision):
-        csv_file.write(f'{batch_start:.0f},{read},{channel},{sig_length},'
-                       f'{";".join([m.target for m in models])},'
-                       f'{";".join([str(float(p)) for p in p_on_targets])},'
-                       f'{threshold},{mode},{decision}\n')
+    @staticmethod
+    def _client_key(read):
+        """What the ReadUntil client identifies a read by: minknow-api <= v5 has `.number`, >= v6 only `.id`
+        (riser/control.py:137-143)."""
+        return read.number if hasattr(read, "number") else read.id

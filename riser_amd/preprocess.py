@@ -14,29 +14,33 @@ import torch
 
 from . import _native as nv
 
-_OUTLIER_LIMIT = 3.5
-_SCALING_FACTOR = 1.4826
-_MIN_INPUT_SIGNALS = 4096        # constrained by the 12 max-pools of the CNN (riser/preprocess.py:8)
-_MAX_INPUT_NT = 280
-_TRIM_RESOLUTION = 500
-_TRIM_MAD_THRESHOLD = 20
-_TRIM_FIXED_LENGTH_NT = 150.6
+# numbers of the reference (riser/preprocess.py:5-13); the kernels hold their own copies of the first two
+OUTLIER_SIGMA = 3.5              # |y| above this is an outlier
+MAD_TO_SIGMA = 1.4826            # MAD -> standard deviation of a normal distribution
+MIN_SAMPLES = 4096               # 12 MaxPool(2) layers need 2^12 samples for one output position
+MAX_NT = 280                     # longest prefix assessed, in nucleotides
+FIXED_TRIM_NT = 150.6            # adapter + poly(A) estimate when no poly(A) end is found
 MAX_SIGNAL = 65536               # LDS staging limit of the normalise kernel
 
+_KITS = {"RNA002": (3012, 70), "RNA004": (4000, 130)}       # sampling rate [Hz], translocation rate [nt/s]
 
-class Kit():
+
+class Kit:
+    """Sequencing chemistry (riser/preprocess.py:15-30): converts nucleotides to samples."""
+
     def __init__(self, sampling_hz, transloc_rate):
-        self.sampling_hz = sampling_hz
-        self.transloc_rate = transloc_rate
+        self.sampling_hz, self.transloc_rate = sampling_hz, transloc_rate
 
     @classmethod
     def create_from_version(cls, version):
-        if version == "RNA002":
-            return cls(3012, 70)
-        elif version == "RNA004":
-            return cls(4000, 130)
-        else:
-            raise Exception(f"Invalid kit version {version}")
+        try:
+            return cls(*_KITS[version])
+        except KeyError:
+            raise Exception(f"Invalid kit version {version}") from None
+
+    def samples(self, nt) -> int:
+        """nt nucleotides in samples, truncated as the reference does."""
+        return int(nt / self.transloc_rate * self.sampling_hz)
 
 
 def _as_int16(signal) -> np.ndarray:
@@ -65,7 +69,7 @@ def pack_reads(signals, device):
             torch.from_numpy(lens).to(device), lens)
 
 
-class SignalProcessor():
+class SignalProcessor:
     def __init__(self, kit, device=None):
         self.kit = kit
         nv.require_gpu()
@@ -74,25 +78,25 @@ class SignalProcessor():
         d = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
 
-    # ---- constants (riser/preprocess.py:33-40,81-85) --------------------------------------
+    # ---- lengths (riser/preprocess.py:33-40,81-85) ------------------------------------------
     def get_min_length(self):
-        return _MIN_INPUT_SIGNALS
+        return MIN_SAMPLES
 
     def get_max_length(self):
-        return int(_MAX_INPUT_NT / self.kit.transloc_rate * self.kit.sampling_hz)
+        return self.kit.samples(MAX_NT)
 
     def is_max_length(self, signal):
-        return len(signal) >= self.get_max_length()
+        return self.get_max_length() <= len(signal)
 
     def get_fixed_trim_length(self):
-        return int(_TRIM_FIXED_LENGTH_NT / self.kit.transloc_rate * self.kit.sampling_hz)
+        return self.kit.samples(FIXED_TRIM_NT)
 
     def should_trim_fixed_length(self, signal):
-        return len(signal) > self.get_fixed_trim_length() + self.get_max_length()
+        # long enough to leave a full-length window after the fixed trim
+        return len(signal) - self.get_fixed_trim_length() > self.get_max_length()
 
     def trim_polyA_fixed_length(self, signal):
-        trim = self.get_fixed_trim_length()
-        return signal[trim:]
+        return signal[self.get_fixed_trim_length():]
 
     # ---- poly(A) (riser/preprocess.py:42-79,87-102) ---------------------------------------
     def get_polyA_end(self, signal):
@@ -115,19 +119,16 @@ class SignalProcessor():
         return out
 
     def trim_polyA(self, signal, read_id, cache):
-        """If the polyA end can be found, trim polyA + sequencing adapter from the start of
-        the signal (riser/preprocess.py:87-102; found ends are cached per read id)."""
-        trimmed = False
-        if read_id in cache:
-            polyA_end = cache[read_id]
-        else:
-            polyA_end = self.get_polyA_end(signal)
-            if polyA_end:
-                cache[read_id] = polyA_end
-        if polyA_end:
-            signal = signal[polyA_end+1:]
-            trimmed = True
-        return signal, trimmed
+        """-> (signal without adapter + poly(A), True) when a poly(A) end is known for the read, else (signal, False)
+        (riser/preprocess.py:87-102).  Ends that were found are memoised per read id in `cache`."""
+        end = cache.get(read_id)
+        if end is None:
+            end = self.get_polyA_end(signal)
+            if end:
+                cache[read_id] = end
+        if not end:                      # None, or the reference's "0 counts as not found"
+            return signal, False
+        return signal[end + 1:], True
 
     # ---- normalisation (riser/preprocess.py:108-147) --------------------------------------
     def mad_normalise(self, signal):
