@@ -1,26 +1,42 @@
 #!/usr/bin/env python3
 """bench.py - chunks/s of the squiggle-classification hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|f32_direct|bf16|f16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config rna004_b512|promethion|progressive]
+                    [--dtype f32|f32_direct|bf16|f16|bf16x3|f16x3]
 
-One "step" = one pass of the hot path over one batch of 512 synthetic RNA004 4 s chunks
-(512 x 16000 int16 samples, BASELINE.json configs[1]) already resident in HBM:
-MAD-normalise + 12-layer ConvNet forward + softmax, through the C ABI.  The default
-arithmetic is fp32 end to end with the conv layers lowered to Winograd F(2,3) on the f32-input
-MFMA (rs_dtype RS_F32W); --dtype f32_direct runs the direct lowering (exact fmaf chains).  With N > 1 (launched
-by torch.distributed.run, one rank per GPU) every rank steps its own 512-read shard - reads
-are independent, there is no data-path collective - and the printed value is the whole-job
-aggregate over the max-over-ranks time ("scaling": "weak").
+One "step" = one pass of the hot path over one batch of synthetic reads already resident in HBM:
+MAD-normalise + 12-layer ConvNet forward + softmax, through the C ABI.
+
+  --config rna004_b512   (default) BASELINE.json configs[1], the configuration the metric is quoted on: 512 RNA004
+                         4 s chunks (512 x 16000 int16 samples) per GPU and step, fp32 (conv layers lowered to
+                         Winograd F(2,3) / F(4,3) on the f32-input MFMA; --dtype f32_direct = exact fmaf chains)
+  --config promethion    configs[3]: 18 000 x N concurrent 4 s chunks sharded by read id over the N ranks
+                         (riser_amd.dist.shard_indices), every rank walks its HBM-resident shard in sub-batches of
+                         --batch reads; one step = one pass over the shard
+  --config progressive   configs[4]: mixed 2 s / 3 s / 4 s chunks (8000 / 12000 / 16000 samples in equal thirds of
+                         each 512-read batch), fused normalise + conv, f16 unless --dtype says otherwise
+
+Ranks: with WORLD_SIZE in the environment (torch.distributed.run, one rank per GPU) this process is one rank.  With
+--gpus N > 1 and NO WORLD_SIZE the script starts the N ranks itself as child processes (before it makes any GPU
+call) and prints rank 0's line; it fails if fewer than N devices are visible.  Reads are independent: every rank steps
+its own shard, there is no data-path collective; the printed value is the whole-job aggregate over the
+max-over-ranks time ("scaling": "weak").
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline      conv stack (layers 1..11, the MFMA kernel family) achieved TFLOP/s from HIP
-                events recorded on the launch stream during the timed steps
-  cpu_baseline  the oracle's torch-CPU port (reference structure: one read at a time) timed
-                on this box's host cores over a bounded sample (rank 0, N = 1 only)
+  roofline      conv stack (layers 1..11, the MFMA kernel family): `achieved` = the TFLOP/s the matrix pipe really
+                executes (padded tiles; Winograd issues 2/3 resp. 1/2 of the direct convolution's multiplications),
+                from HIP events recorded on the launch stream inside the timed steps; `frac` = achieved / dense MFMA
+                peak of the dtype; `algorithmic_tflops` = the direct convolution's FLOPs over the
+                same time.  `traffic` is null: HBM bytes need rocprofv3 PMC passes (profiles/, named per round).
+  cpu_baseline  the oracle's torch-CPU port timed on this box's host cores over a bounded sample, best of a sweep
+                over thread counts (rank 0, N = 1 only)
+  control_loop  scripted 512-channel ReadUntil batches through the batched SequencerControl: p50 / p99 per batch
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,9 +53,12 @@ SETTLE_STEPS = 25
 BATCH = 512
 CHUNK = 16000
 SIG_SEED = 20260103
-PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md:42
-PEAK_BF16_MFMA_TF = 2500.0    # :43
-PEAK_HBM_GBS = 8000.0         # :36
+READS_PER_GPU = 18000         # BASELINE config 4: 144 k concurrent chunks over 8 GPUs
+LAT_WARMUP, LAT_SAMPLES = 20, 200
+PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md:45
+PEAK_BF16_MFMA_TF = 2500.0    # :46
+LIB_DTYPE = {"f32": "f32w", "f32_direct": "f32"}
+MFMA_PASSES = {"bf16x3": 3, "f16x3": 3}       # split-precision modes issue three 16-bit MFMAs per product
 
 
 def conv_flops_per_chunk(channels, L0):
@@ -52,54 +71,377 @@ def conv_flops_per_chunk(channels, L0):
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=30)    # ~60 ms: the shader clock needs ~20 steps to settle
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f32_direct", "bf16", "f16"])
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="rna004_b512", choices=["rna004_b512", "promethion", "progressive"])
+    ap.add_argument("--dtype", default=None, choices=["f32", "f32_direct", "bf16", "f16", "bf16x3", "f16x3"])
+    ap.add_argument("--batch", type=int, default=None, help="reads per library call (sub-batch for promethion)")
     ap.add_argument("--chunk", type=int, default=CHUNK)
+    ap.add_argument("--reads-per-gpu", type=int, default=READS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=18.0)
     ap.add_argument("--no-latency", action="store_true", help="skip the per-batch latency loop (profiling runs)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the f16 / bf16 / ensemble side measurements")
-    args = ap.parse_args()
+    ap.add_argument("--no-variants", action="store_true", help="skip the 16-bit / ensemble side measurements")
+    ap.add_argument("--no-control-loop", action="store_true", help="skip the ReadUntil replay")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU rehearsal of the rank plumbing (tests)
+    args = ap.parse_args(argv)
+    if args.dtype is None:
+        args.dtype = "f16" if args.config == "progressive" else "f32"
+    if args.batch is None:
+        args.batch = 1024 if args.config == "promethion" else BATCH
+    if args.steps is None:
+        args.steps = 3 if args.config == "promethion" else 50
+    if args.warmup is None:
+        args.warmup = 1 if args.config == "promethion" else 30     # ~60 ms: the shader clock needs ~20 steps to settle
+    return args
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# rank launcher: --gpus N without torchrun
+# ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    """Start N fresh child processes, one rank per GPU, and relay rank 0's JSON line.  The parent makes no GPU
+    call (torch.cuda.device_count() does not initialise the runtime on this image)."""
+    n = args.gpus
+    if not args.stub:
+        ndev = torch.cuda.device_count()
+        if ndev < n:
+            raise SystemExit(f"bench.py: --gpus {n} but only {ndev} ROCm device(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    for line in (out0 or "").splitlines():            # stdout carries the ONE JSON line; anything else (library
+        if line.lstrip().startswith("{"):             # chatter such as gloo's connection notes) goes to stderr
+            print(line, flush=True)
+        elif line.strip():
+            print(line, file=sys.stderr, flush=True)
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py: rank(s) failed: {bad}")
+    return 0
+
+
+def run_stub(args, rank, world):
+    """The rank plumbing without a GPU (tests/test_bench_cpu.py): gloo, a fixed-cost host step, the same barriers,
+    reductions and JSON contract."""
+    rdist.init(backend="gloo")
+    B = args.batch
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    rdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002)
+    rdist.barrier()
+    elapsed = rdist.reduce_scalar(time.perf_counter() - t0, "max")
+    total = rdist.reduce_scalar(B * args.steps, "sum")
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(total / elapsed, 1), "unit": "chunks/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "stub", "config": {"workload": "stub step (rank plumbing rehearsal, no GPU)"}}),
+              flush=True)
+    rdist.finalize()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------
+class Workload:
+    """Resident inputs of one rank + step()."""
+
+    def __init__(self, args, model, device, rank, world):
+        from riser_amd.preprocess import pack_reads
+        self.args, self.model, self.device = args, model, device
+        B, L = args.batch, args.chunk
+        cfg = args.config
+        if cfg == "promethion":
+            # the population is 18 000 x N read ids; this rank owns the ids that hash to it (crc32(id) % N)
+            ids = np.arange(args.reads_per_gpu * world, dtype=np.int64)
+            self.mine = rdist.shard_indices(ids, rank, world)
+            n = int(self.mine.shape[0])
+            base = synth.make_signals(SIG_SEED, 512, L)                  # read i carries the signal of i mod 512
+            sigs = base[self.mine % 512]
+            self.sample_sigs = sigs[: min(n, 512)]
+            self.sig = torch.from_numpy(np.ascontiguousarray(sigs.reshape(-1))).to(device)
+            self.n_reads, self.sub = n, B
+            self.lens_host = np.full(n, L, dtype=np.int32)
+            self.probs = torch.empty((1, n, 2), dtype=torch.float32, device=device)
+            self.calls_per_step = -(-n // B)
+            self.reads_per_step = n
+            self.workload = (f"PromethION-scale population of {args.reads_per_gpu * world} x {L}-sample (4 s) int16 chunks, "
+                             f"sharded by read id over {world} GPU(s) ({n} on rank 0), HBM-resident, walked in sub-batches of "
+                             f"{B}: MAD-normalise + 12-layer ConvNet forward + softmax, {args.dtype}")
+        else:
+            sigs = synth.make_signals(SIG_SEED, B, L, first_read=rank * B)   # each rank owns a different shard
+            self.sample_sigs = sigs
+            self.sig, self.off, self.ln, self.lens_host = pack_reads(list(sigs), device)
+            if cfg == "progressive":
+                self.lens_host = np.array([(L // 2, 3 * L // 4, L)[i % 3] for i in range(B)], dtype=np.int32)
+                self.off = torch.from_numpy(np.arange(B, dtype=np.int64) * L).to(device)
+                self.ln = torch.from_numpy(self.lens_host).to(device)
+            self.probs = torch.empty((B, 2), dtype=torch.float32, device=device)
+            self.calls_per_step = 1
+            self.reads_per_step = B
+            what = (f"mixed {L // 2} / {3 * L // 4} / {L}-sample (2 s / 3 s / 4 s) chunks in equal thirds, fused "
+                    f"normalise + conv" if cfg == "progressive" else f"{L}-sample (4 s) int16 chunks")
+            self.workload = (f"mRNA RNA004 model, batch={B} x {what} resident in HBM, MAD-normalise + 12-layer ConvNet "
+                             f"forward + softmax, {args.dtype}")
+
+    def step(self):
+        if self.args.config == "promethion":
+            from riser_amd.stream import classify_resident
+            classify_resident([self.model], self.sig, self.n_reads, self.args.chunk, self.lens_host, self.sub,
+                              out=self.probs)
+        else:
+            self.model.classify_raw(self.sig, self.off, self.ln, self.lens_host, out=self.probs)
+
+
+def roofline_object(args, model, wl, conv_ms_total, conv_calls, stage_ms, detail_calls):
+    """conv stack = layers 1..n-1.  conv_ms_total: HIP-event time of the conv stack summed over `conv_calls` library
+    calls of the timed region; stage_ms / detail_calls: the per-launch pass."""
+    lib_dtype = LIB_DTYPE.get(args.dtype, args.dtype)
+    L = args.chunk
+    nl = model.n_layers
+    lens = wl.lens_host
+    reads_per_call = wl.reads_per_step / wl.calls_per_step
+    # algorithmic FLOPs of one step: per read, by its own length
+    per_len = {int(n): conv_flops_per_chunk(model.channels, int(n)) for n in np.unique(lens)}
+    layer_flop_step = [sum(per_len[int(n)][i] * int((lens == n).sum()) for n in per_len) for i in range(nl)]
+    conv_flop_step = float(sum(layer_flop_step[1:]))
+    steps_timed = conv_calls / wl.calls_per_step if wl.calls_per_step else 0
+    conv_ms_step = conv_ms_total / steps_timed if steps_timed else 0.0
+    info = model.layer_info()
+    passes = MFMA_PASSES.get(args.dtype, 1)
+    per_layer, executed_step = [], 0.0
+    P0 = model.padded_length(int(lens.max()))
+    for i in range(1, nl):
+        ms = float(stage_ms[1 + i]) / max(detail_calls, 1)                       # per library call
+        rows = wl.reads_per_step * -(-(P0 >> i) // info[i]["gemm_row_div"])       # GEMM rows of a step
+        ex = 2.0 * rows * info[i]["n_pad"] * info[i]["k_pad"] * passes
+        executed_step += ex
+        fl_call = layer_flop_step[i] / wl.calls_per_step
+        per_layer.append({"layer": i, "ms": round(ms, 4),
+                          "algorithmic_tflops": round(fl_call / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+                          "executed_tflops": round(ex / wl.calls_per_step / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+                          "tile": [info[i]["bm"], info[i]["bn"], info[i]["kc"]]})
+    alg_tf = conv_flop_step / (conv_ms_step * 1e-3) / 1e12 if conv_ms_step > 0 else 0.0
+    exe_tf = executed_step / (conv_ms_step * 1e-3) / 1e12 if conv_ms_step > 0 else 0.0
+    peak = PEAK_F32_MFMA_TF if args.dtype in ("f32", "f32_direct") else PEAK_BF16_MFMA_TF
+    f23 = [str(i) for i in range(1, nl) if info[i]["gemm_row_div"] == 2]
+    f43 = [str(i) for i in range(1, nl) if info[i]["gemm_row_div"] == 4]
+    kname = {"f32w": "conv_stream_f32_kernel / conv_wino_kernel / conv_wino4_kernel (Winograd F(2,3) layers %s, F(4,3) "
+                     "layers %s, f32-input MFMA)" % (",".join(f23), ",".join(f43)),
+             "f32": "conv_f32_kernel (direct, f32-input MFMA)"}.get(lib_dtype, "16-bit MFMA conv kernels (%s)" % lib_dtype)
+    conv_ms_detail = float(stage_ms[2:2 + nl - 1].sum()) / max(detail_calls, 1)
+    return {"bound": "mfma", "kernel": kname + f", {nl - 1} launches per call, layers 1-{nl - 1}",
+            "achieved": round(exe_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(exe_tf / peak, 4),
+            "traffic": None,
+            "traffic_note": "HBM bytes are not measurable from inside the run; FETCH_SIZE / WRITE_SIZE passes of this tree "
+                            "are under profiles/ (named per round, with the commit they were taken on)",
+            "achieved_note": "MFMA FLOPs the kernels execute (tile padding included; Winograd F(2,3) issues 2/3, F(4,3) 1/2 "
+                             "of the direct convolution's multiplications; split-precision modes three MFMAs per product) / "
+                             "HIP-event time of the conv stack inside the timed steps",
+            "algorithmic_tflops": round(alg_tf, 2),
+            "algorithmic_note": f"direct-convolution FLOPs of layers 1-{nl - 1} (SURVEY.md 8(d): 582.95 MFLOP per 16000-sample "
+                                "chunk) over the same time; can exceed the MFMA peak under Winograd, so it is not the fraction",
+            "avg_launch_ms": round(conv_ms_step / wl.calls_per_step / (nl - 1), 4) if wl.calls_per_step else None,
+            "conv_stack_ms_per_call": round(conv_ms_step / wl.calls_per_step, 4) if wl.calls_per_step else None,
+            "reads_per_call": round(reads_per_call, 1),
+            "timing_note": "achieved / avg_launch_ms: HIP events around the conv stack inside the timed steps; stage_ms and "
+                           "layers[]: a separate pass with one event per launch (each event adds ~4.5 us of stream time)",
+            "conv_stack_ms_per_launch_events": round(conv_ms_detail, 4),
+            "stage_ms": {"normalise": round(float(stage_ms[0]) / max(detail_calls, 1), 4),
+                         "conv0": round(float(stage_ms[1]) / max(detail_calls, 1), 4),
+                         "conv1_11": round(conv_ms_detail, 4),
+                         "head": round(float(stage_ms[nl + 1]) / max(detail_calls, 1), 4)},
+            "layers": per_layer}
+
+
+def side_variants(args, device, wl, ref):
+    """The same 512-read batch through the other arithmetic modes, the 3-model ensemble (config 3) and the mixed-length
+    batch (config 5): throughput, and distance of the probabilities from the fp32 result of this run."""
+    from riser_amd.model import Model, classify_raw_ensemble
+    from riser_amd import _native as nv
+    B, L = args.batch, args.chunk
+    sig, off, ln, lens = wl.sig, wl.off, wl.ln, wl.lens_host
+    variants = {}
+
+    def timed(fn):
+        for _ in range(max(3, min(args.warmup, 10))):
+            fn()
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t1) / args.steps
+
+    def versus_ref(p):
+        return {"max_abs_dprob_vs_f32": float(np.abs(p - ref).max()),
+                "label_flips_at_0.9_vs_f32": int(((p[:, 1] > 0.9) != (ref[:, 1] > 0.9)).sum())}
+
+    for dt in ("f32", "bf16x3", "f16", "bf16"):
+        if dt not in Model.dtypes():
+            continue
+        mv = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dt, device=device)
+        if dt in ("f16", "bf16"):
+            mv.autotune(sig, off, ln, lens)      # optional per-geometry tile tuning (fp32: the planner's picks stand)
+        pv = torch.empty((B, 2), dtype=torch.float32, device=device)
+        dtv = timed(lambda: mv.classify_raw(sig, off, ln, lens, out=pv))
+        variants["f32_direct" if dt == "f32" else dt] = {
+            "chunks_per_s": round(B / dtv, 1), "ms_per_step": round(dtv * 1e3, 4), "batch": B, **versus_ref(pv.cpu().numpy())}
+        mv.close()
+    # BASELINE config 3: three-model ensemble, normalise once + three forwards + decision on the device
+    for dt in ("bf16x3", "bf16"):
+        if dt not in Model.dtypes():
+            continue
+        ens = [Model(synth.make_state_dict(sd_), synth.Config(), None, t_, dtype=dt, device=device)
+               for sd_, t_ in ((1, "mRNA"), (2, "mtRNA"), (3, "globin"))]
+        if dt == "bf16":
+            for mk in ens:
+                mk.autotune(sig, off, ln, lens)
+        pe = torch.empty((3, B, 2), dtype=torch.float32, device=device)
+        dec = torch.empty(B, dtype=torch.uint8, device=device)
+        dte = timed(lambda: classify_raw_ensemble(ens, sig, off, ln, lens, out=pe, decision=dec, max_len=L,
+                                                  threshold=0.9, mode=nv.RS_ENRICH))
+        variants["ensemble3_" + dt] = {"reads_per_s": round(B / dte, 1), "model_forwards_per_s": round(3 * B / dte, 1),
+                                       "ms_per_step": round(dte * 1e3, 4), "batch": B,
+                                       "accepted": int((dec == 1).sum().item()),
+                                       "model0": versus_ref(pe[0].cpu().numpy())}
+        for mk in ens:
+            mk.close()
+    # BASELINE config 5: progressive 2 s / 3 s / 4 s chunks in equal thirds of one batch, f16: per-read lengths
+    # are carried through every layer, no bucketing
+    mix_lens = np.array([(L // 2, 3 * L // 4, L)[i % 3] for i in range(B)], dtype=np.int32)
+    mix_off = torch.from_numpy((np.arange(B, dtype=np.int64) * L)).to(device)
+    mix_len = torch.from_numpy(mix_lens).to(device)
+    mm = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype="f16", device=device)
+    pm = torch.empty((B, 2), dtype=torch.float32, device=device)
+    mm.autotune(sig, mix_off, mix_len, mix_lens)
+    dtm = timed(lambda: mm.classify_raw(sig, mix_off, mix_len, mix_lens, out=pm))
+    variants["mixed_2s_3s_4s_f16"] = {"chunks_per_s": round(B / dtm, 1), "ms_per_step": round(dtm * 1e3, 4),
+                                      "batch": B, "samples_per_step": int(mix_lens.sum())}
+    mm.close()
+    return variants
+
+
+def control_loop_object(device, dtype):
+    """ReadUntil replay (riser_amd/replay.py): scripted 512-channel batches through the batched SequencerControl
+    with 1 and 3 models; what the 1 s decision window has to cover."""
+    from riser_amd.model import Model
+    from riser_amd.preprocess import Kit, SignalProcessor
+    from riser_amd.replay import run_replay, scripted_batches
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=device)
+    batches = scripted_batches(43, 512)
+    out = {"kit": "RNA004", "channels": 512, "dtype": dtype, "window_s": 1.0,
+           "note": "host wall time per ReadUntil batch from get_read_batch() to the reject / finish calls "
+                   "(riser/control.py:31-106): upload, poly(A) scan, gating, normalise, one forward per model, decision, "
+                   "CSV rows; first 3 batches dropped as warm-up"}
+    for n_models in (1, 3):
+        models = [Model(synth.make_state_dict(s), synth.Config(), None, t, dtype=dtype, device=device)
+                  for s, t in list(zip((1, 2, 3), ("mRNA", "mtRNA", "globin")))[:n_models]]
+        out[f"models_{n_models}"] = run_replay(models, proc, batches)
+        for m in models:
+            m.close()
+    return out
+
+
+def cpu_baseline_object(args, sigs):
+    """The oracle's torch-CPU port (kind "port") on this box's host cores: (A) the reference's structure, one read at a
+    time (riser/control.py:63-69), and (B) the same ops batched at 64; each at several thread counts, best reported."""
+    from oracle import riser_oracle as ro
+    from oracle import torch_path
+    ncpu = os.cpu_count() or 1
+    cpu_model = torch_path.TorchCpuModel(synth.make_state_dict(1))
+    counts = sorted({c for c in (8, 32, ncpu) if 1 <= c <= ncpu})
+    budget = max(args.cpu_seconds, 6.0)
+    per_a, per_b = budget * 0.55 / len(counts), budget * 0.45 / len(counts)
+    B = sigs.shape[0]
+    sweep = {}
+    torch_path.classify_per_read(cpu_model, sigs[:2])                    # warm-up
+    for c in counts:
+        torch.set_num_threads(c)
+        torch_path.classify_per_read(cpu_model, sigs[:1])
+        n_done, t1 = 0, time.perf_counter()
+        while n_done < B and time.perf_counter() - t1 < per_a:
+            torch_path.classify_per_read(cpu_model, sigs[n_done:n_done + 4])
+            n_done += 4
+        dt = time.perf_counter() - t1
+        nb, tb0 = 0, time.perf_counter()
+        while nb < B and time.perf_counter() - tb0 < per_b:
+            xs = np.stack([ro.mad_normalise(s) for s in sigs[nb:nb + 64]]).astype(np.float32)
+            torch.softmax(cpu_model.logits(torch.from_numpy(xs)), dim=1)
+            nb += 64
+        dtb = time.perf_counter() - tb0
+        sweep[str(c)] = {"per_read": round(n_done / dt, 2), "per_read_chunks": n_done,
+                         "batched64": round(nb / dtb, 2), "batched64_chunks": nb}
+    best_a = max(sweep, key=lambda k: sweep[k]["per_read"])
+    best_b = max(sweep, key=lambda k: sweep[k]["batched64"])
+    return {"value": sweep[best_a]["per_read"], "unit": "chunks/s", "cores": int(best_a), "kind": "port",
+            "batched64_value": sweep[best_b]["batched64"], "batched64_cores": int(best_b),
+            "thread_sweep": sweep, "host_logical_cpus": ncpu,
+            "sample": f"the first chunks of the step's batch ({sigs.shape[1]} samples each): per thread count "
+                      f"{per_a:.1f} s one read at a time (numpy MAD-normalise + torch-CPU conv stack at batch 1, the structure "
+                      f"of riser/control.py:63-69) and {per_b:.1f} s at batch 64; best thread count reported"}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)                    # before anything touches the GPU
     rank, local_rank, world = rdist.env_world()
-    if world != max(args.gpus, 1) and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.stub:
+        return run_stub(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU fallback)")
     ndev = torch.cuda.device_count()
+    if world > 1 and ndev < world and not os.environ.get("RS_DIST_BACKEND"):
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} ROCm device(s) visible "
+                         "(RS_DIST_BACKEND=gloo rehearses several ranks on one GPU)")
     device = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(device)
     rdist.init(device=device)
 
     from riser_amd.model import Model
-    from riser_amd.preprocess import pack_reads
 
     B, L = args.batch, args.chunk
-    lib_dtype = {"f32": "f32w", "f32_direct": "f32"}.get(args.dtype, args.dtype)
+    lib_dtype = LIB_DTYPE.get(args.dtype, args.dtype)
+    if lib_dtype not in Model.dtypes():
+        raise SystemExit(f"bench.py: dtype {args.dtype} is not built into this library")
     model = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=lib_dtype, device=device)
-    # each rank owns a different shard of the synthetic read population
-    sigs = synth.make_signals(SIG_SEED, B, L, first_read=rank * B)
-    sig, off, ln, lens = pack_reads(list(sigs), device)
-    probs = torch.empty((B, 2), dtype=torch.float32, device=device)
-
-    def step():
-        model.classify_raw(sig, off, ln, lens, out=probs)
+    wl = Workload(args, model, device, rank, world)
+    step = wl.step
 
     # steady state is what the ReadUntil loop runs in: let the shader clock settle (~20 steps = 40 ms after an idle
     # period) before the W counted warm-up steps, whatever W the caller picked
-    for _ in range(SETTLE_STEPS):
+    for _ in range(SETTLE_STEPS if args.config != "promethion" else 1):
         step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(device)
 
     # ---- timed region: exactly K steps, barrier + sync on both sides ---------------------------
-    # HIP events on the launch stream bracket the conv stack inside the timed steps (coarse level: 4 events per step;
+    # HIP events on the launch stream bracket the conv stack inside the timed steps (coarse level: 4 events per call;
     # one event per launch costs ~4.5 us of stream time each, 3 % of the step - that level runs in a separate pass below)
     model.profile(True, coarse=True)
     rdist.barrier(device)
@@ -110,210 +452,76 @@ def main():
     torch.cuda.synchronize(device)
     rdist.barrier(device)
     elapsed = time.perf_counter() - t0
-    coarse_ms, calls = model.profile_read()
+    coarse_ms, conv_calls = model.profile_read()
     model.profile(False)
     elapsed = rdist.reduce_scalar(elapsed, "max", device)
-    total_chunks = rdist.reduce_scalar(B * args.steps, "sum", device)
-    conv_ms_timed = float(coarse_ms[model.n_layers]) / max(calls, 1)        # layers 1..n-1, per step, from the timed region
+    total_chunks = rdist.reduce_scalar(wl.reads_per_step * args.steps, "sum", device)
+    conv_ms_total = float(coarse_ms[model.n_layers])                       # layers 1..n-1 over the timed region
 
     # per-launch detail (not timed): one event after every kernel
     model.profile(True)
-    for _ in range(max(5, min(args.steps, 20))):
+    for _ in range(max(5, min(args.steps, 20)) if args.config != "promethion" else 1):
         step()
     torch.cuda.synchronize(device)
-    stage_ms, calls = model.profile_read()
+    stage_ms, detail_calls = model.profile_read()
     model.profile(False)
 
     # ---- per-batch latency incl. H2D of the int16 batch and D2H of the probabilities -----------
-    host_sig = torch.from_numpy(np.ascontiguousarray(sigs.reshape(-1))).pin_memory()
-    host_probs = torch.empty((B, 2), dtype=torch.float32).pin_memory()
-    lat = []
-    n_lat = 0 if args.no_latency else max(30, min(200, args.steps * 5))
-    for i in range(n_lat + 5 if n_lat else 0):
-        t1 = time.perf_counter()
-        sig.copy_(host_sig, non_blocking=True)
-        step()
-        host_probs.copy_(probs, non_blocking=True)
-        torch.cuda.synchronize(device)
-        if i >= 5:
-            lat.append(time.perf_counter() - t1)
-    lat_ms = np.asarray(lat if lat else [0.0]) * 1e3
-    p50, p99 = float(np.percentile(lat_ms, 50)), float(np.percentile(lat_ms, 99))
+    p50 = p99 = 0.0
+    n_lat = 0
+    if not args.no_latency and args.config != "promethion":
+        host_sig = torch.from_numpy(np.ascontiguousarray(wl.sample_sigs.reshape(-1))).pin_memory()
+        host_probs = torch.empty((B, 2), dtype=torch.float32).pin_memory()
+        lat = []
+        for i in range(LAT_WARMUP + LAT_SAMPLES):
+            t1 = time.perf_counter()
+            wl.sig.copy_(host_sig, non_blocking=True)
+            step()
+            host_probs.copy_(wl.probs, non_blocking=True)
+            torch.cuda.synchronize(device)
+            if i >= LAT_WARMUP:
+                lat.append(time.perf_counter() - t1)
+        lat_ms = np.asarray(lat) * 1e3
+        n_lat = len(lat)
+        p50, p99 = float(np.percentile(lat_ms, 50)), float(np.percentile(lat_ms, 99))
     p99 = rdist.reduce_scalar(p99, "max", device)
 
     if rank != 0:
         rdist.finalize()
-        return
+        return 0
 
     ms_per_step = elapsed / args.steps * 1e3
     value = total_chunks / elapsed
-
-    # ---- roofline of the conv stack (the MFMA kernel family, layers 1..n-1) --------------------
-    flops = conv_flops_per_chunk(model.channels, L)
-    conv_ms_detail = float(stage_ms[2:2 + model.n_layers - 1].sum()) / max(calls, 1)   # per step, per-launch events
-    conv_ms = conv_ms_timed if conv_ms_timed > 0 else conv_ms_detail             # the timed region's figure
-    conv_flop = sum(flops[1:]) * B
-    achieved_tf = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    peak = PEAK_F32_MFMA_TF if args.dtype in ("f32", "f32_direct") else PEAK_BF16_MFMA_TF
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            with open(pmc_path) as f:
-                traffic = json.load(f).get(lib_dtype, {}).get("conv_stack_hbm_bytes_per_step")
-        except Exception:
-            traffic = None
-    info = model.layer_info()
-    per_layer = []
-    executed_flop = 0.0                    # MFMA FLOPs the kernels really issue: padded tiles, Winograd's 4-for-6
-    for i in range(1, model.n_layers):
-        ms = float(stage_ms[1 + i]) / max(calls, 1)
-        P_in = model.padded_length(L) >> i
-        rows = B * -(-P_in // info[i]["gemm_row_div"])                   # GEMM rows: groups of 2 / 4 conv rows for Winograd
-        executed_flop += 2.0 * rows * info[i]["n_pad"] * info[i]["k_pad"]
-        per_layer.append({"layer": i, "ms": round(ms, 4),
-                          "tflops": round(flops[i] * B / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
-                          "tile": [info[i]["bm"], info[i]["bn"], info[i]["kc"]]})
-    executed_tf = executed_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    f23 = [str(i) for i in range(1, model.n_layers) if info[i]["gemm_row_div"] == 2]
-    f43 = [str(i) for i in range(1, model.n_layers) if info[i]["gemm_row_div"] == 4]
-    kname = {"f32w": "conv_stream_f32_kernel / conv_wino_kernel / conv_wino4_kernel (Winograd F(2,3) layers %s, F(4,3) layers %s, "
-                     "f32-input MFMA)" % (",".join(f23), ",".join(f43)), "f32": "conv_f32_kernel (direct, f32-input MFMA)"}.get(
-        lib_dtype, "conv_h16_kernel (%s MFMA)" % lib_dtype)
-    roofline = {"bound": "mfma", "kernel": kname + ", 11 launches/step, layers 1-11",
-                "achieved": round(achieved_tf, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved_tf / peak, 4), "traffic": traffic,
-                "achieved_note": "algorithmic FLOPs of the direct convolution (SURVEY.md 8(d): 582.95 MFLOP per chunk in "
-                                 "layers 1-11) / measured time; Winograd F(2,3) issues 2/3 of them on the matrix pipe, F(4,3) 1/2",
-                "executed_mfma_tflops": round(executed_tf, 2), "executed_mfma_frac": round(executed_tf / peak, 4),
-                "avg_launch_ms": round(conv_ms / (model.n_layers - 1), 4),
-                "timing_note": "achieved / avg_launch_ms: HIP events around the conv stack inside the timed steps; stage_ms and "
-                               "layers[]: a separate pass with one event per launch (each event adds ~4.5 us of stream time)",
-                "conv_stack_ms_per_launch_events": round(conv_ms_detail, 4),
-                "stage_ms": {"normalise": round(float(stage_ms[0]) / max(calls, 1), 4),
-                             "conv0": round(float(stage_ms[1]) / max(calls, 1), 4),
-                             "conv1_11": round(conv_ms_detail, 4),
-                             "head": round(float(stage_ms[model.n_layers + 1]) / max(calls, 1), 4)},
-                "layers": per_layer}
-
     out = {
         "metric": "signal chunks classified/sec (RNA004 4 s chunks, batch=512)",
         "value": round(value, 1), "unit": "chunks/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32" if lib_dtype in ("f32", "f32w") else lib_dtype,
         "data": "synthetic",
-        "config": {"workload": f"mRNA RNA004 model, batch={B} x {L}-sample (4 s) int16 chunks resident in HBM, "
-                               f"MAD-normalise + 12-layer ConvNet forward + softmax, {args.dtype}",
+        "config": {"workload": wl.workload, "name": args.config,
                    "conv_algorithm": {"f32w": "winograd_f23_f43_fp32", "f32": "direct_fp32"}.get(lib_dtype, "direct_" + lib_dtype),
-                   "batch_per_gpu": B, "chunk_samples": L, "sharding": "reads by id across GPUs, no collectives"},
-        "p50_batch_latency_ms": round(p50, 3), "p99_batch_latency_ms": round(p99, 3),
-        "latency_note": "host wall time per 512-read batch incl. H2D of int16 signals from pinned memory and D2H of probabilities",
-        "roofline": roofline,
+                   "batch_per_call": B, "reads_per_gpu_per_step": wl.reads_per_step, "chunk_samples": L,
+                   "sharding": "reads by id across GPUs, no collectives"},
+        "p50_batch_latency_ms": round(p50, 3), "p99_batch_latency_ms": round(p99, 3), "latency_samples": n_lat,
+        "latency_note": f"host wall time per {B}-read batch incl. H2D of int16 signals from pinned memory and D2H of "
+                        f"probabilities; {LAT_SAMPLES} batches after {LAT_WARMUP} warm-up (kernel loop + PCIe; the ReadUntil "
+                        "loop's own latency is control_loop)",
+        "roofline": roofline_object(args, model, wl, conv_ms_total, conv_calls, stage_ms, detail_calls),
     }
 
+    single = world == 1 and args.config == "rna004_b512"
     # ---- side measurements on the same batch (rank 0, N = 1 only; not the headline) --------------
-    if world == 1 and not args.no_variants and args.dtype == "f32":
-        ref = probs.cpu().numpy().copy()
-        variants = {}
-        for dt in ("f32", "f16", "bf16"):
-            mv = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dt, device=device)
-            if dt in ("f16", "bf16"):
-                mv.autotune(sig, off, ln, lens)      # optional per-geometry tile tuning (fp32: the planner's picks stand)
-            pv = torch.empty((B, 2), dtype=torch.float32, device=device)
-            for _ in range(max(2, args.warmup)):
-                mv.classify_raw(sig, off, ln, lens, out=pv)
-            torch.cuda.synchronize(device)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                mv.classify_raw(sig, off, ln, lens, out=pv)
-            torch.cuda.synchronize(device)
-            dtv = (time.perf_counter() - t1) / args.steps
-            pvh = pv.cpu().numpy()
-            variants["f32_direct" if dt == "f32" else dt] = {
-                "chunks_per_s": round(B / dtv, 1), "ms_per_step": round(dtv * 1e3, 4),
-                "max_abs_dprob_vs_f32": float(np.abs(pvh - ref).max()),
-                "label_flips_at_0.9_vs_f32": int(((pvh[:, 1] > 0.9) != (ref[:, 1] > 0.9)).sum()),
-                "batch": B}
-            mv.close()
-        # BASELINE config 3: three-model ensemble, bf16, normalise once + three forwards + decision
-        from riser_amd.preprocess import Kit, SignalProcessor
-        from riser_amd import _native as nv
-        proc = SignalProcessor(Kit.create_from_version("RNA004"), device=device)
-        ens = [Model(synth.make_state_dict(sd_), synth.Config(), None, t_, dtype="bf16", device=device)
-               for sd_, t_ in ((1, "mRNA"), (2, "mtRNA"), (3, "globin"))]
-        for mk in ens:
-            mk.autotune(sig, off, ln, lens)
-        pe = torch.empty((3, B, 2), dtype=torch.float32, device=device)
-        dec = torch.empty(B, dtype=torch.uint8, device=device)
-        from riser_amd.model import classify_raw_ensemble
-
-        def ens_step():
-            classify_raw_ensemble(ens, sig, off, ln, lens, out=pe, decision=dec, max_len=L, threshold=0.9,
-                                  mode=nv.RS_ENRICH)
-        for _ in range(max(3, args.warmup)):
-            ens_step()
-        torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            ens_step()
-        torch.cuda.synchronize(device)
-        dte = (time.perf_counter() - t1) / args.steps
-        variants["ensemble3_bf16"] = {"reads_per_s": round(B / dte, 1), "model_forwards_per_s": round(3 * B / dte, 1),
-                                      "ms_per_step": round(dte * 1e3, 4), "batch": B,
-                                      "accepted": int((dec == 1).sum().item())}
-        for mk in ens:
-            mk.close()
-        # BASELINE config 5: progressive 2 s / 3 s / 4 s chunks (8000 / 12000 / 16000 samples in equal
-        # thirds of one batch), f16: per-read lengths are carried through every layer, no bucketing
-        mix_lens = np.array([(8000, 12000, 16000)[i % 3] for i in range(B)], dtype=np.int32)
-        mix_off = torch.from_numpy((np.arange(B, dtype=np.int64) * L)).to(device)
-        mix_len = torch.from_numpy(mix_lens).to(device)
-        mm = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype="f16", device=device)
-        pm = torch.empty((B, 2), dtype=torch.float32, device=device)
-        mm.autotune(sig, mix_off, mix_len, mix_lens)
-        for _ in range(max(3, args.warmup)):
-            mm.classify_raw(sig, mix_off, mix_len, mix_lens, out=pm)
-        torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            mm.classify_raw(sig, mix_off, mix_len, mix_lens, out=pm)
-        torch.cuda.synchronize(device)
-        dtm = (time.perf_counter() - t1) / args.steps
-        variants["mixed_2s_3s_4s_f16"] = {"chunks_per_s": round(B / dtm, 1), "ms_per_step": round(dtm * 1e3, 4),
-                                          "batch": B, "samples_per_step": int(mix_lens.sum())}
-        mm.close()
-        out["variants"] = variants
-
+    if single and not args.no_variants and args.dtype == "f32":
+        out["variants"] = side_variants(args, device, wl, wl.probs.cpu().numpy().copy())
+    if single and not args.no_control_loop:
+        out["control_loop"] = control_loop_object(device, lib_dtype)
     # ---- CPU baseline (rank 0, N = 1 only): oracle port timed on this box's host cores ---------
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import torch_path
-        cpu_model = torch_path.TorchCpuModel(synth.make_state_dict(1))
-        torch_path.classify_per_read(cpu_model, sigs[:2])                    # warm-up
-        n_done, t1 = 0, time.perf_counter()
-        while n_done < B and time.perf_counter() - t1 < args.cpu_seconds:
-            torch_path.classify_per_read(cpu_model, sigs[n_done:n_done + 8])
-            n_done += 8
-        dt = time.perf_counter() - t1
-        # second figure: the same torch-CPU conv stack at batch 64 - what the reference's ops give
-        # when its per-read loop is batched; normalisation stays per read (numpy), as the reference has no batched form
-        from oracle import riser_oracle as ro
-        nb, tb0 = 0, time.perf_counter()
-        while nb < 128 and time.perf_counter() - tb0 < max(4.0, args.cpu_seconds / 2):
-            xs = np.stack([ro.mad_normalise(s) for s in sigs[nb:nb + 64]]).astype(np.float32)
-            torch.softmax(cpu_model.logits(torch.from_numpy(xs)), dim=1)
-            nb += 64
-        dtb = time.perf_counter() - tb0
-        out["cpu_baseline"] = {"value": round(n_done / dt, 2), "unit": "chunks/s",
-                               "batched64_value": round(nb / dtb, 2),
-                               "batched64_note": f"{nb} chunks through the same torch-CPU ops at batch 64 (+ per-read numpy "
-                                                 f"normalise), {dtb:.1f} s",
-                               "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"first {n_done} of the step's {B} chunks ({L} samples each), one read at a "
-                                         f"time: numpy MAD-normalise + torch-CPU conv stack at batch 1 "
-                                         f"(structure of riser/control.py:63-69), {dt:.1f} s; host has {os.cpu_count()} logical CPUs"}
+    if single and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_object(args, wl.sample_sigs)
     print(json.dumps(out), flush=True)
     rdist.finalize()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -190,6 +190,8 @@ int rs_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, i
  * window MAD <= 20, end at the first later window with MAD > 20.
  *   d_end     int32 [B]: the end index (a multiple of 500) or -1 where the reference
  *             returns None
+ * Reads may have any length (the whole signal is scanned, as the reference does; the scan stops at the first end
+ * found, which nothing later in the signal can change).
  */
 int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B,
                  int32_t* d_end, void* stream);

@@ -21,6 +21,7 @@ never changes results; it is cleared at batch granularity once it holds >= 1000 
 from __future__ import annotations
 
 import time
+from collections import deque
 
 import numpy as np
 import torch
@@ -68,7 +69,8 @@ class SequencerControl:
     def __init__(self, client, models, processor, logger, out_file):
         self.client, self.models, self.proc, self.logger = client, models, processor, logger
         self.out_filename = out_file
-        self.batch_latencies = []          # host wall time per assessed batch (seconds)
+        # host wall time of the most recent assessed batches (seconds): bounded, a run lasts tens of hours
+        self.batch_latencies = deque(maxlen=4096)
 
     # ------------------------------------------------------------------------------------
     def assess_batch(self, entries, mode, threshold, polyA_cache):

@@ -27,6 +27,33 @@ int hip_fail(hipError_t e, const char* what) {
     return RS_ERR_HIP;
 }
 
+Hooks Hooks::from_env() {
+    Hooks h;
+    auto flag = [](const char* n) { return getenv(n) != nullptr; };
+    auto text = [](const char* n, char* dst, size_t cap) {
+        if (const char* e = getenv(n)) {
+            strncpy(dst, e, cap - 1);
+            dst[cap - 1] = 0;
+        }
+    };
+    h.no_rect_order = flag("RS_NO_RECT_ORDER");
+    h.no_fuse0 = flag("RS_NO_FUSE0");
+    h.no_stream_f32 = flag("RS_NO_STREAM_F32");
+    h.no_stream_h16 = flag("RS_NO_STREAM_H16");
+    h.conv_stamps = flag("RS_CONV_STAMPS");
+    text("RS_FORCE_SHAPE_F32", h.force_f32, sizeof(h.force_f32));
+    text("RS_FORCE_SHAPE_WINO", h.force_wino, sizeof(h.force_wino));
+    text("RS_FORCE_SHAPE_WINO4", h.force_wino4, sizeof(h.force_wino4));
+    text("RS_FORCE_SHAPE_H16", h.force_h16, sizeof(h.force_h16));
+    text("RS_H16_PANEL", h.h16_panel, sizeof(h.h16_panel));
+    return h;
+}
+
+const Hooks& default_hooks() {
+    static const Hooks h;
+    return h;
+}
+
 }  // namespace rs
 
 using namespace rs;
@@ -36,6 +63,7 @@ struct rs_model {
     void* dbg_dst = nullptr;
     size_t dbg_bytes = 0;
     int dbg_layer = -1;
+    Hooks hooks;                          // RS_* switches, read once in rs_model_create
     int device = 0;
     int dtype = RS_F32;
     int n_layers = 0;
@@ -263,13 +291,15 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             set_error("rs_model_create: bad layer %d", i);
             return RS_ERR_ARG;
         }
-    RS_HIP(hipSetDevice(device));
+    DeviceGuard guard(device);            // the caller's current device is restored on return
+    RS_HIP(guard.err);
     rs_model* m = new (std::nothrow) rs_model();
     if (!m) {
         set_error("rs_model_create: out of host memory");
         return RS_ERR_OOM;
     }
     m->device = device;
+    m->hooks = Hooks::from_env();
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
@@ -294,6 +324,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
     }
     for (int i = 1; i < n_layers && rc == RS_OK; ++i) {
         ConvLayerDev& L = m->layers[i];
+        L.hooks = &m->hooks;
         L.c_in = channels[i - 1];
         L.c_out = channels[i];
         L.cp_in = m->cp[i - 1];
@@ -398,7 +429,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
 
 int rs_model_destroy(rs_model* m) {
     if (!m) return RS_OK;
-    (void)hipSetDevice(m->device);
+    DeviceGuard guard(m->device);
     if (m->d_w0) (void)hipFree(m->d_w0);
     for (int i = 1; i < m->n_layers; ++i) {
         if (m->layers[i].d_w) (void)hipFree(m->layers[i].d_w);
@@ -472,6 +503,8 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         set_error("rs_forward: batch too large, split it (B * pitch = %lld)", (long long)B * w.P0);
         return RS_ERR_ARG;
     }
+    DeviceGuard guard(m->device);         // launches go to the model's device whatever the caller's current one is
+    RS_HIP(guard.err);
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(d_ws);
     void* buf[2] = {ws + w.bufa_off, ws + w.bufb_off};
@@ -602,6 +635,8 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
         set_error("rs_classify: workspace %zu < required %zu", ws_bytes, w.total);
         return RS_ERR_WORKSPACE;
     }
+    DeviceGuard guard(m->device);
+    RS_HIP(guard.err);
     float* xn = reinterpret_cast<float*>(static_cast<char*>(d_ws) + w.xnorm_off);
     prof_mark(m, -1, static_cast<hipStream_t>(stream));
     int rc = launch_normalise(d_sig, d_off, d_len, B, Lmax, xn, w.P0, w.P0, nullptr, 0, nullptr,
@@ -657,6 +692,8 @@ int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d
         return RS_ERR_WORKSPACE;
     }
     const WsLayout w = ws_layout(m0, B, Lmax);
+    DeviceGuard guard(m0->device);
+    RS_HIP(guard.err);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* xn = reinterpret_cast<float*>(static_cast<char*>(d_ws) + w.xnorm_off);
     prof_mark(m0, -1, st);

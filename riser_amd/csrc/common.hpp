@@ -30,6 +30,44 @@ __device__ __forceinline__ const_len_ptr as_const_len(const int32_t* p) {
     return (const_len_ptr)(uintptr_t)p;
 }
 
+// Restore the caller's current HIP device on scope exit: model construction / destruction and the launch entry
+// points switch to the model's device without leaking that choice into the host program (torch keeps its own
+// notion of the current device; Model.__del__ may run at any point of it).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// Tuning / diagnostic switches.  The RS_* environment variables are read ONCE, when a model is
+// created (rs_model_create), never on the launch path.
+struct Hooks {
+    bool no_rect_order = false;      // RS_NO_RECT_ORDER: n-major tile order instead of XCD rectangles
+    bool no_fuse0 = false;           // RS_NO_FUSE0: layer 0 as its own launch on the fp32 Winograd path
+    bool no_stream_f32 = false;      // RS_NO_STREAM_F32 / _H16: tiled kernels instead of the streaming ones
+    bool no_stream_h16 = false;
+    bool conv_stamps = false;        // RS_CONV_STAMPS: in-kernel clock stamps of the direct fp32 kernel
+    char force_f32[256] = "";        // RS_FORCE_SHAPE_F32 / _WINO / _WINO4 / _H16: "layer:wm,wn,mt,nt;..."
+    char force_wino[256] = "";
+    char force_wino4[256] = "";
+    char force_h16[256] = "";
+    char h16_panel[128] = "";        // RS_H16_PANEL: "64" or "layer:64;..."
+    static Hooks from_env();
+};
+const Hooks& default_hooks();
+
 constexpr int kMaxLayers = 16;
 constexpr int kMaxNormLen = 65536;
 
@@ -61,6 +99,7 @@ struct ConvLayerDev {
     // launch -> shape index), consulted before the cost model; force_shape >= 0 overrides both while tuning
     int force_shape = -1;
     std::vector<std::pair<int64_t, int>> tuned;
+    const Hooks* hooks = &default_hooks();    // the owning model's switches
 };
 
 inline int tuned_shape(const ConvLayerDev& L, int64_t rows) {

@@ -518,7 +518,7 @@ int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const i
     }
     const int n16 = round_up(L.c_out, 16) / 16;
     const Shape* s = choose_shape(rows64, n16, p.kc, p.nch, num_cu, nullptr);
-    if (const char* force = getenv("RS_FORCE_SHAPE_F32")) {         // tuning aid: "layer:wm,wn,mt,nt;..."
+    if (const char* force = L.hooks->force_f32; *force) {         // tuning aid: "layer:wm,wn,mt,nt;..."
         int l, wm, wn, mt, nt;
         for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
             if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
@@ -554,9 +554,9 @@ int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const i
     const int n_mtiles = (a.rows_in + BM - 1) / BM, n_ntiles = (n16 * 16 + BN - 1) / BN;
     const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, BM, 3.0 * BN, check_dead);
+    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, BM, 3.0 * BN, check_dead, !L.hooks->no_rect_order);
     static unsigned long long* d_stamps = nullptr;
-    static const bool want_stamps = getenv("RS_CONV_STAMPS") != nullptr;
+    const bool want_stamps = L.hooks->conv_stamps;
     if (want_stamps && !d_stamps) RS_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), 4096 * 4 * 8));
     a.stamps = want_stamps ? d_stamps : nullptr;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(s->wm * s->wn * 64), lds, st, a);

@@ -426,8 +426,8 @@ const Shape* choose_shape(int64_t rows, int n16, int n_panels, int num_cu, int k
 }
 
 // panel width of a layer: RS_H16_PANEL = "64" / "32" forces it for every tiled layer, "l:w;l:w" per layer
-int panel_ks(int layer_index) {
-    if (const char* e = getenv("RS_H16_PANEL")) {
+int panel_ks(const Hooks& hooks, int layer_index) {
+    if (const char* e = hooks.h16_panel; *e) {
         if (!strchr(e, ':')) return atoi(e) == 64 ? 2 : 1;
         int l, w;
         for (const char* q = e; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
@@ -456,7 +456,7 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
         return RS_ERR_ARG;
     }
     const int n16 = round_up(L.c_out, 16) / 16;
-    int ks = panel_ks(layer_index);
+    int ks = panel_ks(*L.hooks, layer_index);
     int n_panels = (L.plan.nch + ks - 1) / ks;                      // plan.nch counts 32-channel panels
     const Shape* s = choose_shape(rows64, n16, n_panels, num_cu, ks);
     if (!s && ks == 2) {
@@ -464,7 +464,7 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
         n_panels = L.plan.nch;
         s = choose_shape(rows64, n16, n_panels, num_cu, ks);
     }
-    if (const char* force = getenv("RS_FORCE_SHAPE_H16")) {         // tuning aid: "layer:wm,wn,mt,nt;..."
+    if (const char* force = L.hooks->force_h16; *force) {         // tuning aid: "layer:wm,wn,mt,nt;..."
         int l, wm, wn, mt, nt;
         for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
             if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
@@ -508,7 +508,7 @@ int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int
     const int n_mtiles = (a.rows_in + BM - 1) / BM, n_ntiles = (n16 * 16 + BN - 1) / BN;
     const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, BM, 3.0 * BN, check_dead);
+    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, BM, 3.0 * BN, check_dead, !L.hooks->no_rect_order);
     KernelFn fn = s->fn[ks - 1][f16 ? 1 : 0];
     RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));

@@ -232,7 +232,7 @@ using KernelFn = void (*)(const StreamF32Args);
 // at most 32 outputs, and an output slot of at least 16 rows
 bool conv_stream_f32_ok(const ConvLayerDev& L1, int c0, int P_in1) {
     return L1.cp_in == 20 && c0 <= 20 && L1.plan.kc == 20 && L1.plan.nch == 1 && L1.c_out <= 32 && P_in1 >= 64 &&
-           getenv("RS_NO_STREAM_F32") == nullptr;
+           !L1.hooks->no_stream_f32;
 }
 
 int launch_conv_stream_f32(const ConvLayerDev& L1, const float* d_xs, const float* d_w0, int c0, float* d_y,

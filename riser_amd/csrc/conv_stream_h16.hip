@@ -297,7 +297,7 @@ KernelFn pick(int nt, bool f16) {
 
 // a layer qualifies when its input is one MFMA k-step wide and its weights fit the register budget
 bool conv_stream_h16_ok(const ConvLayerDev& L, int P_in) {
-    return L.cp_in <= 32 && L.plan.nch == 1 && L.c_out <= 48 && P_in >= 32 && getenv("RS_NO_STREAM_H16") == nullptr;
+    return L.cp_in <= 32 && L.plan.nch == 1 && L.c_out <= 48 && P_in >= 32 && !L.hooks->no_stream_h16;
 }
 
 int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,

@@ -584,7 +584,7 @@ bool conv_wino_shape_ok(const ConvLayerDev& L, int k) {
 // (20 input channels = one 20-channel chunk, <= 32 outputs) and a tile spans at most two reads
 bool conv_wino_can_fuse0(const ConvLayerDev& L, int P_in) {
     return L.cp_in == 20 && L.plan.kc == 20 && L.plan.nch == 1 && L.c_out <= kFusedBN && P_in >= 2 * kFusedBMP + 2 &&
-           getenv("RS_NO_FUSE0") == nullptr;
+           !L.hooks->no_fuse0;
 }
 
 int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
@@ -602,7 +602,7 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
     }
     const int n16 = round_up(L.c_out, 16) / 16;
     const Shape* s = choose_shape(rows64 / 2, n16, p.kc, p.nch, num_cu, nullptr);
-    if (const char* force = getenv("RS_FORCE_SHAPE_WINO")) {        // tuning aid: "layer:wm,wn,mt,nt;..."
+    if (const char* force = L.hooks->force_wino; *force) {        // tuning aid: "layer:wm,wn,mt,nt;..."
         int l, wm, wn, mt, nt;
         for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
             if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
@@ -671,7 +671,7 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
     const int n_mtiles = (a.rows_out + BMP - 1) / BMP, n_ntiles = (n16 * 16 + BN - 1) / BN;
     const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 2.0 * BMP, 4.0 * BN, check_dead);
+    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 2.0 * BMP, 4.0 * BN, check_dead, !L.hooks->no_rect_order);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, a);
     RS_HIP(hipGetLastError());
     if (bm_out) *bm_out = 2 * BMP;          // reported in conv rows, like the direct kernels

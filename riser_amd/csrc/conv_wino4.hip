@@ -510,7 +510,7 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
     const int n16 = round_up(L.c_out, 16) / 16;
     const int64_t groups = (rows64 + 3) / 4;
     const Shape* s = choose_shape(groups, n16, p.kc, p.nch, num_cu, nullptr);
-    if (const char* force = getenv("RS_FORCE_SHAPE_WINO4")) {       // tuning aid: "layer:wm,wn,mt,nt;..."
+    if (const char* force = L.hooks->force_wino4; *force) {       // tuning aid: "layer:wm,wn,mt,nt;..."
         int l, wm, wn, mt, nt;
         for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
             if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
@@ -549,7 +549,7 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
     const int n_mtiles = (a.n_groups + BG - 1) / BG, n_ntiles = (n16 * 16 + BN - 1) / BN;
     const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 4.0 * BG, 6.0 * BN, check_dead);
+    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 4.0 * BG, 6.0 * BN, check_dead, !L.hooks->no_rect_order);
     const size_t lds = lds_bytes(*s, p.kc);
     KernelFn fn = s->fn[p.kc == 16 ? 0 : 1];
     RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,

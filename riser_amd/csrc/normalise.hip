@@ -14,9 +14,12 @@
 // later pass (two selects, the threshold test, the division pass) runs out of LDS.
 #include "common.hpp"
 
+#include <atomic>
+
 namespace rs {
 namespace {
 
+constexpr int kMaxDevices = 64;
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int kBins = 4096;            // 8 bins per thread
@@ -295,11 +298,15 @@ int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* 
         return RS_ERR_LENGTH;
     }
     const size_t lds = (size_t)kBins * 4 + 512 + (size_t)round_up(Lmax + 8, 8) * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the > 64 KiB dynamic-LDS limit is a per-DEVICE function attribute: raise it once on every device that
+    // launches the kernel (a process may hold models on several GPUs)
+    static std::atomic<bool> attr_set[kMaxDevices];
+    int dev = 0;
+    RS_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices || !attr_set[dev].load(std::memory_order_acquire)) {
         RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(normalise_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        if (dev >= 0 && dev < kMaxDevices) attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(normalise_kernel, dim3(B), dim3(kThreads), lds, st, d_sig, d_off, d_len, d_out32, ld32,
                        pad_to, d_out64, ld64, d_stats, Lmax, zero_prefix);

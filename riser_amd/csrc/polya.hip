@@ -3,14 +3,14 @@
 // it (bitonic, 512 int keys in LDS, padded with +inf) to get the exact median, sorts the
 // integer deviations |2x - 2med| to get the exact MAD, and records the window sum; one
 // lane then replays the reference's sequential start/end rule over the window table in
-// fp64 with the reference's operation order.
+// fp64 with the reference's operation order.  No length limit: the table is filled in passes.
 #include "common.hpp"
 
 namespace rs {
 namespace {
 
 constexpr int kWin = 500;                          // _TRIM_RESOLUTION
-constexpr int kMaxWin = kMaxNormLen / kWin + 1;
+constexpr int kChunkWin = 128;                     // windows per pass over the table (64000 samples)
 constexpr int kPad = 0x7fffffff;
 
 __device__ __forceinline__ void bitonic512(int* keys, int lane) {
@@ -33,65 +33,89 @@ __device__ __forceinline__ void bitonic512(int* keys, int lane) {
     }
 }
 
+// Reads of ANY length (an AccumulatingCache read grows for as long as the strand is in the pore): the window table is
+// filled in passes of kChunkWin windows; after each pass one lane replays the reference's sequential rule over the
+// pass, carrying (start, end) and the sums of the last two windows (the 1000-sample rolling mean) into the next one.
+// Once an end is found nothing later can change it (riser/preprocess.py:66 sets it only while it is None), so the
+// scan stops there.
 __global__ __launch_bounds__(256) void polya_kernel(const int16_t* __restrict__ sig, const int64_t* __restrict__ off,
                                                     const int32_t* __restrict__ len, int32_t* __restrict__ out) {
     __shared__ int keys[4][512];
-    __shared__ int wsum[kMaxWin];
-    __shared__ int wmad4[kMaxWin];
+    __shared__ int wsum[kChunkWin + 2];            // [0], [1]: the two windows before the pass
+    __shared__ int wmad4[kChunkWin];
+    __shared__ int state[2];                       // start, end (-1: none yet)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = min(len[b], kMaxNormLen);
+    const int n = len[b];
     const int16_t* src = sig + off[b];
     const int nw = n / kWin;
     int* K = keys[wave];
-    for (int w0 = 0; w0 < nw; w0 += 4) {
-        const int w = w0 + wave;
-        const bool act = w < nw;
-        int s = 0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = lane + 64 * u;
-            int v = kPad;
-            if (act && i < kWin) {
-                v = src[w * kWin + i];
-                s += v;
-            }
-            K[i] = v;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-        __syncthreads();
-        bitonic512(K, lane);
-        const int sum2 = K[kWin / 2 - 1] + K[kWin / 2];            // 2 * median
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = lane + 64 * u;
-            const int v = K[i];
-            K[i] = (v == kPad) ? kPad : abs(2 * v - sum2);
-        }
-        __syncthreads();
-        bitonic512(K, lane);
-        if (act && lane == 0) {
-            wsum[w] = s;
-            wmad4[w] = K[kWin / 2 - 1] + K[kWin / 2];              // 4 * MAD
-        }
-        __syncthreads();
-    }
     if (tid == 0) {
-        int start = -1, end = -1;
-        for (int w = 0; w < nw; ++w) {
-            const int i = w * kWin;
-            const double mad = (double)wmad4[w] * 0.25;
-            const double mean = (double)wsum[w] / 500.0;
-            double rolling = mean;
-            if (i > 2 * kWin) rolling = (double)(wsum[w - 2] + wsum[w - 1]) / 1000.0;
-            const double change = (mean - rolling) / rolling * 100.0;
-            // `not polyA_start` is also true for index 0 (riser/preprocess.py:62)
-            if (start <= 0 && change > 20.0 && mad <= 20.0) start = i;
-            if (start > 0 && end <= 0 && mad > 20.0) end = i;
-        }
-        out[b] = end > 0 ? end : -1;
+        state[0] = -1;
+        state[1] = -1;
     }
+    __syncthreads();
+    for (int c0 = 0; c0 < nw; c0 += kChunkWin) {
+        const int cn = min(kChunkWin, nw - c0);
+        for (int w0 = 0; w0 < cn; w0 += 4) {
+            const int wl = w0 + wave;                              // window of this wave inside the pass
+            const bool act = wl < cn;
+            const int16_t* wsrc = src + (int64_t)(c0 + wl) * kWin;
+            int s = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = lane + 64 * u;
+                int v = kPad;
+                if (act && i < kWin) {
+                    v = wsrc[i];
+                    s += v;
+                }
+                K[i] = v;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+            __syncthreads();
+            bitonic512(K, lane);
+            const int sum2 = K[kWin / 2 - 1] + K[kWin / 2];            // 2 * median
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = lane + 64 * u;
+                const int v = K[i];
+                K[i] = (v == kPad) ? kPad : abs(2 * v - sum2);
+            }
+            __syncthreads();
+            bitonic512(K, lane);
+            if (act && lane == 0) {
+                wsum[2 + wl] = s;
+                wmad4[wl] = K[kWin / 2 - 1] + K[kWin / 2];              // 4 * MAD
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            int start = state[0], end = state[1];
+            for (int wl = 0; wl < cn && end <= 0; ++wl) {
+                const int w = c0 + wl;
+                const int i = w * kWin;
+                const double mad = (double)wmad4[wl] * 0.25;
+                const double mean = (double)wsum[2 + wl] / 500.0;
+                double rolling = mean;
+                if (i > 2 * kWin) rolling = (double)(wsum[wl] + wsum[wl + 1]) / 1000.0;
+                const double change = (mean - rolling) / rolling * 100.0;
+                // `not polyA_start` is also true for index 0 (riser/preprocess.py:62)
+                if (start <= 0 && change > 20.0 && mad <= 20.0) start = i;
+                if (start > 0 && end <= 0 && mad > 20.0) end = i;
+            }
+            state[0] = start;
+            state[1] = end;
+            if (cn >= 2) {
+                wsum[0] = wsum[cn];
+                wsum[1] = wsum[cn + 1];
+            }
+        }
+        __syncthreads();
+        if (state[1] > 0) break;
+    }
+    if (tid == 0) out[b] = state[1] > 0 ? state[1] : -1;
 }
 
 }  // namespace

@@ -180,7 +180,8 @@ int rs_seqnet_create(const rs_seq_op* ops, int n_ops, int n_buffers, const float
         return RS_ERR_ARG;
     }
     *out = nullptr;
-    RS_HIP(hipSetDevice(device));
+    DeviceGuard guard(device);            // the caller's current device is restored on return
+    RS_HIP(guard.err);
     rs_seqnet* m = new (std::nothrow) rs_seqnet();
     if (!m) return RS_ERR_OOM;
     m->device = device;
@@ -235,7 +236,7 @@ int rs_seqnet_create(const rs_seq_op* ops, int n_ops, int n_buffers, const float
 
 int rs_seqnet_destroy(rs_seqnet* m) {
     if (!m) return RS_OK;
-    (void)hipSetDevice(m->device);
+    DeviceGuard guard(m->device);
     for (OpDev& o : m->ops) {
         if (o.d_w) (void)hipFree(o.d_w);
         if (o.d_b) (void)hipFree(o.d_b);
@@ -268,6 +269,8 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
         set_error("rs_seqnet_forward: workspace too small");
         return RS_ERR_WORKSPACE;
     }
+    DeviceGuard guard(m->device);
+    RS_HIP(guard.err);
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto buf = [&](int i) -> float* {
         return i == 0 ? const_cast<float*>(d_x) : reinterpret_cast<float*>(static_cast<char*>(d_ws) + per * (size_t)(i - 1));

@@ -27,17 +27,17 @@ struct WalkArgs {
 };
 
 // host: fill a WalkArgs for a launch of `grid` workgroups on `num_cu` CUs.  x_rows / w_rows = rows per K channel
-// of one tile's activation / weight slab (their ratio decides the rectangle's aspect).  RS_NO_RECT_ORDER=1 keeps
-// the n-major order (read per launch: tests toggle it).
+// of one tile's activation / weight slab (their ratio decides the rectangle's aspect).  rect_order = false (RS_NO_RECT_ORDER=1
+// when the model was created) keeps the n-major order.
 inline WalkArgs plan_walk(int n_mtiles, int n_ntiles, int64_t grid, int num_cu, double x_rows, double w_rows,
-                          int check_dead) {
+                          int check_dead, bool rect_order = true) {
     WalkArgs w{};
     w.n_mtiles = n_mtiles;
     w.n_ntiles = n_ntiles;
     w.check_dead = check_dead;
     const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
     w.q_total = (int)tiles;
-    if (getenv("RS_NO_RECT_ORDER") || grid != num_cu || num_cu % 8 != 0 || n_ntiles <= 1) return w;
+    if (!rect_order || grid != num_cu || num_cu % 8 != 0 || n_ntiles <= 1) return w;
     const int rect = num_cu / 8;
     const int64_t rounds = (tiles + num_cu - 1) / num_cu;
     double best = 1e300;

@@ -88,3 +88,31 @@ def gather_results(local_idx: np.ndarray, local_probs: np.ndarray, total: int, d
     for idx, pr in objs:
         out[idx] = pr
     return out
+
+
+def classify_population(models, read_ids, load_signals, rank: int | None = None, world: int | None = None,
+                        sub_batch: int = 1024, gather: bool = True):
+    """BASELINE config 4 / 5 as one call per rank: the population `read_ids` is sharded by read id
+    (`shard_indices`), each rank loads ONLY its own reads (`load_signals(indices) -> int16 [n, L]` host array,
+    plus optional per-read lengths as a second return value), uploads them once, classifies them in sub-batches
+    with its replicated models, and - if `gather` - assembles the [n_models, N, 2] probabilities of the whole
+    population on every rank (host side, 8 bytes per read and model; never a device collective).
+    Returns (my_indices, my_probs [n_models, n_mine, 2] numpy, full or None)."""
+    from .stream import classify_resident
+    if rank is None or world is None:
+        rank, _, world = env_world()
+    models = list(models)
+    mine = shard_indices(read_ids, rank, world)
+    loaded = load_signals(mine)
+    sigs, lens = loaded if isinstance(loaded, tuple) else (loaded, None)
+    sigs = np.ascontiguousarray(sigs, dtype=np.int16)
+    n, L = sigs.shape
+    dev = models[0].device
+    probs = np.zeros((len(models), 0, 2), dtype=np.float32)
+    if n:
+        sig_dev = torch.from_numpy(sigs.reshape(-1)).to(dev)
+        probs = classify_resident(models, sig_dev, n, L, lens, sub_batch).cpu().numpy()
+    full = None
+    if gather:
+        full = np.stack([gather_results(mine, probs[m], len(read_ids), dev) for m in range(len(models))])
+    return mine, probs, full

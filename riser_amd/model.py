@@ -38,6 +38,11 @@ class Workspace:
 
 
 class Model:
+    @staticmethod
+    def dtypes():
+        """Arithmetic modes this build of the library accepts (canonical names)."""
+        return ("f32w", "f32", "bf16", "f16")
+
     def __init__(self, state, config, logger, target, dtype: str = "f32w", device=None):
         """dtype: "f32w" (default; fp32 end to end, conv layers as Winograd F(2,3) / F(4,3) on the
         f32-input MFMA), "f32" (fp32, direct lowering: exact fmaf chains), "f16" / "bf16" (16-bit

@@ -108,8 +108,6 @@ class SignalProcessor:
         if len(signals) == 0:
             return np.zeros(0, dtype=np.int32)
         sig, off, ln, lens = pack_reads(signals, self.device)
-        if int(lens.max()) > MAX_SIGNAL:
-            raise ValueError(f"raw read longer than {MAX_SIGNAL} samples")
         return self.polyA_end_device(sig, off, ln, len(signals)).cpu().numpy()
 
     def polyA_end_device(self, sig, off, ln, B) -> torch.Tensor:

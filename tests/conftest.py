@@ -17,3 +17,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def hooked_model(env, state, dtype, device, target="m"):
+    """A Model created while the RS_* tuning / diagnostic variables of `env` are set: the library reads them
+    once, in rs_model_create, never on the launch path."""
+    from riser_amd import synth
+    from riser_amd.model import Model
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return Model(state, synth.Config(), None, target, dtype=dtype, device=device)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v

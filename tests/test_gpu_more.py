@@ -177,7 +177,9 @@ def test_large_ragged_batch_tile_order(dev, dtype):
     from riser_amd.model import Model
     from riser_amd.preprocess import pack_reads
     sd = synth.make_state_dict(2)
+    from conftest import hooked_model
     m = Model(sd, synth.Config(), None, "m", dtype=dtype, device=dev)
+    m_nmajor = hooked_model({"RS_NO_RECT_ORDER": "1"}, sd, dtype, dev)
     rng = np.random.default_rng(77)
     for B in (437, 300):
         lens = rng.choice([4096, 6024, 8000, 8615, 12000, 16000], size=B).astype(np.int32)
@@ -185,11 +187,7 @@ def test_large_ragged_batch_tile_order(dev, dtype):
         sigs = [synth.make_signals(SIG_SEED, 1, int(n), first_read=2000 + i)[0] for i, n in enumerate(lens)]
         sig, off, ln, lh = pack_reads(sigs, dev)
         full = m.classify_raw(sig, off, ln, lh).cpu().numpy()
-        os.environ["RS_NO_RECT_ORDER"] = "1"
-        try:
-            assert np.array_equal(full, m.classify_raw(sig, off, ln, lh).cpu().numpy())
-        finally:
-            del os.environ["RS_NO_RECT_ORDER"]
+        assert np.array_equal(full, m_nmajor.classify_raw(sig, off, ln, lh).cpu().numpy())
         idx = np.sort(rng.choice(B, size=23, replace=False))
         tidx = torch.from_numpy(idx).to(dev)
         part = m.classify_raw(sig, off[tidx].contiguous(), ln[tidx].contiguous(), lh[idx]).cpu().numpy()
@@ -198,6 +196,7 @@ def test_large_ragged_batch_tile_order(dev, dtype):
         want = ro.classify_reads(sd, [sigs[k] for k in pick])
         assert np.abs(full[pick] - want).max() < (1e-3 if dtype == "f32w" else 2e-2)
     m.close()
+    m_nmajor.close()
 
 
 def test_autotune_keeps_results(dev):
@@ -256,7 +255,9 @@ def test_h16_streaming_layers_and_layer0_fold(dev, dtype):
     from riser_amd.model import Model
     from riser_amd.preprocess import pack_reads
     sd = synth.make_state_dict(2)
+    from conftest import hooked_model
     m = Model(sd, synth.Config(), None, "m", dtype=dtype, device=dev)
+    m_tiled = hooked_model({"RS_NO_STREAM_H16": "1"}, sd, dtype, dev)
     tol = {"f16": 2e-2, "bf16": 1.5e-1}[dtype]
     for lens in ([16000] * 6, [4096, 16000, 8615, 5000, 12001, 4097, 16383, 9999]):
         sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=300 + i)[0] for i, n in enumerate(lens)]
@@ -264,16 +265,13 @@ def test_h16_streaming_layers_and_layer0_fold(dev, dtype):
         xs = [ro.mad_normalise(s) for s in sigs]
         fused = m.classify_raw(sig, off, ln, lh).cpu().numpy()               # layer 0 folded into layer 1
         stream = m.classify_batch(xs).cpu().numpy()                          # conv0 kernel + streaming layers 1-2
-        os.environ["RS_NO_STREAM_H16"] = "1"
-        try:
-            tiled = m.classify_raw(sig, off, ln, lh).cpu().numpy()           # conv0 kernel + tiled kernel everywhere
-        finally:
-            del os.environ["RS_NO_STREAM_H16"]
+        tiled = m_tiled.classify_raw(sig, off, ln, lh).cpu().numpy()     # conv0 kernel + tiled kernel everywhere
         assert np.array_equal(fused, stream), np.abs(fused - stream).max()
         assert np.array_equal(fused, tiled), np.abs(fused - tiled).max()
         want = np.stack([ro.classify(sd, x) for x in xs])
         assert np.abs(fused - want).max() < tol
     m.close()
+    m_tiled.close()
 
 
 @pytest.mark.parametrize("dtype", ["f32w", "f16"])
@@ -326,4 +324,65 @@ def test_oversized_batches_are_split(dev, monkeypatch):
     assert np.array_equal(got_raw.cpu().numpy(), want_raw)
     assert torch.equal(got_b, want_b) and torch.equal(got_l, want_l) and torch.equal(got_rl, want_l)
     assert np.array_equal(got_e, want_e)
+    m.close()
+
+
+def test_promethion_per_gpu_shape(dev):
+    """BASELINE config 4, the per-GPU share: 18 000 x 16000-sample chunks resident in HBM, walked in sub-batches
+    (riser_amd.stream.classify_resident).  No oracle at this size, so: (a) a sample against the oracle, (b) bit
+    identity with direct library calls on arbitrary sub-ranges, (c) the population repeats 512 distinct signals, so
+    read i must give exactly the bits of read i mod 512 wherever it sits in whichever sub-batch."""
+    from riser_amd.model import Model
+    from riser_amd.stream import classify_resident
+    sd = synth.make_state_dict(1)
+    m = Model(sd, synth.Config(), None, "m", device=dev)
+    N, L, SUB = 18000, 16000, 1024
+    base = synth.make_signals(SIG_SEED, 512, L)
+    idx = np.arange(N)
+    sig = torch.from_numpy(np.ascontiguousarray(base[idx % 512].reshape(-1))).to(dev)
+    probs = classify_resident([m], sig, N, L, None, SUB).cpu().numpy()
+    assert probs.shape == (1, N, 2) and np.isfinite(probs).all()
+    p = probs[0]
+    assert np.array_equal(p, p[idx % 512]), "a read's result depends on its position in the population"
+    pick = [0, 300, 511]
+    want = ro.classify_reads(sd, base[pick])
+    assert np.abs(p[pick] - want).max() < 1e-3
+    assert np.array_equal(p[pick, 1] > 0.9, want[:, 1] > 0.9)
+    lo, hi = 5000, 5100                                                # straddles no sub-batch boundary ...
+    off = torch.arange(lo, hi, dtype=torch.int64, device=dev) * L
+    ln = torch.full((hi - lo,), L, dtype=torch.int32, device=dev)
+    assert np.array_equal(m.classify_raw(sig, off, ln, np.full(hi - lo, L, np.int32)).cpu().numpy(), p[lo:hi])
+    lo, hi = 17 * SUB - 40, 17 * SUB + 23                               # ... and one that does, ending at the ragged tail
+    off = torch.arange(lo, hi, dtype=torch.int64, device=dev) * L
+    ln = torch.full((hi - lo,), L, dtype=torch.int32, device=dev)
+    assert np.array_equal(m.classify_raw(sig, off, ln, np.full(hi - lo, L, np.int32)).cpu().numpy(), p[lo:hi])
+    m.close()
+
+
+def test_classify_population_shards_by_read_id(dev):
+    """riser_amd.dist.classify_population: each rank loads and classifies only the reads whose id hashes to it; the
+    shards of a (simulated) 8-rank world partition the population and reproduce the single-rank result bit for bit."""
+    from riser_amd import dist as rdist
+    from riser_amd.model import Model
+    m = Model(synth.make_state_dict(2), synth.Config(), None, "m", dtype="f16", device=dev)
+    N, L = 700, 8000
+    ids = [f"read-{i:05d}" for i in range(N)]
+    base = synth.make_signals(SIG_SEED, 64, L, first_read=40)
+    lens_all = np.where(np.arange(N) % 3 == 0, 6000, L).astype(np.int32)
+    loads = []
+
+    def load(ix):
+        loads.append(np.asarray(ix))
+        return base[np.asarray(ix) % 64], lens_all[ix]
+
+    mine, probs, full = rdist.classify_population([m], ids, load, rank=0, world=1, sub_batch=256)
+    assert mine.tolist() == list(range(N)) and np.array_equal(full[0], probs[0])
+    seen = np.zeros(N, dtype=int)
+    for r in range(8):
+        ix, pr, _ = rdist.classify_population([m], ids, load, rank=r, world=8, sub_batch=64, gather=False)
+        assert all(rdist.shard_of(ids[i], 8) == r for i in ix)
+        assert np.array_equal(loads[-1], ix), "a rank must load only its own reads"
+        seen[ix] += 1
+        assert np.array_equal(pr[0], full[0][ix])
+    assert (seen == 1).all()
     m.close()

@@ -430,21 +430,17 @@ def test_full_size_batch_properties(dev):
     half = mh.classify_raw(sig, off, ln, lens).cpu().numpy()
     direct = md.classify_raw(sig, off, ln, lens).cpu().numpy()
     assert np.abs(direct - full).max() < 1e-4
-    os.environ["RS_NO_RECT_ORDER"] = "1"
-    try:
-        assert np.array_equal(full, m.classify_raw(sig, off, ln, lens).cpu().numpy())
-        assert np.array_equal(half, mh.classify_raw(sig, off, ln, lens).cpu().numpy())
-        assert np.array_equal(direct, md.classify_raw(sig, off, ln, lens).cpu().numpy())
-    finally:
-        del os.environ["RS_NO_RECT_ORDER"]
+    from conftest import hooked_model
+    for dt, want_bits in (("f32w", full), ("f16", half), ("f32", direct)):
+        mo = hooked_model({"RS_NO_RECT_ORDER": "1"}, synth.make_state_dict(1), dt, dev)
+        assert np.array_equal(want_bits, mo.classify_raw(sig, off, ln, lens).cpu().numpy()), dt
+        mo.close()
     md.close()
     # (f) 64-channel panels of the 16-bit tiled kernel (RS_H16_PANEL=64: other tile shapes, other accumulation order
     # across k-steps): same probabilities to fp32-accumulation round-off
-    os.environ["RS_H16_PANEL"] = "64"
-    try:
-        wide = mh.classify_raw(sig, off, ln, lens).cpu().numpy()
-    finally:
-        del os.environ["RS_H16_PANEL"]
+    mw = hooked_model({"RS_H16_PANEL": "64"}, synth.make_state_dict(1), "f16", dev)
+    wide = mw.classify_raw(sig, off, ln, lens).cpu().numpy()
+    mw.close()
     # (activations are re-rounded to 16 bits after every layer, so round-off differences are amplified to the 16-bit
     # path's own distance from fp32, ~7e-3)
     assert np.abs(wide - half).max() < 1e-2

@@ -116,20 +116,19 @@ def test_wino_layer01_variants_bit_identical(dev):
     tiled kernel with layer 0 folded into its staging, and the LDS-free streaming kernel (both on the
     rs_classify path) - which must agree bit for bit on full-length and mixed-length batches."""
     from riser_amd.preprocess import pack_reads
+    from conftest import hooked_model
     m = get_model(3, dev)
+    m_folded = hooked_model({"RS_NO_STREAM_F32": "1"}, synth.make_state_dict(3), "f32w", dev)
     for lens in ([16000] * 5, [4096, 16000, 8615, 5000, 12001, 4097, 16383, 9999, 4100]):
         sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=400 + i)[0] for i, n in enumerate(lens)]
         sig, off, ln, lh = pack_reads(sigs, dev)
         xs = [ro.mad_normalise(s) for s in sigs]
         stream = m.classify_raw(sig, off, ln, lh).cpu().numpy()
         unfused = m.classify_batch(xs).cpu().numpy()
-        os.environ["RS_NO_STREAM_F32"] = "1"
-        try:
-            folded = m.classify_raw(sig, off, ln, lh).cpu().numpy()
-        finally:
-            del os.environ["RS_NO_STREAM_F32"]
+        folded = m_folded.classify_raw(sig, off, ln, lh).cpu().numpy()
         assert np.array_equal(stream, unfused), np.abs(stream - unfused).max()
         assert np.array_equal(folded, unfused), np.abs(folded - unfused).max()
+    m_folded.close()
 
 
 @pytest.mark.parametrize("dtype", ["f32w", "f32"])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 4 on one GPU: 18 000 host-resident 4 s chunks streamed through the GPU in
-sub-batches (PCIe upload overlapped with compute).  Prints end-to-end chunks/s per GPU."""
+sub-batches (PCIe upload overlapped with compute).  Prints END-TO-END chunks/s from host memory - the
+PCIe-inclusive figure DESIGN.md quotes beside `python bench.py --config promethion` (HBM-resident)."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,8 +15,9 @@ ap.add_argument("--len", type=int, default=16000)
 ap.add_argument("--sub-batch", type=int, default=1024)
 ap.add_argument("--dtype", default="f32w")
 ap.add_argument("--pinned", action="store_true")
+ap.add_argument("--device", type=int, default=0)
 a = ap.parse_args()
-dev = torch.device("cuda", 0)
+dev = torch.device("cuda", a.device)
 base = synth.make_signals(20260103, 256, a.len)
 sig = np.tile(base, ((a.reads + 255) // 256, 1))[: a.reads]
 if a.pinned:

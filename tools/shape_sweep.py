@@ -23,6 +23,9 @@ m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=DT)
 if DT == "f32w": shapes = WINO4 if W4 else WINO
 ROWMUL = 4 if W4 else 2 if DT == "f32w" else 1
 def run():
+    global m
+    # the library reads RS_FORCE_SHAPE_* once, when a model is created
+    m.close(); m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=DT)
     for _ in range(2): m.classify_raw(sig, off, ln, lens)
     m.profile(True)
     for _ in range(4): m.classify_raw(sig, off, ln, lens)
