@@ -185,3 +185,46 @@ def make_raw_read(seed: int, rid: int, total_len: int, polya: bool = True) -> np
         parts.append(make_signals(seed, 1, r_len, first_read=rid)[0].astype(np.int64))
     x = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
     return np.clip(x, 0, 4095).astype(np.int16)
+
+
+def _quiet(seed: int, stream: int, n: int, level: int, mul: int = 10) -> np.ndarray:
+    """n samples of a quiet plateau: `level` + approximately normal noise of sigma ~ 0.6 * mul."""
+    hn = hash_u64(seed, stream, n)
+    s = ((hn & np.uint64(0xFFFF)) + ((hn >> np.uint64(16)) & np.uint64(0xFFFF))
+         + ((hn >> np.uint64(32)) & np.uint64(0xFFFF)) + (hn >> np.uint64(48))).astype(np.int64)
+    return level + (((s - 131070) * mul) >> 16)
+
+
+def polya_edge_cases(seed: int = 77):
+    """[(name, int16 signal)]: raw reads that exercise the corners of the poly(A) window rule
+    (riser/preprocess.py:42-79) that make_raw_read cannot reach.  Deterministic, so the fixture
+    (tests/golden/polya.npz: `edge_names`, `edge_ends`) stores only the reference's answers."""
+    def noisy(stream, n, level=470):
+        return make_signals(seed ^ 0x5A5A, 1, max(n, 1), first_read=stream, spikes=False)[0, :n].astype(np.int64) - 500 + level
+
+    def i16(parts):
+        return np.clip(np.concatenate(parts), 0, 4095).astype(np.int16)
+
+    cases = []
+    # a start is found but no later window is noisy: the plateau runs to the end of the read -> None
+    cases.append(("plateau_never_ends", i16([noisy(1, 2300), _quiet(seed, 1, 5200, 760)])))
+    # shorter than one window (the while loop never runs), exactly one window, one sample short of two
+    cases.append(("shorter_than_a_window", i16([_quiet(seed, 2, 499, 700)])))
+    cases.append(("exactly_one_window", i16([_quiet(seed, 3, 500, 700)])))
+    cases.append(("one_short_of_two_windows", i16([noisy(2, 500), _quiet(seed, 4, 499, 900)])))
+    # a > 20 % rise inside the first 1000 samples: for i <= 1000 the rolling mean IS the window mean (change 0), and at
+    # i = 1500 the previous 1000 samples are already on the plateau, so the rule never fires on this rise -> None
+    cases.append(("rise_inside_first_1000", i16([noisy(3, 500), _quiet(seed, 5, 2500, 760), noisy(4, 3000, 520)])))
+    # the same rise one window later (i = 1500 sees 1000 samples of adapter): found, ended by the RNA
+    cases.append(("rise_at_1500", i16([noisy(5, 1500), _quiet(seed, 6, 2000, 760), noisy(6, 3000, 520)])))
+    # rolling mean of 0: (mean - 0) / 0 is +inf (> 20: a start if the window is quiet) or nan (0 / 0: never a start)
+    cases.append(("rolling_mean_zero", i16([np.zeros(2500, dtype=np.int64), _quiet(seed, 7, 1500, 700), noisy(7, 2500, 520)])))
+    cases.append(("all_zero", np.zeros(6000, dtype=np.int16)))
+    # a noisy plateau (window MAD > 20) is not a start
+    cases.append(("noisy_plateau", i16([noisy(8, 2000), _quiet(seed, 8, 2500, 760, mul=60), noisy(9, 2500, 520)])))
+    # start and end both beyond 65536 samples (an AccumulatingCache read that sat in the pore for a long time)
+    cases.append(("end_beyond_65536", i16([noisy(10, 66200), _quiet(seed, 9, 2300, 760), noisy(11, 3100, 520)])))
+    # 128-window table boundary of the kernel (64000 samples): the rise straddles it
+    cases.append(("start_at_64000", i16([noisy(12, 64000), _quiet(seed, 10, 1500, 760), noisy(13, 2500, 520)])))
+    cases.append(("end_at_64000", i16([noisy(14, 62000), _quiet(seed, 11, 2000, 760), noisy(15, 2500, 520)])))
+    return cases

@@ -160,6 +160,20 @@ def test_polya_golden(proc, golden_dir):
     assert ok and cache == {"r0": int(cases[0, 4])} and len(trimmed) == len(sigs[0]) - cases[0, 4] - 1
 
 
+def test_polya_edge_cases_golden(proc, golden_dir):
+    """the reference's answers on the corners of the window rule, incl. reads longer than 65536 samples and the
+    kernel's own 128-window table boundary; as single reads and as one ragged batch"""
+    g = np.load(os.path.join(golden_dir, "polya.npz"))
+    want = g["edge_ends"]
+    cases = synth.polya_edge_cases()
+    assert [n for n, _ in cases] == [str(n) for n in g["edge_names"]]
+    got = proc.get_polyA_end_batch([s for _, s in cases])
+    assert np.array_equal(got, want), dict(zip(g["edge_names"], zip(got, want)))
+    for (name, s), w in zip(cases, want):
+        e = proc.get_polyA_end(s)
+        assert (-1 if e is None else e) == w, name
+
+
 def test_polya_random_vs_oracle(proc):
     rng = np.random.default_rng(11)
     sigs = [synth.make_raw_read(1234, i, int(rng.integers(600, 30000)), bool(i % 3)) for i in range(48)]

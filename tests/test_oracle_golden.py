@@ -54,6 +54,22 @@ def test_polya_end(golden_dir):
     assert found >= 20
 
 
+def test_polya_edge_cases(golden_dir):
+    """corners of the window rule (plateau that never ends, reads shorter than a window, a rise where the rule is inert,
+    a rolling mean of 0, reads beyond 65536 samples): the reference's answers for synth.polya_edge_cases()"""
+    import warnings
+    g = np.load(os.path.join(golden_dir, "polya.npz"))
+    want = dict(zip([str(n) for n in g["edge_names"]], g["edge_ends"].tolist()))
+    cases = synth.polya_edge_cases()
+    assert [n for n, _ in cases] == list(want)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for name, sig in cases:
+            got = ro.polya_end(sig)
+            assert (-1 if got is None else got) == want[name], name
+    assert want["plateau_never_ends"] == -1 and want["rolling_mean_zero"] > 0 and want["end_beyond_65536"] > 65536
+
+
 @pytest.fixture(scope="module")
 def net(golden_dir):
     return np.load(os.path.join(golden_dir, "network.npz"))

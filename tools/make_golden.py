@@ -223,9 +223,21 @@ def f4_polya():
         sig = synth.make_raw_read(91, rid, n, polya)
         end = proc.get_polyA_end(sig)
         cases.append([91, rid, n, int(polya), -1 if end is None else int(end)])
-    # hand-made: plateau that never ends (no later noisy window) and a too-short read
-    np.savez_compressed(os.path.join(OUT, "polya.npz"), cases=np.array(cases, dtype=np.int64))
+    # corners of the window rule (riser_amd.synth.polya_edge_cases: a plateau that never ends, reads shorter than a
+    # window, a rise inside the first 1000 samples where the rule is inert, a rolling mean of 0, reads beyond 65536
+    # samples): the signals are rebuilt from integer hashes, the fixture keeps the reference's answers
+    import warnings
+    names, ends = [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)                   # x / 0 in the rolling-mean case
+        for name, sig in synth.polya_edge_cases():
+            end = proc.get_polyA_end(sig)
+            names.append(name)
+            ends.append(-1 if end is None else int(end))
+    np.savez_compressed(os.path.join(OUT, "polya.npz"), cases=np.array(cases, dtype=np.int64),
+                        edge_names=np.array(names), edge_ends=np.array(ends, dtype=np.int64))
     print("F4:", [c[4] for c in cases])
+    print("F4 edge:", dict(zip(names, ends)))
 
 
 # --------------------------------------------------------------------------------------
