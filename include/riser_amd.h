@@ -49,8 +49,14 @@ typedef enum rs_dtype {
     RS_F32 = 0,             /* f32-input MFMA (v_mfma_f32_16x16x4_f32): exact fmaf chains */
     RS_BF16 = 1,            /* bf16 activations/weights, v_mfma_f32_16x16x32_bf16, fp32 accumulate */
     RS_F16 = 2,             /* f16 activations/weights, v_mfma_f32_16x16x32_f16, fp32 accumulate */
-    RS_F32W = 3             /* fp32 throughout, conv lowered to Winograd F(2,3) / F(4,3) on the f32-input MFMA:
+    RS_F32W = 3,            /* fp32 throughout, conv lowered to Winograd F(2,3) / F(4,3) on the f32-input MFMA:
                                2/3 resp. 1/2 of the multiplications of RS_F32, probabilities within ~1e-5 of it */
+    RS_BF16X3 = 4,          /* split precision on the bf16 MFMA: every activation and weight is a pair hi + lo of bf16
+                               values (~16 significand bits), a product is hi*hi + lo*hi + hi*lo on three
+                               v_mfma_f32_16x16x32_bf16 with fp32 accumulate.  The 16-bit mode that meets the 1e-3
+                               probability tolerance of BASELINE configs 3 / 5; RS_BF16 / RS_F16 are the fast,
+                               approximate variants */
+    RS_F16X3 = 5            /* the same with f16 pairs (~22 significand bits above 2^-14, less below) */
 } rs_dtype;
 
 /* decisions of riser/control.py:75-82, as written into rs_decide's output */

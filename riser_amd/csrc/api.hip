@@ -46,6 +46,8 @@ Hooks Hooks::from_env() {
     text("RS_FORCE_SHAPE_WINO4", h.force_wino4, sizeof(h.force_wino4));
     text("RS_FORCE_SHAPE_H16", h.force_h16, sizeof(h.force_h16));
     text("RS_H16_PANEL", h.h16_panel, sizeof(h.h16_panel));
+    text("RS_FORCE_SHAPE_RING", h.force_ring, sizeof(h.force_ring));
+    h.h16_ring = flag("RS_H16_RING");
     return h;
 }
 
@@ -79,6 +81,7 @@ struct rs_model {
     int num_cu = 256;
     int last_bm[kMaxLayers] = {0};
     int last_bn[kMaxLayers] = {0};
+    bool last_ring[kMaxLayers] = {false};  // the layer's last launch ran the LDS-DMA ring kernel
     // stage profiling (rs_profile_*): events recorded on the launch stream
     bool prof_on = false;
     bool prof_open = false;      // a profiled call has recorded its opening event (rs_classify opens before normalise)
@@ -99,6 +102,8 @@ inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 // storage type of the activations: the Winograd fp32 path shares every non-conv kernel with RS_F32
 int act_dtype(const rs_model* m) { return m->dtype == RS_F32W ? RS_F32 : m->dtype; }
 int esize(const rs_model* m) { return act_dtype(m) == RS_F32 ? 4 : 2; }
+// 16-bit storage type of a mode (RS_BF16 or RS_F16), also for the split-precision modes
+int base16(int dtype) { return is_f16_family(dtype) ? RS_F16 : RS_BF16; }
 
 // ---- static part of the plan: the K chunking (fixes the weight packing) -------------------------
 // kc minimises nch * (3*kc/4 + 0.75) k-steps (0.75 step ~ the per-item barrier + LDS write);
@@ -237,6 +242,11 @@ void prof_mark(rs_model* m, int stage, hipStream_t st) {
 }
 
 // fp32 -> bf16 / f16 bits, round to nearest even (host side, weight packing)
+float from_h16(unsigned short u, int dtype) {
+    if (dtype == RS_F16) return (float)__builtin_bit_cast(_Float16, u);
+    return __builtin_bit_cast(float, (unsigned)u << 16);
+}
+
 unsigned short to_h16(float f, int dtype) {
     if (dtype == RS_F16) return __builtin_bit_cast(unsigned short, (_Float16)f);
     unsigned u = __builtin_bit_cast(unsigned, f);
@@ -282,7 +292,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         set_error("rs_model_create: n_classes must be 2 (got %d)", n_classes);
         return RS_ERR_ARG;
     }
-    if (dtype != RS_F32 && dtype != RS_BF16 && dtype != RS_F16 && dtype != RS_F32W) {
+    if (dtype != RS_F32 && dtype != RS_BF16 && dtype != RS_F16 && dtype != RS_F32W && !is_x3(dtype)) {
         set_error("rs_model_create: unknown dtype %d", dtype);
         return RS_ERR_ARG;
     }
@@ -309,7 +319,10 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
     m->n_layers = n_layers;
     for (int i = 0; i < n_layers; ++i) {
         m->channels[i] = channels[i];
-        m->cp[i] = round_up(channels[i], (dtype == RS_F32 || dtype == RS_F32W) ? 4 : 8);
+        // row width of layer i's output buffer: channels padded to 16 bytes; split precision: 32-channel panels laid
+        // out as [hi x 32 | lo x 32] (conv_ring_h16.hip)
+        m->cp[i] = is_x3(dtype) ? 64 * ((channels[i] + 31) / 32)
+                                : round_up(channels[i], (dtype == RS_F32 || dtype == RS_F32W) ? 4 : 8);
     }
     int rc = RS_OK;
     {   // layer 0: (w0, w1, w2, bias) per output channel
@@ -381,22 +394,51 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             rc = upload(&dw, wp);
             L.d_w = dw;
         } else {
-            // 16-bit: panels of 32 input channels, packed [panel][tap][n_alloc][32]
+            // 16-bit: panels of 32 input channels, packed [panel][tap][n_alloc][32] (conv_h16.hip, conv_stream_h16.hip)
+            const int st16 = base16(dtype);
+            const bool x3 = is_x3(dtype);
             ConvPlan& p = L.plan;
             p.kc = 32;
-            p.nch = (L.cp_in + 31) / 32;
-            p.n_alloc = round_up(L.c_out, 16) + conv_h16_max_bn();
-            std::vector<unsigned short> wp((size_t)p.nch * 3 * p.n_alloc * 32, 0);
-            for (int n = 0; n < L.c_out; ++n)
-                for (int ci = 0; ci < L.c_in; ++ci) {
-                    const int pn = ci / 32, cc = ci - pn * 32;
-                    for (int kw = 0; kw < 3; ++kw)
-                        wp[(((size_t)pn * 3 + kw) * p.n_alloc + n) * 32 + cc] =
-                            to_h16(conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw], dtype);
-                }
-            unsigned short* dw = nullptr;
-            rc = upload(&dw, wp);
-            L.d_w = dw;
+            p.nch = (L.c_in + 31) / 32;
+            p.n_alloc = round_up(L.c_out, 16) + std::max(conv_h16_max_bn(), conv_ring_max_bn());
+            if (!x3) {
+                p.nch = (L.cp_in + 31) / 32;
+                std::vector<unsigned short> wp((size_t)p.nch * 3 * p.n_alloc * 32, 0);
+                for (int n = 0; n < L.c_out; ++n)
+                    for (int ci = 0; ci < L.c_in; ++ci) {
+                        const int pn = ci / 32, cc = ci - pn * 32;
+                        for (int kw = 0; kw < 3; ++kw)
+                            wp[(((size_t)pn * 3 + kw) * p.n_alloc + n) * 32 + cc] =
+                                to_h16(conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw], st16);
+                    }
+                unsigned short* dw = nullptr;
+                rc = upload(&dw, wp);
+                L.d_w = dw;
+            }
+            // ring packing [panel][tap][n_alloc][64] (conv_ring_h16.hip): a panel is 64 input channels, or 32 input
+            // channels as [hi x 32 | lo x 32] with lo = round(w - hi) in split precision
+            L.ring_panels = x3 ? (L.c_in + 31) / 32 : (L.cp_in + 63) / 64;
+            if (rc == RS_OK && (x3 || m->hooks.h16_ring)) {
+                std::vector<unsigned short> wr((size_t)L.ring_panels * 3 * p.n_alloc * 64, 0);
+                for (int n = 0; n < L.c_out; ++n)
+                    for (int ci = 0; ci < L.c_in; ++ci)
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const float wv = conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw];
+                            const unsigned short hi = to_h16(wv, st16);
+                            if (x3) {
+                                const int pn = ci / 32, cc = ci - pn * 32;
+                                const size_t at = (((size_t)pn * 3 + kw) * p.n_alloc + n) * 64 + cc;
+                                wr[at] = hi;
+                                wr[at + 32] = to_h16(wv - from_h16(hi, st16), st16);
+                            } else {
+                                const int pn = ci / 64, cc = ci - pn * 64;
+                                wr[(((size_t)pn * 3 + kw) * p.n_alloc + n) * 64 + cc] = hi;
+                            }
+                        }
+                unsigned short* dw2 = nullptr;
+                rc = upload(&dw2, wr);
+                L.d_w2 = dw2;
+            }
         }
         const ConvPlan& p = L.plan;
         std::vector<float> bp((size_t)p.n_alloc, 0.0f);
@@ -433,6 +475,7 @@ int rs_model_destroy(rs_model* m) {
     if (m->d_w0) (void)hipFree(m->d_w0);
     for (int i = 1; i < m->n_layers; ++i) {
         if (m->layers[i].d_w) (void)hipFree(m->layers[i].d_w);
+        if (m->layers[i].d_w2) (void)hipFree(m->layers[i].d_w2);
         if (m->layers[i].d_bias) (void)hipFree(m->layers[i].d_bias);
     }
     if (m->d_fcw) (void)hipFree(m->d_fcw);
@@ -515,7 +558,9 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
     const bool fuse0 = zero_prefix && m->dtype == RS_F32W && ldx == w.P0 && conv_wino_can_fuse0(m->layers[1], w.P0 >> 1);
     // 16-bit paths: the narrow layers 1 and 2 run the per-wave streaming kernel; on the rs_classify path
     // layer 0 is folded into layer 1 there as well ("fused preprocess + conv")
-    const bool is16 = m->dtype == RS_BF16 || m->dtype == RS_F16;
+    const bool x3 = is_x3(m->dtype);
+    const bool is16 = m->dtype == RS_BF16 || m->dtype == RS_F16;          // plain 16-bit
+    const bool f16 = is_f16_family(m->dtype);
     const bool fuse0h = is16 && zero_prefix && ldx == w.P0 && m->channels[0] <= 32 &&
                         conv_stream_h16_ok(m->layers[1], w.P0 >> 1);
     int rc = RS_OK;
@@ -532,7 +577,11 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         // kind of kernel this layer runs: 0 streaming (not tuned), 1 F(4,3), 2 F(2,3), 3 direct fp32, 4 tiled 16-bit
         const bool stream32 = m->dtype == RS_F32W && fuse0 && i == 1 && conv_stream_f32_ok(L, m->channels[0], P_in);
         const bool stream16 = is16 && i <= 2 && conv_stream_h16_ok(L, P_in);
-        const int kind = (stream32 || stream16) ? 0 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2) : m->dtype == RS_F32 ? 3 : 4;
+        // split precision runs the LDS-DMA ring kernel on every layer, plain 16-bit on its tiled layers with RS_H16_RING
+        const bool ring = x3 || (is16 && !stream16 && m->hooks.h16_ring && L.d_w2);
+        const int kind = (stream32 || stream16) ? 0 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)
+                                                            : m->dtype == RS_F32 ? 3 : 4;
+        m->last_ring[i] = ring;
         auto launch_layer = [&]() -> int {
             int rc;
             if (m->dtype == RS_F32W && fuse0 && i == 1 && conv_stream_f32_ok(L, m->channels[0], P_in)) {
@@ -550,24 +599,29 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
             else if (m->dtype == RS_F32)
                 rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
                                      B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
+            else if (ring)
+                rc = launch_conv_ring_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, f16, x3, check_dead, st,
+                                          &m->last_bm[i], &m->last_bn[i]);
             else if (is16 && i <= 2 && conv_stream_h16_ok(L, P_in)) {
                 const bool f0 = fuse0h && i == 1;
-                rc = launch_conv_stream_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, m->dtype == RS_F16, st,
+                rc = launch_conv_stream_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, f16, st,
                                             f0 ? d_x : nullptr, m->d_w0, m->channels[0]);
                 m->last_bm[i] = 16;
                 m->last_bn[i] = round_up(L.c_out, 16);
             } else
                 rc = launch_conv_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, m->d_zero,
-                                     m->dtype == RS_F16, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
+                                     f16, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
             return rc;
         };
-        if (m->tuning && (kind == 1 || kind == 2 || kind == 4)) {
+        if (m->tuning && (kind == 1 || kind == 2 || kind == 4 || kind == 5)) {
             // rs_autotune: every feasible entry of the kernel's shape table on THIS layer's real input (the buffers hold the
             // activations of the batch; re-running a layer rewrites the same output), 1 warm + 3 timed launches each;
             // a shape replaces the planner's choice only if it is > 3 % faster
-            const int n = kind == 1 ? conv_wino4_num_shapes() : kind == 2 ? conv_wino_num_shapes() : conv_h16_num_shapes();
+            const int n = kind == 1 ? conv_wino4_num_shapes() : kind == 2 ? conv_wino_num_shapes()
+                        : kind == 5 ? conv_ring_num_shapes() : conv_h16_num_shapes();
             auto ok = [&](int k) {
-                return kind == 1 ? conv_wino4_shape_ok(L, k) : kind == 2 ? conv_wino_shape_ok(L, k) : conv_h16_shape_ok(L, k);
+                return kind == 1 ? conv_wino4_shape_ok(L, k) : kind == 2 ? conv_wino_shape_ok(L, k)
+                     : kind == 5 ? conv_ring_shape_ok(L, k) : conv_h16_shape_ok(L, k);
             };
             hipEvent_t e0, e1;
             RS_HIP(hipEventCreate(&e0));
@@ -795,6 +849,7 @@ int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out) {
     out->c_in = L.c_in;
     out->cp_in = L.cp_in;
     out->k_pad = (m->dtype == RS_F32W ? (L.wino_m == 4 ? 6 : 4) : 3) * L.plan.kc * L.plan.nch;
+    if (m->last_ring[layer] && !is_x3(m->dtype)) out->k_pad = 3 * 64 * L.ring_panels;      // 64-channel panels
     out->n_pad = m->last_bn[layer] ? round_up(round_up(L.c_out, 16), m->last_bn[layer]) : round_up(L.c_out, 16);
     out->bm = m->last_bm[layer];
     out->bn = m->last_bn[layer];

@@ -63,10 +63,16 @@ struct Hooks {
     char force_wino[256] = "";
     char force_wino4[256] = "";
     char force_h16[256] = "";
+    char force_ring[256] = "";       // RS_FORCE_SHAPE_RING
     char h16_panel[128] = "";        // RS_H16_PANEL: "64" or "layer:64;..."
+    bool h16_ring = false;           // RS_H16_RING: plain 16-bit tiled layers on the LDS-DMA ring kernel
     static Hooks from_env();
 };
 const Hooks& default_hooks();
+
+inline bool is_x3(int dtype) { return dtype == RS_BF16X3 || dtype == RS_F16X3; }
+inline bool is_f16_family(int dtype) { return dtype == RS_F16 || dtype == RS_F16X3; }
+inline bool is_16bit(int dtype) { return dtype == RS_BF16 || dtype == RS_F16 || is_x3(dtype); }
 
 constexpr int kMaxLayers = 16;
 constexpr int kMaxNormLen = 65536;
@@ -94,6 +100,8 @@ struct ConvLayerDev {
     int c_in, c_out, cp_in, cp_out;
     ConvPlan plan;            // packing of d_w follows plan.kc / plan.nch / plan.n_pad
     void* d_w;                // packed weights [n_alloc][nch][3][kc] (f32 or bf16)
+    void* d_w2 = nullptr;     // 16-bit modes: ring packing [panel][tap][n_alloc][64] (conv_ring_h16.hip)
+    int ring_panels = 0;      // panels of the ring packing: 64 channels each (plain) or 32 channels as hi | lo (x3)
     float* d_bias;            // [n_alloc] fp32, zero padded
     // rs_autotune: the measured-best entry of the kernel's tile-shape table per launch geometry (GEMM rows of the
     // launch -> shape index), consulted before the cost model; force_shape >= 0 overrides both while tuning
@@ -135,6 +143,13 @@ bool conv_stream_h16_ok(const ConvLayerDev& L, int P_in);
 int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
                            int layer_index, int num_cu, bool f16, hipStream_t st, const float* fuse_xs,
                            const float* fuse_w0, int fuse_c0);
+// LDS-DMA ring kernel (conv_ring_h16.hip): plain 16-bit and split-precision (x3) modes
+int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
+                         int layer_index, int num_cu, bool f16, bool x3, int check_dead, hipStream_t st, int* bm_out,
+                         int* bn_out);
+int conv_ring_max_bn();
+int conv_ring_num_shapes();
+bool conv_ring_shape_ok(const ConvLayerDev& L, int k);
 int conv_h16_max_bn();
 int conv_f32_max_bn();
 // tile-shape tables of the tiled kernels (rs_autotune): number of entries, and whether entry k can run layer L

@@ -1,0 +1,503 @@
+// K3r (16-bit, LDS-DMA ring): one ConvNet block i >= 1 on the bf16 / f16 MFMA (fp32 accumulate), plain or SPLIT
+// PRECISION ("x3": every activation and weight is a pair hi + lo of 16-bit values, the product is
+// hi*hi + lo*hi + hi*lo on three MFMAs - ~2^-17 per operand instead of 2^-9 (bf16) / 2^-12 (f16)).
+//
+//   Conv1d(C_in -> C_out, k=3, 'same', bias) -> ReLU -> MaxPool1d(2,2)   (riser/nets/cnn.py:52-65)
+//
+// Same lowering as conv_h16.hip (position-major activations, GEMM M = positions, N = output channels, K = 3 * C_in,
+// bias + ReLU + MaxPool fused in registers) with the staging rebuilt around LDS-DMA:
+//   * an LDS row is 128 bytes = one PANEL of one position / output channel: 64 input channels (plain), or 32 input
+//     channels as [hi x 32 | lo x 32] (x3).  The x3 activation buffers and the weights are laid out in HBM in exactly
+//     that panel-interleaved form, so both modes stage identical bytes and differ only in how the two 64-byte halves of
+//     a row are paired on the matrix pipe: (h0,h0),(h1,h1) resp. (hi,hi),(lo,hi),(hi,lo);
+//   * a work item is a SUB-STAGE (tile, panel, tap): 2 (plain) or 3 (x3) x MT x NT MFMAs per wave;
+//   * staging is `buffer_load_dwordx4 ... offen lds` from inline asm (hipcc neither tracks nor waits for it): 1 KiB per
+//     wave instruction = 8 rows; the 16-byte-slot XOR swizzle (slot ^ (row & 7), conflict-free ds_read_b128 for all
+//     three tap shifts) is applied on the per-lane SOURCE address, the LDS image of a piece stays lane-linear.  Rows
+//     outside the activation buffer (row -1, rows past the end) resolve to out-of-range offsets, for which the DMA
+//     writes zeros (tools/ubench/lds_dma_probe.cpp);
+//   * the ring: two activation slabs of (BM + 8) rows (current panel / next panel) and one weight slab per TAP
+//     (BN rows each).  Tap t's weights for the next use are issued two sub-stages ahead, the next panel's slab during
+//     taps 0 and 1, so every transfer has a whole sub-stage of MFMA work to land; a sub-stage ends with
+//     s_waitcnt vmcnt(0) + s_barrier - no counted waits, no register staging, no LDS writes by the waves;
+//   * the tile's bias / length look-ups are loaded when the tile starts and consumed right after a sub-stage's barrier,
+//     when the vector-memory queue is empty, so the compiler's own wait for them costs nothing.
+// The accumulation order over K is panel -> tap -> half, identical to conv_h16.hip with 64-channel panels: plain-mode
+// results are bit-identical to that kernel.
+#include "common.hpp"
+#include "tile_walk.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace rs {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 512;
+constexpr int kRowB = 128;                      // bytes of an LDS row (one panel)
+constexpr int kPieceRows = 1024 / kRowB;        // rows per DMA piece (one wave instruction)
+constexpr unsigned kOob = 0x80000000u;
+
+struct RingArgs {
+    const unsigned short* x;     // [rows_in][cpx_in]
+    const unsigned short* w;     // ring packing [panel][tap][n_alloc][64]
+    const float* bias;           // [n_alloc]
+    unsigned short* y;           // [rows_in / 2][cpx_out]
+    const int32_t* len;
+    unsigned x_bytes, w_bytes;
+    int rows_in;
+    int P_out;
+    float inv_P_out;
+    int cpx_in, cpx_out;         // row pitches in 16-bit elements
+    int cols_out;                // logical output columns that exist in a row (plain: cpx_out; x3: 32 x panels)
+    int n_panels;
+    int n_alloc;
+    int shift_out;
+    WalkArgs walk;
+};
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
+                                                      0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                       c, 0, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ unsigned short cvt16(float f) {
+    if constexpr (F16)
+        return __builtin_bit_cast(unsigned short, (_Float16)f);
+    else
+        return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+template <bool F16>
+__device__ __forceinline__ float widen16(unsigned short u) {
+    if constexpr (F16)
+        return (float)__builtin_bit_cast(_Float16, u);
+    else
+        return __builtin_bit_cast(float, (unsigned)u << 16);
+}
+
+// one LDS-DMA piece: lane l's 16 bytes at rsrc + voff land at LDS byte lds_addr + 16 l (zeros if voff is out of range)
+__device__ __forceinline__ void dma_piece(unsigned voff, const __amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr) {
+    // the LDS address is wave-uniform by construction; readfirstlane makes that provable to the compiler ("s" operand)
+    const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                 :: "v"(voff), "s"(m0v), "s"(rsrc) : "memory");
+}
+
+// physical element index of logical output column c inside a row
+template <bool X3>
+__device__ __forceinline__ int phys_col(int c) {
+    return X3 ? ((c >> 5) << 6) + (c & 31) : c;
+}
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+template <int WM, int WN, int MT, int NT, bool F16, bool X3>
+__global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingArgs a) {
+    static_assert(WM * WN == 8, "8 waves per workgroup");
+    constexpr int BM = WM * 16 * MT;
+    constexpr int BN = WN * 16 * NT;
+    constexpr int XROWS = BM + 8;                                   // slab rows: positions m0 - 1 .. m0 + BM + 6
+    constexpr int XS = XROWS * kRowB;                               // bytes of an activation slab
+    constexpr int WS = BN * kRowB;                                  // bytes of a weight slab (one tap)
+    constexpr int XP = XROWS / kPieceRows;                          // DMA pieces per activation slab
+    constexpr int XH = (XP + 1) / 2;                                // ... issued during tap 0 (the rest during tap 1)
+    constexpr int WP = BN / kPieceRows;                             // DMA pieces per weight slab
+    constexpr int W_OFF = 2 * XS;                                   // LDS: [X slab 0][X slab 1][W tap 0][W tap 1][W tap 2]
+    static_assert(BN % kPieceRows == 0 && XROWS % kPieceRows == 0, "slabs are whole pieces");
+    static_assert(W_OFF + 3 * WS <= 160 * 1024, "LDS capacity");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int r = lane & 15, g = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, a.w_bytes, 0x00020000);
+
+    // ---- DMA source maps: lane l of a piece = row l >> 3 of the piece, physical slot l & 7, which holds the
+    // logical slot (l & 7) ^ (row & 7) (piece bases are multiples of 8 rows) --------------------------------
+    const int prow = lane >> 3, lslot = (lane & 7) ^ prow;
+    const unsigned x_lane = (unsigned)(prow * a.cpx_in + 8 * lslot) * 2u;
+    const unsigned w_lane = (unsigned)(prow * 64 + 8 * lslot) * 2u;
+
+    struct Panel {
+        int m0, n0, p;
+        bool live;
+    };
+    // pieces [lo, hi) of panel q's activation slab into slab `xb` (this wave's share: every 8th piece)
+    auto issue_x = [&](const Panel& q, int xb, int lo, int hi) {
+        const unsigned base = (unsigned)(((q.m0 - 1) * a.cpx_in + q.p * 64) * 2) + x_lane;
+        const unsigned step = (unsigned)(kPieceRows * a.cpx_in * 2);
+#pragma unroll
+        for (int k0 = 0; k0 < (XP + 7) / 8; ++k0) {
+            const int k = lo + wave + 8 * k0;
+            if (k < hi) dma_piece(base + (unsigned)k * step, rs_x, (unsigned)(xb * XS + k * 1024));
+        }
+    };
+    auto issue_w = [&](const Panel& q, int tap) {
+        const unsigned base = (unsigned)((((q.p * 3 + tap) * a.n_alloc + q.n0) * 64) * 2) + w_lane;
+#pragma unroll
+        for (int k0 = 0; k0 < (WP + 7) / 8; ++k0) {
+            const int k = wave + 8 * k0;
+            if (k < WP) dma_piece(base + (unsigned)(k * kPieceRows * 64 * 2), rs_w, (unsigned)(W_OFF + tap * WS + k * 1024));
+        }
+    };
+    auto stage_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- tile walk (tile_walk.hpp) with dead-tile elimination, as in conv_h16.hip -----------------------------
+    const int tiles = a.walk.q_total;
+    const int P_in_ = 2 * a.P_out;
+    auto tile_origin = [&](int q, int& tm0, int& tn0) -> bool {
+        int mi, nt_;
+        const bool ok = walk_tile(a.walk, q, mi, nt_);
+        tm0 = mi * BM;
+        tn0 = nt_ * BN;
+        return ok;
+    };
+    TileWalk walk;
+    auto next_live = [&]() {                                       // order index of this workgroup's next live tile
+        int q = walk.next_index(a.walk);
+        while (q < tiles) {
+            int tm0, tn0;
+            const bool valid = tile_origin(q, tm0, tn0);
+            if (valid) {
+                if (!a.walk.check_dead) break;
+                const int b = tm0 / P_in_;
+                const int t0 = tm0 - b * P_in_;
+                if (!(t0 + BM <= P_in_ && t0 >= (as_const_len(a.len)[b] >> (a.shift_out - 1)))) break;
+                // zero-fill the BM/2 x BN output tile in 16-byte pieces (x3: the hi and the lo half of every piece)
+                const int pieces_per_row = BN / 8;
+                for (int f = threadIdx.x; f < (BM / 2) * pieces_per_row; f += blockDim.x) {
+                    const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 8;
+                    const int orow = (tm0 >> 1) + rr, col = tn0 + cc;
+                    if (2 * orow < a.rows_in && col < a.cols_out) {
+                        unsigned short* dst = a.y + (int64_t)orow * a.cpx_out + phys_col<X3>(col);
+                        *reinterpret_cast<uint4*>(dst) = make_uint4(0u, 0u, 0u, 0u);
+                        if constexpr (X3) *reinterpret_cast<uint4*>(dst + 32) = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
+            }
+            q = walk.next_index(a.walk);
+        }
+        return q;
+    };
+    Panel cur;
+    {
+        const int o = next_live();
+        if (o >= tiles) return;
+        tile_origin(o, cur.m0, cur.n0);
+        cur.p = 0;
+        cur.live = true;
+    }
+
+    // ---- fragment read addresses (bytes in LDS; + xb * XS for the activation slab in use) ---------------------
+    unsigned a_rd[3][2], b_rd[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int R = wm * 16 * MT + r + tap;
+            a_rd[tap][h] = (unsigned)(R * kRowB + (((4 * h + g) ^ (R & 7)) << 4));
+        }
+        b_rd[h] = (unsigned)(W_OFF + (wn * 16 * NT + r) * kRowB + (((4 * h + g) ^ (r & 7)) << 4));
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // one sub-stage: tap TAP of the panel held in slab xb
+    auto compute = [&](auto TAP, int xb) {
+        constexpr int tap = decltype(TAP)::value;
+        const unsigned ax0 = a_rd[tap][0] + (unsigned)(xb * XS), ax1 = a_rd[tap][1] + (unsigned)(xb * XS);
+        u32x4 af[MT][2], bf[NT][2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            af[i][0] = *reinterpret_cast<const u32x4*>(lds + ax0 + i * 16 * kRowB);
+            af[i][1] = *reinterpret_cast<const u32x4*>(lds + ax1 + i * 16 * kRowB);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bf[j][0] = *reinterpret_cast<const u32x4*>(lds + b_rd[0] + tap * WS + j * 16 * kRowB);
+            bf[j][1] = *reinterpret_cast<const u32x4*>(lds + b_rd[1] + tap * WS + j * 16 * kRowB);
+        }
+        if constexpr (X3) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i][0], bf[j][0], acc[i][j]);     // hi * hi
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i][1], bf[j][0], acc[i][j]);     // lo * hi
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i][0], bf[j][1], acc[i][j]);     // hi * lo
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i][h], bf[j][h], acc[i][j]);
+        }
+    };
+
+    // ---- per-tile constants, loaded when the tile starts (see the header) -------------------------------------
+    float bias[NT];
+    int lim_[MT][2];                                  // valid output rows of the read of pooled row (i, h); -1: row not stored
+    int pin_[MT][2];                                  // position of that pooled row inside its read
+    auto load_tile_consts = [&](const Panel& q) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bias[j] = a.bias[q.n0 + (wn * NT + j) * 16 + r];
+        const int pr0 = q.m0 >> 1;
+        const int b0 = pr0 / a.P_out;
+        const int p0 = pr0 - b0 * a.P_out;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = q.m0 + (wm * MT + i) * 16 + 4 * g;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int orow = (row >> 1) + h;
+                const bool in = 2 * orow < a.rows_in;
+                const int t = p0 + (orow - pr0);
+                const int e = (int)(((float)t + 0.5f) * a.inv_P_out);
+                const int b = in ? b0 + e : 0;
+                pin_[i][h] = t - e * a.P_out;
+                lim_[i][h] = in ? (a.len[b] >> a.shift_out) : -1;
+            }
+        }
+    };
+    auto epilogue = [&](const Panel& q) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = q.m0 + (wm * MT + i) * 16 + 4 * g;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (lim_[i][h] >= 0) {
+                    const int orow = (row >> 1) + h;
+                    const bool valid = pin_[i][h] < lim_[i][h];
+                    unsigned short* yrow = a.y + (int64_t)orow * a.cpx_out;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int col = q.n0 + (wn * NT + j) * 16 + r;
+                        if (col < a.cols_out) {
+                            const float v = fmaxf(fmaxf(acc[i][j][2 * h], acc[i][j][2 * h + 1]) + bias[j], 0.0f);
+                            const unsigned short hi = valid ? cvt16<F16>(v) : (unsigned short)0;
+                            yrow[phys_col<X3>(col)] = hi;
+                            if constexpr (X3)
+                                yrow[phys_col<X3>(col) + 32] = valid ? cvt16<F16>(v - widen16<F16>(hi)) : (unsigned short)0;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    // ---- prologue: the first panel's slab and its first two tap slabs ----------------------------------------
+    issue_x(cur, 0, 0, XP);
+    issue_w(cur, 0);
+    issue_w(cur, 1);
+    stage_end();
+    load_tile_consts(cur);
+    int xb = 0;
+
+    while (true) {
+        // the panel after this one: the next panel of the tile, or panel 0 of the workgroup's next live tile
+        Panel nxt = cur;
+        ++nxt.p;
+        if (nxt.p == a.n_panels) {
+            const int o = next_live();
+            nxt.p = 0;
+            nxt.live = o < tiles;
+            if (nxt.live) tile_origin(o, nxt.m0, nxt.n0);
+        }
+        const bool tile_end = cur.p == a.n_panels - 1;
+
+        issue_w(cur, 2);
+        if (nxt.live) issue_x(nxt, xb ^ 1, 0, XH);
+        compute(std::integral_constant<int, 0>{}, xb);
+        stage_end();
+
+        if (nxt.live) {
+            issue_w(nxt, 0);
+            issue_x(nxt, xb ^ 1, XH, XP);
+        }
+        compute(std::integral_constant<int, 1>{}, xb);
+        stage_end();
+
+        if (nxt.live) issue_w(nxt, 1);
+        compute(std::integral_constant<int, 2>{}, xb);
+        stage_end();
+
+        if (tile_end) {
+            epilogue(cur);
+            if (!nxt.live) break;
+            load_tile_consts(nxt);
+        }
+        cur = nxt;
+        xb ^= 1;
+    }
+}
+
+using KernelFn = void (*)(const RingArgs);
+
+struct Shape {
+    int wm, wn, mt, nt;
+    KernelFn fn[2][2];     // [plain, x3][bf16, f16]
+};
+
+constexpr size_t lds_bytes_of(int bm, int bn) { return (size_t)(2 * (bm + 8) + 3 * bn) * kRowB; }
+
+#define RS_SHAPE(WM, WN, MT, NT)                                                                                  \
+    {WM, WN, MT, NT,                                                                                              \
+     {{conv_ring_h16_kernel<WM, WN, MT, NT, false, false>, conv_ring_h16_kernel<WM, WN, MT, NT, true, false>},   \
+      {conv_ring_h16_kernel<WM, WN, MT, NT, false, true>, conv_ring_h16_kernel<WM, WN, MT, NT, true, true>}}}
+const Shape kShapes[] = {
+    RS_SHAPE(8, 1, 2, 2), RS_SHAPE(8, 1, 2, 3), RS_SHAPE(8, 1, 2, 5), RS_SHAPE(8, 1, 2, 7), RS_SHAPE(8, 1, 4, 2),
+    RS_SHAPE(8, 1, 4, 3), RS_SHAPE(8, 1, 4, 5), RS_SHAPE(4, 2, 4, 3), RS_SHAPE(4, 2, 4, 4), RS_SHAPE(4, 2, 4, 5),
+    RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 4, 7), RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(2, 4, 4, 4),
+    RS_SHAPE(2, 4, 2, 4), RS_SHAPE(2, 4, 4, 3),
+};
+#undef RS_SHAPE
+constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
+
+size_t lds_bytes(const Shape& s) { return lds_bytes_of(s.wm * 16 * s.mt, s.wn * 16 * s.nt); }
+
+// cost model in SIMD cycles per tile: a sub-stage is bound by its MFMAs (two waves share a SIMD, 16 cycles per
+// 16x16x32) or by its DMA (~20 B/clk/CU from L2), plus a fixed barrier / first-fragment bubble; the epilogue is paid
+// per tile.  Rounds over the CUs quantise the whole.
+const Shape* choose_shape(int64_t rows, int n16, int n_panels, int num_cu, bool x3) {
+    const Shape* best = nullptr;
+    double best_cost = 1e300;
+    for (int k = 0; k < kNumShapes; ++k) {
+        const Shape& s = kShapes[k];
+        if (lds_bytes(s) > 160 * 1024) continue;
+        const int bm = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
+        const int64_t mtiles = (rows + bm - 1) / bm;
+        const int64_t ntiles = (n16 + bnt - 1) / bnt;
+        const int64_t tiles = mtiles * ntiles;
+        const int64_t rounds = (tiles + num_cu - 1) / num_cu;
+        const double mfma = (x3 ? 3.0 : 2.0) * s.mt * s.nt * 16.0 * 2.0;
+        const double dma = ((bm + 8) / 3.0 + bnt * 16.0) * 128.0 / 20.0;
+        const double ldsr = 2.0 * 8.0 * (s.mt + s.nt) * 1024.0 / 256.0 * 1.2;
+        const double sub = std::max(std::max(mfma, dma), ldsr) + 250.0;
+        const double tile = 3.0 * n_panels * sub + 1500.0 + 60.0 * s.mt * s.nt * (x3 ? 1.5 : 1.0);
+        const double cost = (double)rounds * tile;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = &s;
+        }
+    }
+    return best;
+}
+
+}  // namespace
+
+int conv_ring_max_bn() { return 256; }
+int conv_ring_num_shapes() { return kNumShapes; }
+bool conv_ring_shape_ok(const ConvLayerDev&, int k) {
+    return k >= 0 && k < kNumShapes && lds_bytes(kShapes[k]) <= 160 * 1024;
+}
+
+int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
+                         int layer_index, int num_cu, bool f16, bool x3, int check_dead, hipStream_t st, int* bm_out,
+                         int* bn_out) {
+    const int64_t rows64 = (int64_t)B * P_in;
+    if (rows64 > 0x7fffffff) {
+        set_error("conv_ring_h16: batch too large (%lld rows)", (long long)rows64);
+        return RS_ERR_ARG;
+    }
+    if (!L.d_w2) {
+        set_error("conv_ring_h16: layer %d has no ring-packed weights", layer_index);
+        return RS_ERR_ARG;
+    }
+    const int n16 = round_up(L.c_out, 16) / 16;
+    const int n_panels = L.ring_panels;
+    const Shape* s = choose_shape(rows64, n16, n_panels, num_cu, x3);
+    if (const char* force = L.hooks->force_ring; *force) {          // tuning aid: "layer:wm,wn,mt,nt;..."
+        int l, wm, wn, mt, nt;
+        for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
+            if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
+                for (int k = 0; k < kNumShapes; ++k)
+                    if (kShapes[k].wm == wm && kShapes[k].wn == wn && kShapes[k].mt == mt && kShapes[k].nt == nt &&
+                        lds_bytes(kShapes[k]) <= 160 * 1024)
+                        s = &kShapes[k];
+    }
+    if (const int k = tuned_shape(L, rows64); k >= 0 && conv_ring_shape_ok(L, k)) s = &kShapes[k];
+    if (!s) {
+        set_error("conv_ring_h16: no tile shape fits");
+        return RS_ERR_ARG;
+    }
+    const int BM = s->wm * 16 * s->mt, BN = s->wn * 16 * s->nt;
+    RingArgs a;
+    a.x = static_cast<const unsigned short*>(d_x);
+    a.w = static_cast<const unsigned short*>(L.d_w2);
+    a.bias = L.d_bias;
+    a.y = static_cast<unsigned short*>(d_y);
+    a.len = d_len;
+    const int64_t xb = rows64 * L.cp_in * 2, wb = (int64_t)n_panels * 3 * L.plan.n_alloc * 64 * 2;
+    if (xb >= 0x80000000LL || wb >= 0x80000000LL) {
+        set_error("conv_ring_h16: activation buffer exceeds the 2 GiB buffer-load window, split the batch");
+        return RS_ERR_ARG;
+    }
+    a.x_bytes = (unsigned)xb;
+    a.w_bytes = (unsigned)wb;
+    a.rows_in = (int)rows64;
+    a.P_out = P_in / 2;
+    a.inv_P_out = 1.0f / (float)a.P_out;
+    a.cpx_in = L.cp_in;
+    a.cpx_out = L.cp_out;
+    a.cols_out = x3 ? L.cp_out / 2 : L.cp_out;
+    a.n_panels = n_panels;
+    a.n_alloc = L.plan.n_alloc;
+    a.shift_out = layer_index + 1;
+    const int n_mtiles = (a.rows_in + BM - 1) / BM, n_ntiles = (n16 * 16 + BN - 1) / BN;
+    const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, BM, 3.0 * BN, check_dead, !L.hooks->no_rect_order);
+    KernelFn fn = s->fn[x3 ? 1 : 0][f16 ? 1 : 0];
+    RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes(*s), st, a);
+    RS_HIP(hipGetLastError());
+    if (bm_out) *bm_out = BM;
+    if (bn_out) *bn_out = BN;
+    return RS_OK;
+}
+
+}  // namespace rs

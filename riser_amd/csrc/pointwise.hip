@@ -6,17 +6,20 @@
 namespace rs {
 namespace {
 
-// DT: 0 = fp32, 1 = bf16, 2 = f16 (rs_dtype)
+// DT: 0 = fp32, 1 = bf16, 2 = f16, 4 = bf16 pairs, 5 = f16 pairs (rs_dtype; 4 / 5 = split precision: a value is
+// hi + lo, stored per 32-channel panel as [hi x 32 | lo x 32], see conv_ring_h16.hip)
+template <int DT>
+constexpr bool kX3 = DT == RS_BF16X3 || DT == RS_F16X3;
 template <int DT>
 __device__ __forceinline__ unsigned short to16(float f) {
-    if constexpr (DT == 2)
+    if constexpr (DT == 2 || DT == RS_F16X3)
         return __builtin_bit_cast(unsigned short, (_Float16)f);
     else
         return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 template <int DT>
 __device__ __forceinline__ float from16(unsigned short u) {
-    if constexpr (DT == 2)
+    if constexpr (DT == 2 || DT == RS_F16X3)
         return (float)__builtin_bit_cast(_Float16, u);
     else
         return __builtin_bit_cast(float, (unsigned)u << 16);
@@ -69,7 +72,27 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
             }
         }
         const int64_t piece = ((int64_t)b * P1 + p) * cq + q;     // 16-byte piece index
-        if constexpr (DT != 0) {
+        if constexpr (kX3<DT>) {
+            // channels 8q .. 8q+7 of panel q >> 2: the hi piece, and the lo piece 64 bytes behind it
+            unsigned short hi[8], lo[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                hi[j] = to16<DT>(o[j]);
+                lo[j] = to16<DT>(o[j] - from16<DT>(hi[j]));
+            }
+            const int64_t at = ((int64_t)b * P1 + p) * (2 * cq) + (q >> 2) * 8 + (q & 3);
+            uint4 v;
+            v.x = hi[0] | ((unsigned)hi[1] << 16);
+            v.y = hi[2] | ((unsigned)hi[3] << 16);
+            v.z = hi[4] | ((unsigned)hi[5] << 16);
+            v.w = hi[6] | ((unsigned)hi[7] << 16);
+            reinterpret_cast<uint4*>(yv)[at] = v;
+            v.x = lo[0] | ((unsigned)lo[1] << 16);
+            v.y = lo[2] | ((unsigned)lo[3] << 16);
+            v.z = lo[4] | ((unsigned)lo[5] << 16);
+            v.w = lo[6] | ((unsigned)lo[7] << 16);
+            reinterpret_cast<uint4*>(yv)[at + 4] = v;
+        } else if constexpr (DT != 0) {
             uint4 v;
             v.x = to16<DT>(o[0]) | ((unsigned)to16<DT>(o[1]) << 16);
             v.y = to16<DT>(o[2]) | ((unsigned)to16<DT>(o[3]) << 16);
@@ -101,6 +124,11 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(const void* __restri
     const int rows = len[b] >> n_layers;
     const float inv = 1.0f / (float)rows;
     auto ld = [&](int t, int ch) -> float {
+        if constexpr (kX3<DT>) {
+            const int64_t at = ((int64_t)b * P_last + t) * cp + ((ch >> 5) << 6) + (ch & 31);
+            const unsigned short* y16 = reinterpret_cast<const unsigned short*>(yv);
+            return from16<DT>(y16[at]) + from16<DT>(y16[at + 32]);
+        }
         const int64_t idx = ((int64_t)b * P_last + t) * cp + ch;
         if constexpr (DT != 0)
             return from16<DT>(reinterpret_cast<const unsigned short*>(yv)[idx]);
@@ -185,13 +213,16 @@ __global__ __launch_bounds__(256) void decide_kernel(const float* __restrict__ p
 int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int P0, const float* d_w4,
                  int cp_out, void* d_y, int dtype, hipStream_t st) {
     const int P1 = P0 / 2;
-    const int cq = cp_out / (dtype == RS_F32 ? 4 : 8);            // 16-byte pieces per output row
+    // 16-byte pieces of 4 (fp32) / 8 (16-bit) channels per output row; split precision: per row cp_out / 2 logical
+    // channel slots, each 8-channel group stored as a hi piece and a lo piece
+    const int cq = is_x3(dtype) ? cp_out / 16 : cp_out / (dtype == RS_F32 ? 4 : 8);
     if (cq < 1 || cq > 256) {
         set_error("conv0: unsupported first-layer width %d", cp_out);
         return RS_ERR_ARG;
     }
     dim3 grid((P1 + kC0PosPerBlock - 1) / kC0PosPerBlock, B);
-    auto fn = dtype == RS_F16 ? conv0_kernel<2> : dtype == RS_BF16 ? conv0_kernel<1> : conv0_kernel<0>;
+    auto fn = dtype == RS_F16 ? conv0_kernel<2> : dtype == RS_BF16 ? conv0_kernel<1>
+            : dtype == RS_BF16X3 ? conv0_kernel<RS_BF16X3> : dtype == RS_F16X3 ? conv0_kernel<RS_F16X3> : conv0_kernel<0>;
     hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, d_x, ldx, d_len, P1, cq, cp_out,
                        reinterpret_cast<const float4*>(d_w4), d_y);
     RS_HIP(hipGetLastError());
@@ -200,7 +231,8 @@ int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int
 
 int launch_head(const void* d_y, int dtype, int cp, int c, int P_last, int n_layers, const int32_t* d_len,
                 int B, const float* d_fcw, const float* d_fcb, float* d_probs, float* d_logits, hipStream_t st) {
-    auto fn = dtype == RS_F16 ? head_kernel<2> : dtype == RS_BF16 ? head_kernel<1> : head_kernel<0>;
+    auto fn = dtype == RS_F16 ? head_kernel<2> : dtype == RS_BF16 ? head_kernel<1>
+            : dtype == RS_BF16X3 ? head_kernel<RS_BF16X3> : dtype == RS_F16X3 ? head_kernel<RS_F16X3> : head_kernel<0>;
     hipLaunchKernelGGL(fn, dim3(B), dim3(kHeadThreads), 0, st, d_y, cp, c, P_last, n_layers, d_len, d_fcw, d_fcb, d_probs,
                        d_logits);
     RS_HIP(hipGetLastError());

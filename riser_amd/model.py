@@ -16,7 +16,8 @@ from . import _native as nv
 
 _DTYPES = {"f32": nv.RS_F32, "fp32": nv.RS_F32, "float32": nv.RS_F32,
            "bf16": nv.RS_BF16, "bfloat16": nv.RS_BF16, "f16": nv.RS_F16, "fp16": nv.RS_F16,
-           "float16": nv.RS_F16, "f32w": nv.RS_F32W, "f32_winograd": nv.RS_F32W}
+           "float16": nv.RS_F16, "f32w": nv.RS_F32W, "f32_winograd": nv.RS_F32W,
+           "bf16x3": nv.RS_BF16X3, "f16x3": nv.RS_F16X3}
 
 
 def _stream_ptr(device) -> int:
@@ -41,12 +42,14 @@ class Model:
     @staticmethod
     def dtypes():
         """Arithmetic modes this build of the library accepts (canonical names)."""
-        return ("f32w", "f32", "bf16", "f16")
+        return ("f32w", "f32", "bf16", "f16", "bf16x3", "f16x3")
 
     def __init__(self, state, config, logger, target, dtype: str = "f32w", device=None):
         """dtype: "f32w" (default; fp32 end to end, conv layers as Winograd F(2,3) / F(4,3) on the
-        f32-input MFMA), "f32" (fp32, direct lowering: exact fmaf chains), "f16" / "bf16" (16-bit
-        activations and weights, fp32 accumulate)."""
+        f32-input MFMA), "f32" (fp32, direct lowering: exact fmaf chains), "bf16x3" / "f16x3" (split
+        precision on the 16-bit MFMA: hi + lo pairs, three MFMAs per product, fp32 accumulate - the 16-bit mode
+        that stays within 1e-3 of the reference), "f16" / "bf16" (plain 16-bit activations and weights, fp32
+        accumulate: fast, approximate)."""
         self.target = target
         self.logger = logger
         self.device = self._get_device(device)
