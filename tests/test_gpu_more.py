@@ -274,7 +274,34 @@ def test_h16_streaming_layers_and_layer0_fold(dev, dtype):
     m_tiled.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32w", "f16"])
+def test_config3_ensemble_split_precision_full_size(dev):
+    """BASELINE config 3 at full size: the mRNA + mtRNA + globin stand-ins, 512 x 16000-sample chunks, one
+    rs_classify_ensemble call on the 16-bit MFMA in split precision (bf16x3).  Against the fp32 ensemble of the same
+    library on the same batch: every probability within 1e-3 and every accept / reject / try-again decision identical,
+    in both modes; and the single call equals three rs_classify calls + rs_decide bit for bit."""
+    from riser_amd.model import Model, classify_raw_ensemble
+    from riser_amd.preprocess import pack_reads
+    B, L = 512, 16000
+    spec = ((1, "mRNA"), (2, "mtRNA"), (3, "globin"))
+    x3 = [Model(synth.make_state_dict(k), synth.Config(), None, t, dtype="bf16x3", device=dev) for k, t in spec]
+    f32 = [Model(synth.make_state_dict(k), synth.Config(), None, t, dtype="f32w", device=dev) for k, t in spec]
+    sigs = synth.make_signals(SIG_SEED, B, L)
+    sig, off, ln, lh = pack_reads(list(sigs), dev)
+    for mode in (nv.RS_ENRICH, nv.RS_DEPLETE):
+        dec = torch.empty(B, dtype=torch.uint8, device=dev)
+        dec32 = torch.empty(B, dtype=torch.uint8, device=dev)
+        p = classify_raw_ensemble(x3, sig, off, ln, lh, decision=dec, max_len=L, threshold=0.9, mode=mode)
+        p32 = classify_raw_ensemble(f32, sig, off, ln, lh, decision=dec32, max_len=L, threshold=0.9, mode=mode)
+        assert float((p - p32).abs().max()) < 1e-3
+        assert torch.equal(dec, dec32), int((dec != dec32).sum())
+        assert torch.equal(p, torch.stack([m.classify_raw(sig, off, ln, lh) for m in x3]))
+    counts = np.bincount(dec.cpu().numpy(), minlength=4)
+    assert counts[nv.RS_ACCEPT] > 10 and counts[nv.RS_REJECT] > 10, counts       # a discriminating population
+    for m in x3 + f32:
+        m.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32w", "f16", "bf16x3"])
 def test_classify_ensemble_entry(dev, dtype):
     """rs_classify_ensemble (normalise once, N forwards, decision on the device) == N x rs_classify + rs_decide."""
     from riser_amd.model import Model, classify_raw_ensemble

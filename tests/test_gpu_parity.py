@@ -294,9 +294,81 @@ def test_small_custom_network(dev):
 
 
 # ------------------------------------------------------------------------------------------
-# 16-bit conv variants (BASELINE configs 3 / 5): fp32 accumulate, 16-bit activations + weights
+# 16-bit MFMA conv variants (BASELINE configs 3 / 5), fp32 accumulate.
+#   bf16x3 / f16x3  split precision (hi + lo pairs, three MFMAs per product): THE 16-bit modes that claim configs 3 / 5.
+#                   Bar = north_star's: probabilities within 1e-3 of the reference, accept / reject labels identical.
+#   f16 / bf16      plain 16-bit activations + weights: labelled "fast, approximate"; they do NOT meet 1e-3
+#                   (measured 7e-3 / 6e-2 worst over 512 reads) and are tested against their own measured envelope.
 # ------------------------------------------------------------------------------------------
-H16_TOL = {"f16": 2e-2, "bf16": 1.5e-1}     # measured: 7e-3 / 6e-2 worst over 512 reads
+X3_TOL = 1e-3                                # north_star
+H16_TOL = {"f16": 2e-2, "bf16": 1.5e-1, "bf16x3": X3_TOL, "f16x3": X3_TOL}
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3"])
+def test_split_precision_forward_vs_reference(dev, golden_dir, dtype):
+    """every golden case of the reference (14 (seed, length, batch) cases incl. 64 x 6024 and 32 x 16000), through
+    rs_forward (conv0 kernel + ring kernel on layers 1-11) and through rs_classify on the raw signals: probabilities
+    within 1e-3, labels at 0.9 identical - the same bars as the fp32 path"""
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    net = np.load(os.path.join(golden_dir, "network.npz"))
+    models = {}
+    worst = 0.0
+    for seed, L, B, first in net["cases"]:
+        tag = f"s{seed}_L{L}_B{B}_r{first}"
+        seed = int(seed)
+        if seed not in models:
+            models[seed] = Model(synth.make_state_dict(seed), synth.Config(), None, "m", dtype=dtype, device=dev)
+        sigs = synth.make_signals(int(net["sig_seed"][0]), int(B), int(L), first_read=int(first))
+        want = net[f"{tag}.probs"]
+        probs = models[seed].classify_batch([ro.mad_normalise(s) for s in sigs]).cpu().numpy()
+        sig, off, ln, lh = pack_reads(list(sigs), dev)
+        fused = models[seed].classify_raw(sig, off, ln, lh).cpu().numpy()
+        for got in (probs, fused):
+            assert np.isfinite(got).all()
+            err = float(np.abs(got - want).max())
+            worst = max(worst, err)
+            assert err < X3_TOL, (tag, err)
+            assert np.array_equal(got[:, 1] > 0.9, want[:, 1] > 0.9), tag
+    print(f"{dtype}: worst |dp| {worst:.2e} over the golden cases, no label differs")
+    for m in models.values():
+        m.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3"])
+def test_split_precision_full_size_batch(dev, dtype):
+    """BASELINE config 3 / 5 shapes at full size: 512 x 16000 (and the mixed 2 s / 3 s / 4 s batch) in split precision
+    against the fp32 path of the same library run on the same batch (itself pinned to the reference above), plus the
+    size-independent properties: idempotence, sub-batch and read-order invariance, bit for bit."""
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    B, L = 512, 16000
+    sd = synth.make_state_dict(1)
+    m = Model(sd, synth.Config(), None, "m", dtype=dtype, device=dev)
+    ref = get_model(1, dev)
+    sigs = synth.make_signals(SIG_SEED, B, L)
+    sig, off, ln, lens = pack_reads(list(sigs), dev)
+    for name in ("full", "mixed"):
+        if name == "mixed":
+            lens = np.array([(8000, 12000, 16000)[i % 3] for i in range(B)], dtype=np.int32)
+            off = torch.from_numpy(np.arange(B, dtype=np.int64) * L).to(dev)
+            ln = torch.from_numpy(lens).to(dev)
+        got = m.classify_raw(sig, off, ln, lens).cpu().numpy()
+        want = ref.classify_raw(sig, off, ln, lens).cpu().numpy()
+        assert np.abs(got - want).max() < X3_TOL, (name, float(np.abs(got - want).max()))
+        assert np.array_equal(got[:, 1] > 0.9, want[:, 1] > 0.9), name
+        assert np.array_equal(got, m.classify_raw(sig, off, ln, lens).cpu().numpy())
+        idx = torch.arange(100, 164, device=dev)
+        part = m.classify_raw(sig, off[idx].contiguous(), ln[idx].contiguous(), lens[100:164]).cpu().numpy()
+        assert np.array_equal(part, got[100:164])
+        ridx = torch.arange(B - 1, -1, -1, device=dev)
+        rev = m.classify_raw(sig, off[ridx].contiguous(), ln[ridx].contiguous(), lens[::-1].copy()).cpu().numpy()
+        assert np.array_equal(rev[::-1], got)
+    pick = [0, 17, 255, 511]
+    oracle = ro.classify_reads(sd, [sigs[k][: lens[k]] for k in pick])
+    assert np.abs(got[pick] - oracle).max() < X3_TOL
+    assert (got[:, 1] > 0.9).sum() > 10 and (got[:, 1] < 0.1).sum() > 10
+    m.close()
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
@@ -331,7 +403,7 @@ def test_h16_forward_vs_reference(dev, golden_dir, dtype):
         m.close()
 
 
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16x3", "f16x3"])
 def test_h16_mixed_lengths_and_determinism(dev, dtype):
     from riser_amd.model import Model
     m = Model(synth.make_state_dict(2), synth.Config(), None, "m", dtype=dtype, device=dev)
