@@ -60,6 +60,7 @@ struct RingArgs {
     int cols_out;                // logical output columns that exist in a row (plain: cpx_out; x3: 32 x panels)
     int n_panels;
     int n_alloc;
+    int n_reads;
     int shift_out;
     WalkArgs walk;
 };
@@ -123,9 +124,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     constexpr int XP = XROWS / kPieceRows;                          // DMA pieces per activation slab
     constexpr int XH = (XP + 1) / 2;                                // ... issued during tap 0 (the rest during tap 1)
     constexpr int WP = BN / kPieceRows;                             // DMA pieces per weight slab
-    constexpr int W_OFF = 2 * XS;                                   // LDS: [X slab 0][X slab 1][W tap 0][W tap 1][W tap 2]
+    constexpr int W_OFF = 2 * XS;                                   // LDS: [X slab 0][X slab 1][W tap 0][W tap 1][W tap 2][bias][len]
+    // per-tile constants, double buffered (a fast wave issues the next tile's while a slow one is still in its epilogue):
+    // 1 KiB = the tile's BN bias values (fp32), 1 KiB = lengths of the reads the tile's rows belong to
+    constexpr int CONST_OFF = W_OFF + 3 * WS;
     static_assert(BN % kPieceRows == 0 && XROWS % kPieceRows == 0, "slabs are whole pieces");
-    static_assert(W_OFF + 3 * WS <= 160 * 1024, "LDS capacity");
+    static_assert(BN <= 256, "one piece holds the tile's bias values");
+    static_assert(CONST_OFF + 4096 <= 160 * 1024, "LDS capacity");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x;
@@ -138,6 +143,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)a.n_alloc * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_l =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.len), 0, (unsigned)a.n_reads * 4u, 0x00020000);
 
     // ---- DMA source maps: lane l of a piece = row l >> 3 of the piece, physical slot l & 7, which holds the
     // logical slot (l & 7) ^ (row & 7) (piece bases are multiples of 8 rows) --------------------------------
@@ -145,31 +154,45 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     const unsigned x_lane = (unsigned)(prow * a.cpx_in + 8 * lslot) * 2u;
     const unsigned w_lane = (unsigned)(prow * 64 + 8 * lslot) * 2u;
 
+    // a panel of the walk: tile origin (m0, n0) and panel index p; plain ints (a struct with a bool member goes through
+    // scratch when it is copied in the loop)
     struct Panel {
         int m0, n0, p;
-        bool live;
     };
-    // pieces [lo, hi) of panel q's activation slab into slab `xb` (this wave's share: every 8th piece)
+    // ---- DMA pieces.  Every wave issues every 8th piece of a slab: piece k = wave + 8 * idx ---------------------
+    constexpr int WPW = (WP + 7) / 8;                               // weight pieces per wave and sub-stage
+    constexpr int XPW0 = (XH + 7) / 8, XPW1 = (XP - XH + 7) / 8;    // activation pieces per wave in taps 0 / 1
+    // The number of pieces a wave issues per sub-stage is STATIC (the stage-end wait counts them): a wave whose share
+    // of a slab has run out re-issues the slab's last piece (same bytes to the same LDS rows as the wave that owns it),
+    // and when there is no next panel (`live` false) the pieces are issued out of range (zeros into slabs nobody reads).
+    auto issue_x_piece = [&](const Panel& q, bool live, int xb, int lo, int hi, int idx) {
+        const int k = min(lo + wave + 8 * idx, hi - 1);
+        const unsigned off = (unsigned)(((q.m0 - 1 + k * kPieceRows) * a.cpx_in + q.p * 64) * 2) + x_lane;
+        dma_piece(live ? off : kOob, rs_x, (unsigned)(xb * XS + k * 1024));
+    };
+    auto issue_w_piece = [&](const Panel& q, bool live, int tap, int idx) {
+        const int k = min(wave + 8 * idx, WP - 1);
+        const unsigned off = (unsigned)((((q.p * 3 + tap) * a.n_alloc + q.n0 + k * kPieceRows) * 64) * 2) + w_lane;
+        dma_piece(live ? off : kOob, rs_w, (unsigned)(W_OFF + tap * WS + k * 1024));
+    };
     auto issue_x = [&](const Panel& q, int xb, int lo, int hi) {
-        const unsigned base = (unsigned)(((q.m0 - 1) * a.cpx_in + q.p * 64) * 2) + x_lane;
-        const unsigned step = (unsigned)(kPieceRows * a.cpx_in * 2);
 #pragma unroll
-        for (int k0 = 0; k0 < (XP + 7) / 8; ++k0) {
-            const int k = lo + wave + 8 * k0;
-            if (k < hi) dma_piece(base + (unsigned)k * step, rs_x, (unsigned)(xb * XS + k * 1024));
-        }
+        for (int idx = 0; idx < (XP + 7) / 8; ++idx) issue_x_piece(q, true, xb, lo, hi, idx);
     };
     auto issue_w = [&](const Panel& q, int tap) {
-        const unsigned base = (unsigned)((((q.p * 3 + tap) * a.n_alloc + q.n0) * 64) * 2) + w_lane;
 #pragma unroll
-        for (int k0 = 0; k0 < (WP + 7) / 8; ++k0) {
-            const int k = wave + 8 * k0;
-            if (k < WP) dma_piece(base + (unsigned)(k * kPieceRows * 64 * 2), rs_w, (unsigned)(W_OFF + tap * WS + k * 1024));
-        }
+        for (int idx = 0; idx < WPW; ++idx) issue_w_piece(q, true, tap, idx);
     };
-    auto stage_end = [&]() {
+    // End of a sub-stage: wait until at most KEEP vector-memory operations of this wave are outstanding - the KEEP
+    // pieces it issued during THIS sub-stage stay in flight across the barrier, everything older (the previous
+    // sub-stage's pieces, epilogue stores, the tile constants) has landed - then the workgroup barrier that publishes
+    // those pieces.  A piece is therefore readable two sub-stages after the one that issued it, which is when the issue
+    // schedule below first reads it.  Compiler-issued vector-memory operations all sit between a barrier and the next
+    // sub-stage's first piece, so they only ever make the counted wait stricter.
+    auto stage_end = [&](auto KEEP_) {
+        constexpr int KEEP = decltype(KEEP_)::value;
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -216,7 +239,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         if (o >= tiles) return;
         tile_origin(o, cur.m0, cur.n0);
         cur.p = 0;
-        cur.live = true;
     }
 
     // ---- fragment read addresses (bytes in LDS; + xb * XS for the activation slab in use) ---------------------
@@ -237,9 +259,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // one sub-stage: tap TAP of the panel held in slab xb
-    auto compute = [&](auto TAP, int xb) {
+    // One sub-stage: tap TAP of the panel held in slab xb.  `dma(idx)` issues the idx-th of this sub-stage's NDMA
+    // staging pieces of this wave: they are spread over the MFMA stream (a piece costs ~50 issue cycles: in program
+    // order behind an MFMA it overlaps the matrix pipe's drain instead of delaying the first MFMA after the barrier).
+    auto compute = [&](auto TAP, int xb, auto NDMA_, auto&& dma) {
         constexpr int tap = decltype(TAP)::value;
+        constexpr int NDMA = decltype(NDMA_)::value;
+        constexpr int NM = (X3 ? 3 : 2) * MT * NT;                  // MFMAs of the sub-stage
+        constexpr int GAP = NM / (NDMA + 1) > 0 ? NM / (NDMA + 1) : 1;
         const unsigned ax0 = a_rd[tap][0] + (unsigned)(xb * XS), ax1 = a_rd[tap][1] + (unsigned)(xb * XS);
         u32x4 af[MT][2], bf[NT][2];
 #pragma unroll
@@ -252,36 +279,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
             bf[j][0] = *reinterpret_cast<const u32x4*>(lds + b_rd[0] + tap * WS + j * 16 * kRowB);
             bf[j][1] = *reinterpret_cast<const u32x4*>(lds + b_rd[1] + tap * WS + j * 16 * kRowB);
         }
-        if constexpr (X3) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i][0], bf[j][0], acc[i][j]);     // hi * hi
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i][1], bf[j][0], acc[i][j]);     // lo * hi
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i][0], bf[j][1], acc[i][j]);     // hi * lo
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(af[i][h], bf[j][h], acc[i][j]);
-        }
+        static_for<NM>([&](auto N_) {
+            constexpr int n = decltype(N_)::value;
+            constexpr int pass = n / (MT * NT), ij = n % (MT * NT), i = ij / NT, j = ij % NT;
+            // plain: (h0, h0), (h1, h1);  x3: hi * hi, lo * hi, hi * lo
+            constexpr int ha = X3 ? (pass == 1 ? 1 : 0) : pass, hb = X3 ? (pass == 2 ? 1 : 0) : pass;
+            acc[i][j] = mfma16<F16>(af[i][ha], bf[j][hb], acc[i][j]);
+            if constexpr (NDMA > 0 && n % GAP == GAP - 1 && n / GAP < NDMA) dma(std::integral_constant<int, n / GAP>{});
+        });
     };
 
-    // ---- per-tile constants, loaded when the tile starts (see the header) -------------------------------------
-    float bias[NT];
-    int lim_[MT][2];                                  // valid output rows of the read of pooled row (i, h); -1: row not stored
-    int pin_[MT][2];                                  // position of that pooled row inside its read
-    auto load_tile_consts = [&](const Panel& q) {
+    // ---- per-tile constants: the tile's BN bias values and the lengths of the reads its rows belong to travel by
+    // LDS-DMA too (two pieces, issued by every wave during tap 0 of the tile's last panel, identical bytes), so the
+    // steady state holds NO compiler-tracked vector load whose wait could drain the pieces in flight ---------------
+    auto issue_tile_consts = [&](const Panel& q, int cb) {
+        dma_piece((unsigned)(q.n0 * 4 + lane * 16), rs_b, (unsigned)(CONST_OFF + cb * 2048));
+        const int b0 = (q.m0 >> 1) / a.P_out;
+        dma_piece((unsigned)(b0 * 4 + lane * 16), rs_l, (unsigned)(CONST_OFF + cb * 2048 + 1024));
+    };
+    auto epilogue = [&](const Panel& q, int cb) {
+        const float* lbias = reinterpret_cast<const float*>(lds + CONST_OFF + cb * 2048);
+        const int* llen = reinterpret_cast<const int*>(lds + CONST_OFF + cb * 2048 + 1024);
+        float bias[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bias[j] = a.bias[q.n0 + (wn * NT + j) * 16 + r];
+        for (int j = 0; j < NT; ++j) bias[j] = lbias[(wn * NT + j) * 16 + r];
         const int pr0 = q.m0 >> 1;
         const int b0 = pr0 / a.P_out;
         const int p0 = pr0 - b0 * a.P_out;
@@ -291,24 +312,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int orow = (row >> 1) + h;
-                const bool in = 2 * orow < a.rows_in;
-                const int t = p0 + (orow - pr0);
-                const int e = (int)(((float)t + 0.5f) * a.inv_P_out);
-                const int b = in ? b0 + e : 0;
-                pin_[i][h] = t - e * a.P_out;
-                lim_[i][h] = in ? (a.len[b] >> a.shift_out) : -1;
-            }
-        }
-    };
-    auto epilogue = [&](const Panel& q) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int row = q.m0 + (wm * MT + i) * 16 + 4 * g;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (lim_[i][h] >= 0) {
-                    const int orow = (row >> 1) + h;
-                    const bool valid = pin_[i][h] < lim_[i][h];
+                if (2 * orow < a.rows_in) {
+                    // read and position of the pooled row: float quotient, exact for t < 2^16 (conv_f32.hip)
+                    const int t = p0 + (orow - pr0);
+                    const int e = (int)(((float)t + 0.5f) * a.inv_P_out);
+                    const bool valid = t - e * a.P_out < (llen[e] >> a.shift_out);
                     unsigned short* yrow = a.y + (int64_t)orow * a.cpx_out;
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
@@ -332,42 +340,55 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     issue_x(cur, 0, 0, XP);
     issue_w(cur, 0);
     issue_w(cur, 1);
-    stage_end();
-    load_tile_consts(cur);
-    int xb = 0;
+    stage_end(std::integral_constant<int, 0>{});
+    int xb = 0, cb = 0;
 
     while (true) {
         // the panel after this one: the next panel of the tile, or panel 0 of the workgroup's next live tile
         Panel nxt = cur;
+        bool nxt_live = true;
         ++nxt.p;
         if (nxt.p == a.n_panels) {
             const int o = next_live();
             nxt.p = 0;
-            nxt.live = o < tiles;
-            if (nxt.live) tile_origin(o, nxt.m0, nxt.n0);
+            nxt_live = o < tiles;
+            if (nxt_live) tile_origin(o, nxt.m0, nxt.n0);
         }
         const bool tile_end = cur.p == a.n_panels - 1;
 
-        issue_w(cur, 2);
-        if (nxt.live) issue_x(nxt, xb ^ 1, 0, XH);
-        compute(std::integral_constant<int, 0>{}, xb);
-        stage_end();
-
-        if (nxt.live) {
-            issue_w(nxt, 0);
-            issue_x(nxt, xb ^ 1, XH, XP);
+        // tap 0: this panel's tap-2 weights, first half of the next panel's activation slab
+        compute(std::integral_constant<int, 0>{}, xb, std::integral_constant<int, WPW + XPW0>{}, [&](auto I_) {
+            constexpr int idx = decltype(I_)::value;
+            if constexpr (idx < WPW)
+                issue_w_piece(cur, true, 2, idx);
+            else
+                issue_x_piece(nxt, nxt_live, xb ^ 1, 0, XH, idx - WPW);
+        });
+        if (tile_end) {
+            issue_tile_consts(cur, cb);
+            stage_end(std::integral_constant<int, WPW + XPW0 + 2>{});
+        } else {
+            stage_end(std::integral_constant<int, WPW + XPW0>{});
         }
-        compute(std::integral_constant<int, 1>{}, xb);
-        stage_end();
-
-        if (nxt.live) issue_w(nxt, 1);
-        compute(std::integral_constant<int, 2>{}, xb);
-        stage_end();
+        // tap 1: the next panel's tap-0 weights, second half of its activation slab
+        compute(std::integral_constant<int, 1>{}, xb, std::integral_constant<int, WPW + XPW1>{}, [&](auto I_) {
+            constexpr int idx = decltype(I_)::value;
+            if constexpr (idx < WPW)
+                issue_w_piece(nxt, nxt_live, 0, idx);
+            else
+                issue_x_piece(nxt, nxt_live, xb ^ 1, XH, XP, idx - WPW);
+        });
+        stage_end(std::integral_constant<int, WPW + XPW1>{});
+        // tap 2: the next panel's tap-1 weights
+        compute(std::integral_constant<int, 2>{}, xb, std::integral_constant<int, WPW>{}, [&](auto I_) {
+            issue_w_piece(nxt, nxt_live, 1, decltype(I_)::value);
+        });
+        stage_end(std::integral_constant<int, WPW>{});
 
         if (tile_end) {
-            epilogue(cur);
-            if (!nxt.live) break;
-            load_tile_consts(nxt);
+            epilogue(cur, cb);
+            if (!nxt_live) break;
+            cb ^= 1;
         }
         cur = nxt;
         xb ^= 1;
@@ -381,7 +402,7 @@ struct Shape {
     KernelFn fn[2][2];     // [plain, x3][bf16, f16]
 };
 
-constexpr size_t lds_bytes_of(int bm, int bn) { return (size_t)(2 * (bm + 8) + 3 * bn) * kRowB; }
+constexpr size_t lds_bytes_of(int bm, int bn) { return (size_t)(2 * (bm + 8) + 3 * bn) * kRowB + 4096; }
 
 #define RS_SHAPE(WM, WN, MT, NT)                                                                                  \
     {WM, WN, MT, NT,                                                                                              \
@@ -389,8 +410,8 @@ constexpr size_t lds_bytes_of(int bm, int bn) { return (size_t)(2 * (bm + 8) + 3
       {conv_ring_h16_kernel<WM, WN, MT, NT, false, true>, conv_ring_h16_kernel<WM, WN, MT, NT, true, true>}}}
 const Shape kShapes[] = {
     RS_SHAPE(8, 1, 2, 2), RS_SHAPE(8, 1, 2, 3), RS_SHAPE(8, 1, 2, 5), RS_SHAPE(8, 1, 2, 7), RS_SHAPE(8, 1, 4, 2),
-    RS_SHAPE(8, 1, 4, 3), RS_SHAPE(8, 1, 4, 5), RS_SHAPE(4, 2, 4, 3), RS_SHAPE(4, 2, 4, 4), RS_SHAPE(4, 2, 4, 5),
-    RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 4, 7), RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(2, 4, 4, 4),
+    RS_SHAPE(8, 1, 4, 3), RS_SHAPE(8, 1, 4, 4), RS_SHAPE(4, 2, 4, 3), RS_SHAPE(4, 2, 4, 4), RS_SHAPE(4, 2, 4, 5),
+    RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(2, 4, 4, 4),
     RS_SHAPE(2, 4, 2, 4), RS_SHAPE(2, 4, 4, 3),
 };
 #undef RS_SHAPE
@@ -485,6 +506,7 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     a.cols_out = x3 ? L.cp_out / 2 : L.cp_out;
     a.n_panels = n_panels;
     a.n_alloc = L.plan.n_alloc;
+    a.n_reads = B;
     a.shift_out = layer_index + 1;
     const int n_mtiles = (a.rows_in + BM - 1) / BM, n_ntiles = (n16 * 16 + BN - 1) / BN;
     const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
