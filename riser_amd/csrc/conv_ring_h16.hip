@@ -33,6 +33,23 @@
 
 #include <algorithm>
 
+// Diagnostic build only (-DRS_RING_STAMPS, tools/ring_stamps.py): s_memtime sums of the sub-stage loop per wave:
+// [0] sub-stage bodies (fragment reads + MFMAs + piece issue), [1] stage-end wait + barrier, [2] epilogues,
+// [3] walk bookkeeping between sub-stages, [4] sub-stages, [5] total
+#ifdef RS_RING_STAMPS
+#define RS_STAMP(k)                                                                  \
+    do {                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        unsigned long long t__;                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");  \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        ph[k] += t__ - tl;                                                           \
+        tl = t__;                                                                    \
+    } while (0)
+#else
+#define RS_STAMP(k) do { } while (0)
+#endif
+
 namespace rs {
 namespace {
 
@@ -52,7 +69,7 @@ struct RingArgs {
     const float* bias;           // [n_alloc]
     unsigned short* y;           // [rows_in / 2][cpx_out]
     const int32_t* len;
-    unsigned x_bytes, w_bytes;
+    unsigned x_bytes, w_bytes, y_bytes;
     int rows_in;
     int P_out;
     float inv_P_out;
@@ -63,6 +80,7 @@ struct RingArgs {
     int n_reads;
     int shift_out;
     WalkArgs walk;
+    unsigned long long* stamps;  // diagnostic builds only
 };
 
 template <bool F16>
@@ -96,6 +114,26 @@ __device__ __forceinline__ void dma_piece(unsigned voff, const __amdgpu_buffer_r
     const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
                  :: "v"(voff), "s"(m0v), "s"(rsrc) : "memory");
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 -> one dword of two 16-bit values (lo in bits 0-15), round to nearest even (v_cvt_pk_{f16,bf16}_f32)
+template <bool F16>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    if constexpr (F16)
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+    else
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// value of the lane that holds the neighbouring output column (lane ^ 1)
+__device__ __forceinline__ float swap_pair(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1 /* quad_perm [1,0,3,2] */,
+                                                              0xF, 0xF, true));
 }
 
 // physical element index of logical output column c inside a row
@@ -143,6 +181,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.w), 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)a.n_alloc * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_l =
@@ -297,43 +336,77 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         const int b0 = (q.m0 >> 1) / a.P_out;
         dma_piece((unsigned)(b0 * 4 + lane * 16), rs_l, (unsigned)(CONST_OFF + cb * 2048 + 1024));
     };
-    auto epilogue = [&](const Panel& q, int cb) {
+    // ---- epilogue: bias + ReLU + MaxPool(2,2) in registers, then THROUGH LDS so that the tile leaves in 16-byte
+    // pieces of whole output-row segments (a lane of the 16x16 accumulator holds one channel of two pooled rows:
+    // direct stores would be 2 bytes wide, 2 * MT * NT (x3: twice that) of them per lane).  Per 16-row block i a wave
+    // holds 8 pooled rows x NT*16 channels: neighbouring lanes (channels c, c+1) exchange one value by DPP so that the
+    // even lane owns the channel pair of pooled row 2g and the odd lane that of row 2g+1, packs it to one dword
+    // (x3: a hi and a lo dword) and parks it in a wave-private scratch image laid out like the output row segment;
+    // the wave then reads the image back 16 bytes per lane and stores it with buffer stores (masked pieces resolve to
+    // an out-of-range offset).  The scratch aliases the activation slab the tile has just finished with; the barrier
+    // behind the epilogue keeps the next sub-stage's pieces out of it.  LDS operations of one wave execute in order,
+    // so the image needs no wait between its writes and its reads.
+    constexpr int PW = X3 ? 4 : 2;                                  // 16-byte pieces per 16-channel group of an output row
+    constexpr int PITCH = NT * PW * 16 + 16;                        // scratch row pitch: rows 2g of the 4 lane groups on distinct banks
+    constexpr int NPIECE = 8 * NT * PW;                             // pieces of one block's 8 pooled rows
+    // free at this point: the tile's last activation slab and the tap-2 weight slab (the next panel's is issued after
+    // the barrier); short tiles put waves 4-7 into the latter
+    constexpr bool SCR_IN_X = 8 * (8 * PITCH) <= XS;
+    static_assert(SCR_IN_X || (4 * (8 * PITCH) <= XS && 4 * (8 * PITCH) <= WS), "epilogue scratch fits the free slabs");
+    auto epilogue = [&](const Panel& q, int cb, int xb) {
         const float* lbias = reinterpret_cast<const float*>(lds + CONST_OFF + cb * 2048);
         const int* llen = reinterpret_cast<const int*>(lds + CONST_OFF + cb * 2048 + 1024);
+        unsigned char* scr = (SCR_IN_X || wave < 4) ? lds + xb * XS + wave * (8 * PITCH)
+                                                     : lds + W_OFF + 2 * WS + (wave - 4) * (8 * PITCH);
         float bias[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) bias[j] = lbias[(wn * NT + j) * 16 + r];
         const int pr0 = q.m0 >> 1;
         const int b0 = pr0 / a.P_out;
         const int p0 = pr0 - b0 * a.P_out;
+        const int c0 = q.n0 + wn * NT * 16;
+        const bool odd = r & 1;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int row = q.m0 + (wm * MT + i) * 16 + 4 * g;
+            const int orow0 = (q.m0 + (wm * MT + i) * 16) >> 1;      // first of the block's 8 pooled rows
+            bool valid[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int orow = (row >> 1) + h;
-                if (2 * orow < a.rows_in) {
-                    // read and position of the pooled row: float quotient, exact for t < 2^16 (conv_f32.hip)
-                    const int t = p0 + (orow - pr0);
-                    const int e = (int)(((float)t + 0.5f) * a.inv_P_out);
-                    const bool valid = t - e * a.P_out < (llen[e] >> a.shift_out);
-                    unsigned short* yrow = a.y + (int64_t)orow * a.cpx_out;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int col = q.n0 + (wn * NT + j) * 16 + r;
-                        if (col < a.cols_out) {
-                            const float v = fmaxf(fmaxf(acc[i][j][2 * h], acc[i][j][2 * h + 1]) + bias[j], 0.0f);
-                            const unsigned short hi = valid ? cvt16<F16>(v) : (unsigned short)0;
-                            yrow[phys_col<X3>(col)] = hi;
-                            if constexpr (X3)
-                                yrow[phys_col<X3>(col) + 32] = valid ? cvt16<F16>(v - widen16<F16>(hi)) : (unsigned short)0;
-                        }
-                    }
-                }
+                // read and position of pooled row 2g + h: float quotient, exact for t < 2^16 (conv_f32.hip)
+                const int t = p0 + (orow0 + 2 * g + h - pr0);
+                const int e = (int)(((float)t + 0.5f) * a.inv_P_out);
+                valid[h] = t - e * a.P_out < (llen[e] >> a.shift_out);
             }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NT; ++j) {
+                const float v0 = valid[0] ? fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]) + bias[j], 0.0f) : 0.0f;
+                const float v1 = valid[1] ? fmaxf(fmaxf(acc[i][j][2], acc[i][j][3]) + bias[j], 0.0f) : 0.0f;
+                const float got = swap_pair(odd ? v0 : v1);
+                const float ca = odd ? got : v0, cb_ = odd ? v1 : got;          // channels (r & ~1, r | 1) of row 2g + odd
+                const unsigned hi = pack2<F16>(ca, cb_);
+                unsigned char* dst = scr + (2 * g + (odd ? 1 : 0)) * PITCH + j * PW * 16 + (r & ~1) * 2;
+                *reinterpret_cast<unsigned*>(dst) = hi;
+                if constexpr (X3)
+                    *reinterpret_cast<unsigned*>(dst + 32) =
+                        pack2<F16>(ca - widen16<F16>((unsigned short)(hi & 0xffffu)), cb_ - widen16<F16>((unsigned short)(hi >> 16)));
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < (NPIECE + 63) / 64; ++u) {
+                const int qi = lane + 64 * u;
+                const int row8 = qi / (NT * PW), w = qi - row8 * (NT * PW);
+                const int jj = w / PW, part = w - jj * PW;
+                const int orow = orow0 + row8;
+                const int col = c0 + 16 * jj + 8 * (part & 1);
+                const int elem = phys_col<X3>(col) + (X3 ? 32 * (part >> 1) : 0);
+                const bool ok = qi < NPIECE && 2 * orow < a.rows_in && col < a.cols_out;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(scr + row8 * PITCH + w * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, ok ? (unsigned)(orow * a.cpx_out + elem) * 2u : kOob, 0, 0);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- prologue: the first panel's slab and its first two tap slabs ----------------------------------------
@@ -342,6 +415,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     issue_w(cur, 1);
     stage_end(std::integral_constant<int, 0>{});
     int xb = 0, cb = 0;
+#ifdef RS_RING_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = tl;
+#endif
 
     while (true) {
         // the panel after this one: the next panel of the tile, or panel 0 of the workgroup's next live tile
@@ -355,6 +432,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
             if (nxt_live) tile_origin(o, nxt.m0, nxt.n0);
         }
         const bool tile_end = cur.p == a.n_panels - 1;
+        RS_STAMP(3);
 
         // tap 0: this panel's tap-2 weights, first half of the next panel's activation slab
         compute(std::integral_constant<int, 0>{}, xb, std::integral_constant<int, WPW + XPW0>{}, [&](auto I_) {
@@ -364,12 +442,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
             else
                 issue_x_piece(nxt, nxt_live, xb ^ 1, 0, XH, idx - WPW);
         });
+        RS_STAMP(0);
         if (tile_end) {
             issue_tile_consts(cur, cb);
             stage_end(std::integral_constant<int, WPW + XPW0 + 2>{});
         } else {
             stage_end(std::integral_constant<int, WPW + XPW0>{});
         }
+        RS_STAMP(1);
         // tap 1: the next panel's tap-0 weights, second half of its activation slab
         compute(std::integral_constant<int, 1>{}, xb, std::integral_constant<int, WPW + XPW1>{}, [&](auto I_) {
             constexpr int idx = decltype(I_)::value;
@@ -378,21 +458,36 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
             else
                 issue_x_piece(nxt, nxt_live, xb ^ 1, XH, XP, idx - WPW);
         });
+        RS_STAMP(0);
         stage_end(std::integral_constant<int, WPW + XPW1>{});
+        RS_STAMP(1);
         // tap 2: the next panel's tap-1 weights
         compute(std::integral_constant<int, 2>{}, xb, std::integral_constant<int, WPW>{}, [&](auto I_) {
             issue_w_piece(nxt, nxt_live, 1, decltype(I_)::value);
         });
+        RS_STAMP(0);
         stage_end(std::integral_constant<int, WPW>{});
+        RS_STAMP(1);
+#ifdef RS_RING_STAMPS
+        ph[4] += 3;
+#endif
 
         if (tile_end) {
-            epilogue(cur, cb);
+            epilogue(cur, cb, xb);
+            RS_STAMP(2);
             if (!nxt_live) break;
             cb ^= 1;
         }
         cur = nxt;
         xb ^= 1;
     }
+#ifdef RS_RING_STAMPS
+    if (a.stamps && lane == 0 && blockIdx.x < 4) {
+        unsigned long long* q = a.stamps + (blockIdx.x * 8 + wave) * 8;
+        for (int k = 0; k < 5; ++k) q[k] = ph[k];
+        q[5] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
+#endif
 }
 
 using KernelFn = void (*)(const RingArgs);
@@ -496,8 +591,14 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
         set_error("conv_ring_h16: activation buffer exceeds the 2 GiB buffer-load window, split the batch");
         return RS_ERR_ARG;
     }
+    const int64_t yb = rows64 / 2 * L.cp_out * 2;
+    if (yb >= 0x80000000LL) {
+        set_error("conv_ring_h16: output buffer exceeds the 2 GiB buffer window, split the batch");
+        return RS_ERR_ARG;
+    }
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
+    a.y_bytes = (unsigned)yb;
     a.rows_in = (int)rows64;
     a.P_out = P_in / 2;
     a.inv_P_out = 1.0f / (float)a.P_out;
@@ -515,8 +616,28 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     KernelFn fn = s->fn[x3 ? 1 : 0][f16 ? 1 : 0];
     RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
+    a.stamps = nullptr;
+#ifdef RS_RING_STAMPS
+    static unsigned long long* d_stamps = nullptr;
+    if (!d_stamps) RS_HIP(hipMalloc(&d_stamps, 4 * 8 * 8 * 8));
+    a.stamps = d_stamps;
+#endif
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes(*s), st, a);
     RS_HIP(hipGetLastError());
+#ifdef RS_RING_STAMPS
+    {
+        RS_HIP(hipStreamSynchronize(st));
+        unsigned long long hp[4 * 8 * 8];
+        RS_HIP(hipMemcpy(hp, d_stamps, sizeof(hp), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 8; w += 4) {
+            const unsigned long long* q = &hp[w * 8];
+            const double n = (double)q[4];
+            fprintf(stderr, "[ring-stamps] layer %d %s tile %dx%d panels %d wave %d: %.0f sub-stages, total %.0f cyc; per sub-stage: "
+                    "body %.0f | wait+barrier %.0f | epilogue %.0f | walk %.0f\n", layer_index, x3 ? "x3" : "plain", BM, BN,
+                    n_panels, w, n, (double)q[5], q[0] / n, q[1] / n, q[2] / n, q[3] / n);
+        }
+    }
+#endif
     if (bm_out) *bm_out = BM;
     if (bn_out) *bn_out = BN;
     return RS_OK;
