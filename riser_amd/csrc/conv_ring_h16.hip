@@ -298,34 +298,51 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // One sub-stage: tap TAP of the panel held in slab xb.  `dma(idx)` issues the idx-th of this sub-stage's NDMA
-    // staging pieces of this wave: they are spread over the MFMA stream (a piece costs ~50 issue cycles: in program
-    // order behind an MFMA it overlaps the matrix pipe's drain instead of delaying the first MFMA after the barrier).
-    auto compute = [&](auto TAP, int xb, auto NDMA_, auto&& dma) {
+    // One sub-stage: tap TAP of the panel held in slab xb.  Its MFMAs come in PASSES over the MT x NT accumulators -
+    // plain: (h0, h0), (h1, h1); x3: hi * hi, lo * hi, hi * lo - and the LAST pass is DEFERRED to the head of the next
+    // sub-stage: right behind the barrier a wave issues the new sub-stage's first fragment reads and then has a pass of
+    // MFMAs whose operands are already in registers (`keep_a`, `keep_b`), so the matrix pipe works while the eight
+    // waves' read bursts drain through the LDS (stamps of the un-deferred loop: ~450 of ~2800 cycles per sub-stage were
+    // this bubble).  Per accumulator the MFMA order is unchanged, results are bit-identical.  `between()` runs after
+    // the deferred pass (the epilogue, when the previous sub-stage ended a tile).  `dma(idx)` issues the idx-th of this
+    // sub-stage's NDMA staging pieces of this wave, spread over the sub-stage's own passes.
+    u32x4 keep_a[MT], keep_b[NT];
+    auto deferred_pass = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(keep_a[i], keep_b[j], acc[i][j]);
+    };
+    auto substage = [&](auto TAP, int xb, bool have_prev, auto NDMA_, auto&& dma, auto&& between) {
         constexpr int tap = decltype(TAP)::value;
         constexpr int NDMA = decltype(NDMA_)::value;
-        constexpr int NM = (X3 ? 3 : 2) * MT * NT;                  // MFMAs of the sub-stage
+        constexpr int NM = (X3 ? 2 : 1) * MT * NT;                  // MFMAs of the passes executed here
         constexpr int GAP = NM / (NDMA + 1) > 0 ? NM / (NDMA + 1) : 1;
         const unsigned ax0 = a_rd[tap][0] + (unsigned)(xb * XS), ax1 = a_rd[tap][1] + (unsigned)(xb * XS);
-        u32x4 af[MT][2], bf[NT][2];
+        u32x4 a0[MT], b0[NT], a1[MT], b1[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            af[i][0] = *reinterpret_cast<const u32x4*>(lds + ax0 + i * 16 * kRowB);
-            af[i][1] = *reinterpret_cast<const u32x4*>(lds + ax1 + i * 16 * kRowB);
-        }
+        for (int j = 0; j < NT; ++j) b0[j] = *reinterpret_cast<const u32x4*>(lds + b_rd[0] + tap * WS + j * 16 * kRowB);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            bf[j][0] = *reinterpret_cast<const u32x4*>(lds + b_rd[0] + tap * WS + j * 16 * kRowB);
-            bf[j][1] = *reinterpret_cast<const u32x4*>(lds + b_rd[1] + tap * WS + j * 16 * kRowB);
-        }
+        for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const u32x4*>(lds + ax0 + i * 16 * kRowB);
+        if (have_prev) deferred_pass();
+        between();
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a1[i] = *reinterpret_cast<const u32x4*>(lds + ax1 + i * 16 * kRowB);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b1[j] = *reinterpret_cast<const u32x4*>(lds + b_rd[1] + tap * WS + j * 16 * kRowB);
         static_for<NM>([&](auto N_) {
             constexpr int n = decltype(N_)::value;
             constexpr int pass = n / (MT * NT), ij = n % (MT * NT), i = ij / NT, j = ij % NT;
-            // plain: (h0, h0), (h1, h1);  x3: hi * hi, lo * hi, hi * lo
-            constexpr int ha = X3 ? (pass == 1 ? 1 : 0) : pass, hb = X3 ? (pass == 2 ? 1 : 0) : pass;
-            acc[i][j] = mfma16<F16>(af[i][ha], bf[j][hb], acc[i][j]);
+            if constexpr (pass == 0)
+                acc[i][j] = mfma16<F16>(a0[i], b0[j], acc[i][j]);       // hi * hi  (plain: h0 * h0)
+            else
+                acc[i][j] = mfma16<F16>(a1[i], b0[j], acc[i][j]);       // lo * hi
             if constexpr (NDMA > 0 && n % GAP == GAP - 1 && n / GAP < NDMA) dma(std::integral_constant<int, n / GAP>{});
         });
+#pragma unroll
+        for (int i = 0; i < MT; ++i) keep_a[i] = X3 ? a0[i] : a1[i];   // deferred: hi * lo  (plain: h1 * h1)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) keep_b[j] = b1[j];
     };
 
     // ---- per-tile constants: the tile's BN bias values and the lengths of the reads its rows belong to travel by
@@ -420,6 +437,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     const unsigned long long t_begin = tl;
 #endif
 
+    bool have_prev = false, prev_tile_end = false;
+    Panel done = cur;                                  // the tile whose epilogue is pending (valid when prev_tile_end)
+    int done_cb = 0, done_xb = 0;
+    auto nothing = [&]() {};
     while (true) {
         // the panel after this one: the next panel of the tile, or panel 0 of the workgroup's next live tile
         Panel nxt = cur;
@@ -434,14 +455,24 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         const bool tile_end = cur.p == a.n_panels - 1;
         RS_STAMP(3);
 
-        // tap 0: this panel's tap-2 weights, first half of the next panel's activation slab
-        compute(std::integral_constant<int, 0>{}, xb, std::integral_constant<int, WPW + XPW0>{}, [&](auto I_) {
-            constexpr int idx = decltype(I_)::value;
-            if constexpr (idx < WPW)
-                issue_w_piece(cur, true, 2, idx);
-            else
-                issue_x_piece(nxt, nxt_live, xb ^ 1, 0, XH, idx - WPW);
-        });
+        // tap 0: this panel's tap-2 weights, first half of the next panel's activation slab; the previous tile's
+        // epilogue, if one is pending, runs behind its deferred pass (and before any piece is issued into its scratch)
+        substage(std::integral_constant<int, 0>{}, xb, have_prev, std::integral_constant<int, WPW + XPW0>{},
+                 [&](auto I_) {
+                     constexpr int idx = decltype(I_)::value;
+                     if constexpr (idx < WPW)
+                         issue_w_piece(cur, true, 2, idx);
+                     else
+                         issue_x_piece(nxt, nxt_live, xb ^ 1, 0, XH, idx - WPW);
+                 },
+                 [&]() {
+                     if (prev_tile_end) {
+                         RS_STAMP(0);
+                         epilogue(done, done_cb, done_xb);
+                         RS_STAMP(2);
+                     }
+                 });
+        have_prev = true;
         RS_STAMP(0);
         if (tile_end) {
             issue_tile_consts(cur, cb);
@@ -451,20 +482,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         }
         RS_STAMP(1);
         // tap 1: the next panel's tap-0 weights, second half of its activation slab
-        compute(std::integral_constant<int, 1>{}, xb, std::integral_constant<int, WPW + XPW1>{}, [&](auto I_) {
-            constexpr int idx = decltype(I_)::value;
-            if constexpr (idx < WPW)
-                issue_w_piece(nxt, nxt_live, 0, idx);
-            else
-                issue_x_piece(nxt, nxt_live, xb ^ 1, XH, XP, idx - WPW);
-        });
+        substage(std::integral_constant<int, 1>{}, xb, true, std::integral_constant<int, WPW + XPW1>{},
+                 [&](auto I_) {
+                     constexpr int idx = decltype(I_)::value;
+                     if constexpr (idx < WPW)
+                         issue_w_piece(nxt, nxt_live, 0, idx);
+                     else
+                         issue_x_piece(nxt, nxt_live, xb ^ 1, XH, XP, idx - WPW);
+                 },
+                 nothing);
         RS_STAMP(0);
         stage_end(std::integral_constant<int, WPW + XPW1>{});
         RS_STAMP(1);
         // tap 2: the next panel's tap-1 weights
-        compute(std::integral_constant<int, 2>{}, xb, std::integral_constant<int, WPW>{}, [&](auto I_) {
-            issue_w_piece(nxt, nxt_live, 1, decltype(I_)::value);
-        });
+        substage(std::integral_constant<int, 2>{}, xb, true, std::integral_constant<int, WPW>{},
+                 [&](auto I_) { issue_w_piece(nxt, nxt_live, 1, decltype(I_)::value); }, nothing);
         RS_STAMP(0);
         stage_end(std::integral_constant<int, WPW>{});
         RS_STAMP(1);
@@ -472,15 +504,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         ph[4] += 3;
 #endif
 
+        prev_tile_end = tile_end;
         if (tile_end) {
-            epilogue(cur, cb, xb);
-            RS_STAMP(2);
-            if (!nxt_live) break;
+            done = cur;
+            done_cb = cb;
+            done_xb = xb;
             cb ^= 1;
         }
+        if (!nxt_live) break;
         cur = nxt;
         xb ^= 1;
     }
+    // the walk's last sub-stage: its deferred pass and the last tile's epilogue
+    deferred_pass();
+    epilogue(done, done_cb, done_xb);
+    RS_STAMP(2);
 #ifdef RS_RING_STAMPS
     if (a.stamps && lane == 0 && blockIdx.x < 4) {
         unsigned long long* q = a.stamps + (blockIdx.x * 8 + wave) * 8;
