@@ -400,7 +400,9 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             ConvPlan& p = L.plan;
             p.kc = 32;
             p.nch = (L.c_in + 31) / 32;
-            p.n_alloc = round_up(L.c_out, 16) + std::max(conv_h16_max_bn(), conv_ring_max_bn());
+            // rows of the packed weight / bias tables: the channels (split precision: all 32 slots of the last panel,
+            // every one of which a tile covers) plus zero rows for the widest tile's overhang
+            p.n_alloc = (x3 ? 32 * ((L.c_out + 31) / 32) : round_up(L.c_out, 16)) + std::max(conv_h16_max_bn(), conv_ring_max_bn());
             if (!x3) {
                 p.nch = (L.cp_in + 31) / 32;
                 std::vector<unsigned short> wp((size_t)p.nch * 3 * p.n_alloc * 32, 0);
@@ -561,7 +563,7 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
     const bool x3 = is_x3(m->dtype);
     const bool is16 = m->dtype == RS_BF16 || m->dtype == RS_F16;          // plain 16-bit
     const bool f16 = is_f16_family(m->dtype);
-    const bool fuse0h = is16 && zero_prefix && ldx == w.P0 && m->channels[0] <= 32 &&
+    const bool fuse0h = (is16 || x3) && zero_prefix && ldx == w.P0 && m->channels[0] <= 32 &&
                         conv_stream_h16_ok(m->layers[1], w.P0 >> 1);
     int rc = RS_OK;
     if (!fuse0 && !fuse0h) rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
@@ -576,9 +578,9 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         const int check_dead = (Lmin <= 0 || (w.P0 >> i) - (Lmin >> i) >= 64) ? 1 : 0;
         // kind of kernel this layer runs: 0 streaming (not tuned), 1 F(4,3), 2 F(2,3), 3 direct fp32, 4 tiled 16-bit
         const bool stream32 = m->dtype == RS_F32W && fuse0 && i == 1 && conv_stream_f32_ok(L, m->channels[0], P_in);
-        const bool stream16 = is16 && i <= 2 && conv_stream_h16_ok(L, P_in);
+        const bool stream16 = (is16 || x3) && i <= 2 && conv_stream_h16_ok(L, P_in);
         // split precision runs the LDS-DMA ring kernel on every layer, plain 16-bit on its tiled layers with RS_H16_RING
-        const bool ring = x3 || (is16 && !stream16 && m->hooks.h16_ring && L.d_w2);
+        const bool ring = !stream16 && (x3 || (is16 && m->hooks.h16_ring && L.d_w2));
         const int kind = (stream32 || stream16) ? 0 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)
                                                             : m->dtype == RS_F32 ? 3 : 4;
         m->last_ring[i] = ring;
@@ -599,7 +601,13 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
             else if (m->dtype == RS_F32)
                 rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
                                      B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
-            else if (ring)
+            else if (stream16) {
+                const bool f0 = fuse0h && i == 1;
+                rc = launch_conv_stream_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, f16, st,
+                                            f0 ? d_x : nullptr, m->d_w0, m->channels[0], x3);
+                m->last_bm[i] = 16;
+                m->last_bn[i] = round_up(L.c_out, 16);
+            } else if (ring)
                 rc = launch_conv_ring_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, f16, x3, check_dead, st,
                                           &m->last_bm[i], &m->last_bn[i]);
             else if (is16 && i <= 2 && conv_stream_h16_ok(L, P_in)) {

@@ -142,7 +142,7 @@ int conv_wino_max_bn();
 bool conv_stream_h16_ok(const ConvLayerDev& L, int P_in);
 int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
                            int layer_index, int num_cu, bool f16, hipStream_t st, const float* fuse_xs,
-                           const float* fuse_w0, int fuse_c0);
+                           const float* fuse_w0, int fuse_c0, bool x3 = false);
 // LDS-DMA ring kernel (conv_ring_h16.hip): plain 16-bit and split-precision (x3) modes
 int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
                          int layer_index, int num_cu, bool f16, bool x3, int check_dead, hipStream_t st, int* bm_out,

@@ -600,7 +600,9 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
         set_error("conv_ring_h16: layer %d has no ring-packed weights", layer_index);
         return RS_ERR_ARG;
     }
-    const int n16 = round_up(L.c_out, 16) / 16;
+    // split precision: a row holds 32 channel slots per panel and EVERY slot must be written (the next layer multiplies
+    // the slots behind the last channel by zero weights: they have to be finite), so the tiles cover all of them
+    const int n16 = x3 ? L.cp_out / 32 : round_up(L.c_out, 16) / 16;
     const int n_panels = L.ring_panels;
     const Shape* s = choose_shape(rows64, n16, n_panels, num_cu, x3);
     if (const char* force = L.hooks->force_ring; *force) {          // tuning aid: "layer:wm,wn,mt,nt;..."

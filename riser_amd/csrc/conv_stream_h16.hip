@@ -21,6 +21,12 @@
 //     whole output rows.
 // Ring rows are 64 bytes, XOR-swizzled at 16-byte granularity exactly as in conv_h16.hip
 // (conflict-free ds_read_b128 for all three tap shifts).
+//
+// SPLIT PRECISION (X3, rs_dtype RS_BF16X3 / RS_F16X3; layout and arithmetic of conv_ring_h16.hip): activations are
+// hi + lo pairs stored per 32-channel panel as [hi x 32 | lo x 32] (128-byte rows in HBM and in the ring, swizzle
+// slot ^ (row & 7)), weights come from the ring packing [tap][n_alloc][hi x 32 | lo x 32], a product is three MFMAs
+// (hi*hi, lo*hi, hi*lo) and the epilogue splits every output once more.  Twice the weight registers: two waves per
+// SIMD instead of four.
 #include "common.hpp"
 
 #include <stdlib.h>
@@ -35,6 +41,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWaves = 4;                     // per workgroup; each wave is independent
 constexpr int kRing = 64;                     // ring rows per wave (64 bytes each): 4 sub-tiles, 3 are live
@@ -54,7 +61,7 @@ struct StreamArgs {
     const float* xs;          // FUSE0: normalised signals, flat [B * P0], preceded by 16 zero bytes
     const float* w0;          // FUSE0: layer 0 (w0, w1, w2, bias) per channel, [cp0][4] fp32
     int c0;                   // FUSE0: layer-0 channels (<= 32)
-    const unsigned short* w;  // packed [panel = 1][tap][n_alloc][32]
+    const unsigned short* w;  // packed [panel = 1][tap][n_alloc][32]; X3: ring packing [tap][n_alloc][64] = hi x 32 | lo x 32
     const float* bias;        // [n_alloc]
     void* y;                  // [rows_in / 2][cp_out] 16-bit
     const int32_t* len;
@@ -93,7 +100,23 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
         return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
+template <bool X3>
+__device__ __forceinline__ int swz(int row) {
+    return X3 ? (row & 7) : ((row >> 2) & 1) << 1;
+}
+
+template <bool F16>
+__device__ __forceinline__ float widen16(unsigned short u) {
+    if constexpr (F16)
+        return (float)__builtin_bit_cast(_Float16, u);
+    else
+        return __builtin_bit_cast(float, (unsigned)u << 16);
+}
+// lo dword of a pair of values whose hi dword (two 16-bit roundings) is `hi`
+template <bool F16>
+__device__ __forceinline__ unsigned pack2_lo(float a, float b, unsigned hi) {
+    return pack2<F16>(a - widen16<F16>((unsigned short)(hi & 0xffffu)), b - widen16<F16>((unsigned short)(hi >> 16)));
+}
 
 // max of x and the value of the lane that holds the other position of the pooling pair (lane ^ 1)
 __device__ __forceinline__ float max_pair(float x) {
@@ -101,13 +124,15 @@ __device__ __forceinline__ float max_pair(float x) {
     return fmaxf(x, __builtin_bit_cast(float, o));
 }
 
-template <bool FUSE0, int NT, bool F16>
-__global__ __launch_bounds__(kWaves * 64, 4) void conv_stream_h16_kernel(const StreamArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char ring_all[kWaves * kRing * 64];
+template <bool FUSE0, int NT, bool F16, bool X3>
+__global__ __launch_bounds__(kWaves * 64, X3 ? 2 : 4) void conv_stream_h16_kernel(const StreamArgs a) {
+    constexpr int ROWB = X3 ? 128 : 64;                         // ring row / input row of one panel
+    constexpr int NH = X3 ? 2 : 1;                              // 16-byte halves a lane handles per row: hi (and lo)
+    __shared__ __attribute__((aligned(16))) unsigned char ring_all[kWaves * kRing * ROWB];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, kq = lane >> 4;
-    unsigned char* ring = ring_all + wave * (kRing * 64);
+    unsigned char* ring = ring_all + wave * (kRing * ROWB);
 
     const int gw = blockIdx.x * kWaves + wave;                 // global wave index
     const int u0 = gw * a.sub_per_wave;                         // first sub-tile of this wave's run
@@ -119,12 +144,14 @@ __global__ __launch_bounds__(kWaves * 64, 4) void conv_stream_h16_kernel(const S
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
 
     // ---- resident operands ---------------------------------------------------------------------------
-    u32x4 wf[3][NT];                                            // A fragments: W[n = 16j + r][tap][8kq .. 8kq+7]
+    u32x4 wf[NH][3][NT];                                        // A fragments: W[n = 16j + r][tap][8kq .. 8kq+7], hi (and lo)
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            wf[t][j] = *reinterpret_cast<const u32x4*>(a.w + ((size_t)t * a.n_alloc + 16 * j + r) * 32 + 8 * kq);
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                wf[h][t][j] = *reinterpret_cast<const u32x4*>(a.w + ((size_t)t * a.n_alloc + 16 * j + r) * (32 * NH) + 32 * h + 8 * kq);
     f32x4 bias[NT];                                             // channels 16j + 4kq + q of this lane's accumulators
 #pragma unroll
     for (int j = 0; j < NT; ++j) bias[j] = *reinterpret_cast<const f32x4*>(a.bias + 16 * j + 4 * kq);
@@ -176,15 +203,25 @@ __global__ __launch_bounds__(kWaves * 64, 4) void conv_stream_h16_kernel(const S
 
     // ---- producer: one sub-tile of input rows into the ring ------------------------------------------
     constexpr int D = 4;
-    u32x4 pre[D];                                               // raw loads, D sub-tiles ahead of the producer
-    auto issue_load = [&](int u, u32x4& dst) {
+    constexpr int NL = (X3 && !FUSE0) ? 2 : 1;                  // raw 16-byte loads per lane and sub-tile
+    struct Raw {
+        u32x4 v[NL];
+    };
+    Raw pre[D];                                                 // raw loads, D sub-tiles ahead of the producer
+    auto issue_load = [&](int u, Raw& dst) {
         const int g = 16 * u + r;
         unsigned off;
         if constexpr (FUSE0)
             off = (u >= 0 && g < a.rows_in) ? (unsigned)(2 * g - 1 + 4) * 4u : kOob;        // x[2g-1 .. 2g+2]
+        else if constexpr (X3)
+            off = (u >= 0 && g < a.rows_in) ? ((unsigned)g * a.cp_in + 8 * kq) * 2u : kOob;  // hi piece; lo 64 bytes on
         else
             off = (u >= 0 && g < a.rows_in && 8 * kq < a.cp_in) ? ((unsigned)g * a.cp_in + 8 * kq) * 2u : kOob;
-        dst = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+        dst.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+        if constexpr (NL == 2) dst.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off == kOob ? kOob : off + 64u, 0, 0);
+    };
+    struct Row {
+        u32x4 v[NH];                                            // this lane's 8 channels of its row: hi (and lo)
     };
     auto conv0 = [&](const u32x4& raw, bool valid) {
         const f32x4 xv = __builtin_bit_cast(f32x4, raw);
@@ -195,23 +232,34 @@ __global__ __launch_bounds__(kWaves * 64, 4) void conv_stream_h16_kernel(const S
             const float f = fmaf(w0r[q][2], xv[3], fmaf(w0r[q][1], xv[2], fmaf(w0r[q][0], xv[1], w0r[q][3])));
             o[q] = valid ? fmaxf(fmaxf(e, f), 0.0f) : 0.0f;
         }
-        return (u32x4){pack2<F16>(o[0], o[1]), pack2<F16>(o[2], o[3]), pack2<F16>(o[4], o[5]), pack2<F16>(o[6], o[7])};
+        Row out;
+        out.v[0] = (u32x4){pack2<F16>(o[0], o[1]), pack2<F16>(o[2], o[3]), pack2<F16>(o[4], o[5]), pack2<F16>(o[6], o[7])};
+        if constexpr (X3)
+            out.v[1] = (u32x4){pack2_lo<F16>(o[0], o[1], out.v[0][0]), pack2_lo<F16>(o[2], o[3], out.v[0][1]),
+                               pack2_lo<F16>(o[4], o[5], out.v[0][2]), pack2_lo<F16>(o[6], o[7], out.v[0][3])};
+        return out;
     };
-    auto produce = [&](int u, const u32x4& raw, const SubInfo& si) {
-        u32x4 v = raw;
+    auto produce = [&](int u, const Raw& raw, const SubInfo& si) {
+        Row v;
         if constexpr (FUSE0) {
             if (u >= 0 && si.t0 + 16 <= si.l0) {
-                v = conv0(raw, true);
+                v = conv0(raw.v[0], true);
             } else if (u < 0 || (si.t0 >= si.l0 && si.t0 + 16 <= a.P_in)) {
-                v = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int h = 0; h < NH; ++h) v.v[h] = (u32x4){0u, 0u, 0u, 0u};
             } else {
                 int t, lim;
                 lane_info(si, t, lim);
-                v = conv0(raw, t < lim);
+                v = conv0(raw.v[0], t < lim);
             }
+        } else {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) v.v[h] = raw.v[h];
         }
         const int rr = (16 * u + r) & (kRing - 1);
-        *reinterpret_cast<u32x4*>(ring + rr * 64 + ((kq ^ swz(rr)) << 4)) = v;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+            *reinterpret_cast<u32x4*>(ring + rr * ROWB + (((4 * h + kq) ^ swz<X3>(rr)) << 4)) = v.v[h];
     };
 
     // ---- consumer: outputs of sub-tile u from ring rows 16u - 1 .. 16u + 16 ---------------------------
@@ -219,12 +267,32 @@ __global__ __launch_bounds__(kWaves * 64, 4) void conv_stream_h16_kernel(const S
         const unsigned rowoff = (unsigned)((16 * u + r) >> 1) * (unsigned)(a.cp_out * 2);
         const bool odd = r & 1;
         const bool dead = (si.t0 >> 1) >= (si.l0 >> 1) && si.t0 + 16 <= a.P_in;       // uniform: all outputs are zero
+        // byte offset of logical channel ch inside an output row (X3: 32-channel panels of [hi x 32 | lo x 32]) and
+        // the number of logical channel slots of a row
+        auto ch_off = [&](int ch) { return (unsigned)(X3 ? ((ch >> 5) << 6) + (ch & 31) : ch) * 2u; };
+        const int ch_lim = X3 ? a.cp_out / 2 : a.cp_out;
+        // X3: a row holds 32 channel slots per panel but only NT * 16 channels are computed: the slots behind them are
+        // written as zeros (the next layer multiplies them by zero weights, so they must be finite), and a lane stores
+        // 8 bytes: the even lane of a pooling pair the hi halves of its 4 channels, the odd lane the lo halves
+        auto zero_tail = [&]() {
+            if constexpr (X3)
+                for (int j = NT; 16 * j < ch_lim; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){0u, 0u}, rs_y,
+                                                          rowoff + ch_off(16 * j + 4 * kq) + (odd ? 64u : 0u), 0, 0);
+        };
         if (dead) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int ch = 16 * j + 4 * kq + (odd ? 2 : 0);
-                __builtin_amdgcn_raw_buffer_store_b32(0u, rs_y, ch < a.cp_out ? rowoff + (unsigned)ch * 2u : kOob, 0, 0);
+                if constexpr (X3) {
+                    const int ch = 16 * j + 4 * kq;
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){0u, 0u}, rs_y,
+                                                          ch < ch_lim ? rowoff + ch_off(ch) + (odd ? 64u : 0u) : kOob, 0, 0);
+                } else {
+                    const int ch = 16 * j + 4 * kq + (odd ? 2 : 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_y, ch < ch_lim ? rowoff + ch_off(ch) : kOob, 0, 0);
+                }
             }
+            zero_tail();
             return;
         }
         f32x4 acc[NT];
@@ -233,9 +301,18 @@ __global__ __launch_bounds__(kWaves * 64, 4) void conv_stream_h16_kernel(const S
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int rr = (16 * u + r + t - 1) & (kRing - 1);
-            const u32x4 xf = *reinterpret_cast<const u32x4*>(ring + rr * 64 + ((kq ^ swz(rr)) << 4));
+            u32x4 xf[NH];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = mfma16<F16>(wf[t][j], xf, acc[j]);
+            for (int h = 0; h < NH; ++h)
+                xf[h] = *reinterpret_cast<const u32x4*>(ring + rr * ROWB + (((4 * h + kq) ^ swz<X3>(rr)) << 4));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[j] = mfma16<F16>(wf[0][t][j], xf[0], acc[j]);               // hi * hi
+                if constexpr (X3) {
+                    acc[j] = mfma16<F16>(wf[1][t][j], xf[0], acc[j]);           // w lo * x hi
+                    acc[j] = mfma16<F16>(wf[0][t][j], xf[1], acc[j]);           // w hi * x lo
+                }
+            }
         }
         int t, lim;
         lane_info(si, t, lim);
@@ -249,11 +326,20 @@ __global__ __launch_bounds__(kWaves * 64, 4) void conv_stream_h16_kernel(const S
                 const float m = max_pair(acc[j][q]);
                 p[q] = valid ? fmaxf(m + bias[j][q], 0.0f) : 0.0f;
             }
-            const unsigned word = odd ? pack2<F16>(p[2], p[3]) : pack2<F16>(p[0], p[1]);
-            const int ch = 16 * j + 4 * kq + (odd ? 2 : 0);
-            const unsigned off = ch < a.cp_out ? rowoff + (unsigned)ch * 2u : kOob;      // rows past the end: out of range
-            __builtin_amdgcn_raw_buffer_store_b32(word, rs_y, off, 0, 0);
+            if constexpr (X3) {
+                const unsigned h0 = pack2<F16>(p[0], p[1]), h1 = pack2<F16>(p[2], p[3]);
+                const u32x2 word = odd ? (u32x2){pack2_lo<F16>(p[0], p[1], h0), pack2_lo<F16>(p[2], p[3], h1)} : (u32x2){h0, h1};
+                const int ch = 16 * j + 4 * kq;
+                const unsigned off = ch < ch_lim ? rowoff + ch_off(ch) + (odd ? 64u : 0u) : kOob;
+                __builtin_amdgcn_raw_buffer_store_b64(word, rs_y, off, 0, 0);
+            } else {
+                const unsigned word = odd ? pack2<F16>(p[2], p[3]) : pack2<F16>(p[0], p[1]);
+                const int ch = 16 * j + 4 * kq + (odd ? 2 : 0);
+                const unsigned off = ch < ch_lim ? rowoff + ch_off(ch) : kOob;           // rows past the end: out of range
+                __builtin_amdgcn_raw_buffer_store_b32(word, rs_y, off, 0, 0);
+            }
         }
+        zero_tail();
     };
 
     // ---- run: step s produces sub-tile v = u0 - 1 + s (the first one only for its last row, the last one
@@ -284,12 +370,12 @@ __global__ __launch_bounds__(kWaves * 64, 4) void conv_stream_h16_kernel(const S
 
 using KernelFn = void (*)(const StreamArgs);
 
-template <bool FUSE0>
+template <bool FUSE0, bool X3>
 KernelFn pick(int nt, bool f16) {
     switch (nt) {
-        case 1: return f16 ? conv_stream_h16_kernel<FUSE0, 1, true> : conv_stream_h16_kernel<FUSE0, 1, false>;
-        case 2: return f16 ? conv_stream_h16_kernel<FUSE0, 2, true> : conv_stream_h16_kernel<FUSE0, 2, false>;
-        default: return f16 ? conv_stream_h16_kernel<FUSE0, 3, true> : conv_stream_h16_kernel<FUSE0, 3, false>;
+        case 1: return f16 ? conv_stream_h16_kernel<FUSE0, 1, true, X3> : conv_stream_h16_kernel<FUSE0, 1, false, X3>;
+        case 2: return f16 ? conv_stream_h16_kernel<FUSE0, 2, true, X3> : conv_stream_h16_kernel<FUSE0, 2, false, X3>;
+        default: return f16 ? conv_stream_h16_kernel<FUSE0, 3, true, X3> : conv_stream_h16_kernel<FUSE0, 3, false, X3>;
     }
 }
 
@@ -297,12 +383,12 @@ KernelFn pick(int nt, bool f16) {
 
 // a layer qualifies when its input is one MFMA k-step wide and its weights fit the register budget
 bool conv_stream_h16_ok(const ConvLayerDev& L, int P_in) {
-    return L.cp_in <= 32 && L.plan.nch == 1 && L.c_out <= 48 && P_in >= 32 && !L.hooks->no_stream_h16;
+    return L.c_in <= 32 && L.plan.nch == 1 && L.c_out <= 48 && P_in >= 32 && !L.hooks->no_stream_h16;
 }
 
 int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
                            int layer_index, int num_cu, bool f16, hipStream_t st, const float* fuse_xs,
-                           const float* fuse_w0, int fuse_c0) {
+                           const float* fuse_w0, int fuse_c0, bool x3) {
     const int64_t rows64 = (int64_t)B * P_in;
     const int64_t xb = rows64 * L.cp_in * 2, yb = rows64 / 2 * L.cp_out * 2, sb = rows64 * 2 * 4;
     if (rows64 > 0x7fffffff || xb >= 0x80000000LL || yb >= 0x80000000LL || (fuse_xs && sb >= 0x80000000LL)) {
@@ -314,7 +400,11 @@ int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, co
     a.xs = fuse_xs;
     a.w0 = fuse_w0;
     a.c0 = fuse_c0;
-    a.w = static_cast<const unsigned short*>(L.d_w);
+    a.w = static_cast<const unsigned short*>(x3 ? L.d_w2 : L.d_w);
+    if (!a.w) {
+        set_error("conv_stream_h16: layer %d has no packed weights for this mode", layer_index);
+        return RS_ERR_ARG;
+    }
     a.bias = L.d_bias;
     a.y = d_y;
     a.len = d_len;
@@ -331,13 +421,15 @@ int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, co
     a.n_alloc = L.plan.n_alloc;
     a.shift_in = layer_index;
     a.n_sub = (int)((rows64 + 15) / 16);
-    // 4 workgroups (16 waves) per CU; runs of at least 32 sub-tiles so the two warm-up sub-tiles stay cheap
-    const int waves = num_cu * 4 * kWaves;
+    // 4 workgroups (16 waves) per CU - 2 in split precision (register budget); runs of at least 32 sub-tiles so the
+    // two warm-up sub-tiles stay cheap
+    const int waves = num_cu * (x3 ? 2 : 4) * kWaves;
     a.sub_per_wave = std::max(32, (a.n_sub + waves - 1) / waves);
     const int n_waves = (a.n_sub + a.sub_per_wave - 1) / a.sub_per_wave;
     const int grid = (n_waves + kWaves - 1) / kWaves;
     const int nt = (round_up(L.c_out, 16)) / 16;
-    KernelFn fn = fuse_xs ? pick<true>(nt, f16) : pick<false>(nt, f16);
+    KernelFn fn = x3 ? (fuse_xs ? pick<true, true>(nt, f16) : pick<false, true>(nt, f16))
+                     : (fuse_xs ? pick<true, false>(nt, f16) : pick<false, false>(nt, f16));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kWaves * 64), 0, st, a);
     RS_HIP(hipGetLastError());
     return RS_OK;
