@@ -171,6 +171,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     static_assert(CONST_OFF + 4096 <= 160 * 1024, "LDS capacity");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
+#ifdef RS_RING_STAMPS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -524,6 +528,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         unsigned long long* q = a.stamps + (blockIdx.x * 8 + wave) * 8;
         for (int k = 0; k < 5; ++k) q[k] = ph[k];
         q[5] = __builtin_amdgcn_s_memtime() - t_begin;
+        q[6] = t_begin - t_entry;                                  // prologue: walk set-up + first slab's round trip
+        q[7] = __builtin_amdgcn_s_memrealtime() - rt_entry;        // whole workgroup, 100 MHz ticks
     }
 #endif
 }
@@ -673,8 +679,9 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
             const unsigned long long* q = &hp[w * 8];
             const double n = (double)q[4];
             fprintf(stderr, "[ring-stamps] layer %d %s tile %dx%d panels %d wave %d: %.0f sub-stages, total %.0f cyc; per sub-stage: "
-                    "body %.0f | wait+barrier %.0f | epilogue %.0f | walk %.0f\n", layer_index, x3 ? "x3" : "plain", BM, BN,
-                    n_panels, w, n, (double)q[5], q[0] / n, q[1] / n, q[2] / n, q[3] / n);
+                    "body %.0f | wait+barrier %.0f | epilogue %.0f | walk %.0f; prologue %.0f cyc; workgroup %.1f us (%.2f GHz)\n",
+                    layer_index, x3 ? "x3" : "plain", BM, BN, n_panels, w, n, (double)q[5], q[0] / n, q[1] / n, q[2] / n,
+                    q[3] / n, (double)q[6], q[7] / 100.0, ((double)q[5] + q[6]) / (q[7] * 10.0));
         }
     }
 #endif
