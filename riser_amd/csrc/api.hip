@@ -47,7 +47,7 @@ Hooks Hooks::from_env() {
     text("RS_FORCE_SHAPE_H16", h.force_h16, sizeof(h.force_h16));
     text("RS_H16_PANEL", h.h16_panel, sizeof(h.h16_panel));
     text("RS_FORCE_SHAPE_RING", h.force_ring, sizeof(h.force_ring));
-    h.h16_ring = flag("RS_H16_RING");
+    if (const char* e = getenv("RS_H16_RING")) h.h16_ring = atoi(e) != 0;     // "0": the register-staged tiled kernel
     return h;
 }
 

@@ -65,7 +65,7 @@ struct Hooks {
     char force_h16[256] = "";
     char force_ring[256] = "";       // RS_FORCE_SHAPE_RING
     char h16_panel[128] = "";        // RS_H16_PANEL: "64" or "layer:64;..."
-    bool h16_ring = false;           // RS_H16_RING: plain 16-bit tiled layers on the LDS-DMA ring kernel
+    bool h16_ring = true;            // RS_H16_RING=0: plain 16-bit tiled layers on conv_h16.hip instead of the LDS-DMA ring kernel
     static Hooks from_env();
 };
 const Hooks& default_hooks();

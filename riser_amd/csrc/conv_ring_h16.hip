@@ -180,6 +180,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int r = lane & 15, g = lane >> 4;
+#ifdef RS_RING_YOUNG_PRIO
+    // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);

@@ -38,7 +38,7 @@ for dt in ("f32w", "bf16x3", "f16x3", "f16", "bf16"):
     m.close()
 for dt in ("f16", "bf16"):
     a = model(dt, {"RS_H16_RING": "1"})
-    b = model(dt, {"RS_H16_PANEL": "64"})
+    b = model(dt, {"RS_H16_PANEL": "64", "RS_H16_RING": "0"})
     pa = a.classify_raw(sig, off, ln, lh).cpu().numpy()
     pb = b.classify_raw(sig, off, ln, lh).cpu().numpy()
     print(f"{dt} ring vs tiled(64-channel panels): identical = {np.array_equal(pa, pb)}, max diff {np.abs(pa - pb).max():.3e}", flush=True)
@@ -48,7 +48,7 @@ B, L = 512, 16000
 sigs = synth.make_signals(SEED, B, L)
 sig, off, ln, lh = pack_reads(list(sigs), dev)
 ref = None
-for dt, env in (("f32w", {}), ("bf16x3", {}), ("f16x3", {}), ("f16", {}), ("f16", {"RS_H16_RING": "1"}), ("bf16", {"RS_H16_RING": "1"})):
+for dt, env in (("f32w", {}), ("bf16x3", {}), ("f16x3", {}), ("f16", {"RS_H16_RING": "0"}), ("f16", {}), ("bf16", {})):
     m = model(dt, env)
     for _ in range(10):
         p = m.classify_raw(sig, off, ln, lh)
