@@ -83,6 +83,8 @@ def mad_normalise(signal: np.ndarray) -> np.ndarray:
     n = signal.shape[0]
     if n == 0:
         raise ValueError("Signal must not be empty")                    # :109-110
+    if np.issubdtype(signal.dtype, np.floating):
+        return mad_normalise_float(signal)
     med, mad = median_mad(signal)
     if mad == 0:
         return np.zeros(n, dtype=np.int64)
@@ -102,6 +104,31 @@ def mad_normalise(signal: np.ndarray) -> np.ndarray:
             else:
                 v = (y[i - 1] + y[i + 1]) / 2
                 y[i] = min(max(v, -OUTLIER_LIMIT), OUTLIER_LIMIT)
+    return y
+
+
+def mad_normalise_float(signal: np.ndarray) -> np.ndarray:
+    """riser/preprocess.py:108-147 for float32 / float64 input (the retrain path's pA-scaled signals,
+    riser/retrain/preprocess.py:79).  numpy >= 2 (NEP 50) keeps the array's precision: np.median and np.abs(x - med)
+    return the input dtype T, the Python float 1.4826 adopts T in `1.4826 * mad`, so y = (x - med) / (T(1.4826) * mad)
+    and the smoothing recurrence run entirely in T.  mad == 0 gives the int64 zero array of the integer case."""
+    x = np.asarray(signal)
+    T = x.dtype.type
+    n = x.shape[0]
+    med = np.median(x)
+    mad = np.median(np.abs(x - med))
+    if mad == 0:
+        return np.zeros(n, dtype=np.int64)
+    y = ((x - med) / (T(SCALING_FACTOR) * mad)).astype(x.dtype)
+    lim = T(OUTLIER_LIMIT)
+    for i in np.flatnonzero(np.abs(y) > lim):                            # ascending; the set is fixed up front (:129)
+        if i == 0:
+            y[0] = y[1]
+        elif i == n - 1:
+            y[i] = y[i - 1]
+        else:
+            v = (y[i - 1] + y[i + 1]) / T(2)
+            y[i] = min(max(v, -lim), lim)
     return y
 
 

@@ -516,6 +516,15 @@ int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
                             static_cast<hipStream_t>(stream));
 }
 
+int rs_normalise_float(const void* d_sig, int elem_bytes, const int64_t* d_off, const int32_t* d_len, int B, void* d_out,
+                       int64_t ld, double* d_stats, void* stream) {
+    if (B < 0 || (B > 0 && (!d_sig || !d_off || !d_len || !d_out)) || (elem_bytes != 4 && elem_bytes != 8)) {
+        set_error("rs_normalise_float: null argument or element size %d not 4 / 8", elem_bytes);
+        return RS_ERR_ARG;
+    }
+    return launch_normalise_float(d_sig, elem_bytes, d_off, d_len, B, d_out, ld, d_stats, static_cast<hipStream_t>(stream));
+}
+
 static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmin, int Lmax,
                         void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream, bool zero_prefix);
 

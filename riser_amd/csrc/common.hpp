@@ -84,6 +84,9 @@ int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* 
                      float* d_out32, int64_t ld32, int32_t pad_to, double* d_out64, int64_t ld64,
                      double* d_stats, hipStream_t st, int zero_prefix = 0);
 
+int launch_normalise_float(const void* d_sig, int elem_bytes, const int64_t* d_off, const int32_t* d_len, int B, void* d_out,
+                           int64_t ld, double* d_stats, hipStream_t st);
+
 // layer 0: x fp32 [B, ldx] -> y [B*P1, cp_out] (fp32 or bf16 rows), fused bias+ReLU+maxpool
 int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int P0,
                  const float* d_w4 /* [cp_out][4] = w0,w1,w2,bias */, int cp_out,

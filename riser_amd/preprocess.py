@@ -132,6 +132,11 @@ class SignalProcessor:
     def mad_normalise(self, signal):
         if np.asarray(signal).shape[0] == 0:
             raise ValueError("Signal must not be empty")
+        if np.issubdtype(np.asarray(signal).dtype, np.floating):
+            # pA-scaled float signals (riser/retrain/preprocess.py:79): numpy keeps the input's precision end to end,
+            # float32 in -> float32 out (riser/preprocess.py:108-115 under NEP 50), and so does the float kernel
+            out, stats = self.mad_normalise_float_batch([signal], return_stats=True)
+            return np.zeros(out[0].shape[0], dtype=np.int64) if stats[0, 1] == 0 else out[0]
         out, stats = self.mad_normalise_batch([signal], return_stats=True)
         if stats[0, 1] == 0:
             # np.vectorize over Python ints yields an int64 zero array (riser/preprocess.py:122-125)
@@ -153,6 +158,34 @@ class SignalProcessor:
                                        out64.data_ptr(), lmax, stats.data_ptr(),
                                        torch.cuda.current_stream(self.device).cuda_stream), "rs_normalise")
         host = out64.cpu().numpy()
+        res = [host[i, : lens[i]].copy() for i in range(B)]
+        return (res, stats.cpu().numpy()) if return_stats else res
+
+    def mad_normalise_float_batch(self, signals, return_stats: bool = False):
+        """List of float32 (or float64) signals of one dtype -> list of arrays of that dtype, bit-identical to the
+        reference's mad_normalise on the same input (rs_normalise_float)."""
+        arrs = [np.ascontiguousarray(s) for s in signals]
+        dt = arrs[0].dtype
+        if dt not in (np.float32, np.float64) or any(a.dtype != dt for a in arrs):
+            raise TypeError("riser_amd normalises float32 or float64 signals (one dtype per batch); "
+                            f"got {sorted({str(a.dtype) for a in arrs})}")
+        if any(a.shape[0] == 0 for a in arrs):
+            raise ValueError("Signal must not be empty")
+        lens = np.array([a.shape[0] for a in arrs], dtype=np.int32)
+        offs = np.zeros(len(arrs), dtype=np.int64)
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+        tdt = torch.float32 if dt == np.float32 else torch.float64
+        dev = self.device
+        sig = torch.from_numpy(np.concatenate(arrs)).to(dev)
+        B, lmax = len(arrs), int(lens.max())
+        out = torch.empty((B, lmax), dtype=tdt, device=dev)
+        stats = torch.empty((B, 2), dtype=torch.float64, device=dev)
+        off_d, len_d = torch.from_numpy(offs).to(dev), torch.from_numpy(lens).to(dev)     # keep them alive over the call
+        nv.check(nv.lib().rs_normalise_float(sig.data_ptr(), dt.itemsize, off_d.data_ptr(), len_d.data_ptr(), B,
+                                             out.data_ptr(), lmax,
+                                             stats.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                 "rs_normalise_float")
+        host = out.cpu().numpy()
         res = [host[i, : lens[i]].copy() for i in range(B)]
         return (res, stats.cpu().numpy()) if return_stats else res
 

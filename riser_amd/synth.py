@@ -228,3 +228,30 @@ def polya_edge_cases(seed: int = 77):
     cases.append(("start_at_64000", i16([noisy(12, 64000), _quiet(seed, 10, 1500, 760), noisy(13, 2500, 520)])))
     cases.append(("end_at_64000", i16([noisy(14, 62000), _quiet(seed, 11, 2000, 760), noisy(15, 2500, 520)])))
     return cases
+
+
+def normalise_float_cases(seed: int = 20260103):
+    """[(name, float32 / float64 signal)]: pA-scaled versions (x * scale + offset, the form the retrain path feeds to
+    mad_normalise, riser/retrain/preprocess.py:79) of integer cases with outliers at both ends, runs, half-integer
+    medians and MAD = 0; tests/golden/normalise_float.npz holds the reference's outputs for them."""
+    base = make_signals(seed, 1, 5000, first_read=3, spikes=False)[0]
+
+    def spiked(pos_val):
+        s = base.copy()
+        for p, v in pos_val:
+            s[p] = v
+        return s
+
+    ints = {"synth_6024": make_signals(seed, 1, 6024, first_read=6024 % 97)[0],
+            "synth_runs_8000": make_signals(seed, 1, 8000, first_read=16)[0],
+            "out_first_two": spiked([(0, 2500), (1, 2400)]),
+            "out_last_two": spiked([(4998, 30), (4999, 2500)]),
+            "run5_then_gap_run2": spiked([(300 + k, 1500 + 37 * k) for k in range(5)] + [(306, 1700), (307, 20)]),
+            "even_half_median": np.array([1, 2, 3, 4, 5, 6, 7, 8, 100, -50] * 410, dtype=np.int16),
+            "odd_len": np.array([3, -2, 7, 7, 1, 0, 9, 11, -30000, 30000, 4] * 373, dtype=np.int16),
+            "mad0_constant": np.full(4096, 512, dtype=np.int16)}
+    out = []
+    for name, s in ints.items():
+        for dt in (np.float32, np.float64):
+            out.append((f"{name}.{np.dtype(dt).name}", (s.astype(np.float64) * 0.17548 + 3.25).astype(dt)))
+    return out

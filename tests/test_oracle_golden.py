@@ -33,6 +33,20 @@ def test_normalise_bit_exact(norm):
         assert np.array_equal(got, want), name                    # bit-exact float64
 
 
+def test_normalise_float_inputs_bit_exact(golden_dir):
+    """float32 / float64 signals (the retrain path's pA-scaled input): numpy keeps the input's precision, and so must
+    the restatement - dtype and every bit of the reference's output"""
+    g = np.load(os.path.join(golden_dir, "normalise_float.npz"))
+    cases = synth.normalise_float_cases()
+    assert [n for n, _ in cases] == [str(n) for n in g["names"]]
+    for name, x in cases:
+        want = g[f"{name}.out"]
+        got = ro.mad_normalise(x.copy())
+        assert got.dtype == want.dtype, name
+        assert np.array_equal(got, want), (name, float(np.abs(got.astype(np.float64) - want).max()))
+    assert g["mad0_constant.float32.out"].dtype == np.int64 and g["synth_6024.float32.out"].dtype == np.float32
+
+
 def test_normalise_empty_raises():
     with pytest.raises(ValueError):
         ro.mad_normalise(np.zeros(0, dtype=np.int16))

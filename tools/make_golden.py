@@ -9,7 +9,7 @@ own code returned for them.
     PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
 
 Reference entry points exercised:
-  F1  SignalProcessor.mad_normalise          riser/preprocess.py:108-147
+  F1  SignalProcessor.mad_normalise          riser/preprocess.py:108-147  (F1b: float32 / float64 inputs)
   F2  Model.classify / ConvNet.forward        riser/model.py:22-28, riser/nets/cnn.py:43-65
   F3  SequencerControl.target                 riser/control.py:11-124 (fake client)
   F4  SignalProcessor.get_polyA_end           riser/preprocess.py:42-79
@@ -105,6 +105,18 @@ def f1_normalise():
     out["names"] = np.array(names)
     np.savez_compressed(os.path.join(OUT, "normalise.npz"), **out)
     print("F1:", len(names), "cases")
+
+
+def f1b_normalise_float():
+    proc = SignalProcessor(Kit.create_from_version("RNA004"))
+    res, names = {}, []
+    for name, x in synth.normalise_float_cases():
+        y = np.asarray(proc.mad_normalise(x.copy()))
+        names.append(name)
+        res[f"{name}.out"] = y
+    res["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "normalise_float.npz"), **res)
+    print("F1b:", len(names), "float cases;", {n: str(res[f"{n}.out"].dtype) for n in names[:4]})
 
 
 # --------------------------------------------------------------------------------------
@@ -294,6 +306,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5"]
     if "f1" in which:
         f1_normalise()
+    if "f1b" in which or "f1" in which:
+        f1b_normalise_float()
     if "f4" in which:
         f4_polya()
     if "f2" in which:
