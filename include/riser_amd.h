@@ -231,10 +231,11 @@ int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out);
  * loadable by the reference's Model, no shipped config or weights).  The host folds eval-mode
  * BatchNorm into each conv and hands over an execution list; activations live in `n_buffers`
  * numbered buffers (0 = the normalised input [B, L], the rest carved from the workspace).
- * One uniform length per batch.  Parity-grade direct fp32 kernels, not the tuned hot path.
+ * One uniform length per batch.  Convs run on the f32-input MFMA (generic over k / stride / pad, not tuned per shape);
+ * also used for ConvNet configurations outside the shipped class (depth > 1, kernels other than 3).
  */
 typedef struct rs_seq_op {
-    int32_t kind;           /* 0 = conv1d (+bias, +residual, +relu), 1 = MaxPool1d(2, 2, padding 1) */
+    int32_t kind;           /* 0 = conv1d (+bias, +residual, +relu), 1 = MaxPool1d(2, 2, padding `pad` = 0 or 1) */
     int32_t src, dst, add;  /* buffer ids; add = -1 for no residual input */
     int32_t c_in, c_out, k, stride, pad, relu;
     const float* w;         /* HOST fp32 [c_out, c_in, k], BN already folded in (conv only) */

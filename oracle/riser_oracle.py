@@ -208,6 +208,31 @@ def convnet_forward(sd: dict, x: np.ndarray, acc=np.float32, return_layers: bool
     return logits
 
 
+def convnet_forward_general(sd: dict, x: np.ndarray, depth: int, acc=np.float32) -> np.ndarray:
+    """ConvNet.forward for configurations outside the shipped class (riser/nets/cnn.py:13-18,52-65): per layer `depth` x
+    [Conv1d(odd k, stride 1, zero 'same' padding, bias) -> ReLU] then MaxPool1d(2, 2); `gap_fc` classifier.
+    State-dict keys layers.{i}.{2 d}.weight / .bias (nn.Sequential indices)."""
+    n_layers = sum(1 for k in sd if k.startswith("layers.") and k.endswith(".0.weight"))
+    h = np.asarray(x, dtype=acc)[:, None, :]
+    for i in range(n_layers):
+        for d in range(depth):
+            w = np.asarray(sd[f"layers.{i}.{2 * d}.weight"]).astype(acc)
+            b = np.asarray(sd[f"layers.{i}.{2 * d}.bias"]).astype(acc)
+            k = w.shape[2]
+            p = (k - 1) // 2
+            B, C, L = h.shape
+            hp = np.zeros((B, C, L + k - 1), dtype=acc)
+            hp[:, :, p:p + L] = h
+            y = b[None, :, None] + sum(np.matmul(w[:, :, t], hp[:, :, t:t + L]) for t in range(k))
+            h = np.maximum(y, 0).astype(acc)
+        Lo = h.shape[2] // 2
+        h = np.maximum(h[:, :, 0:2 * Lo:2], h[:, :, 1:2 * Lo:2])
+    if h.shape[2] == 0:
+        raise RuntimeError("input shorter than 2**n_layers samples")
+    feat = h.mean(axis=2, dtype=acc)
+    return feat @ np.asarray(sd["classifier.2.weight"]).astype(acc).T + np.asarray(sd["classifier.2.bias"]).astype(acc)
+
+
 def softmax(logits: np.ndarray) -> np.ndarray:
     """torch.nn.functional.softmax(dim=1) (riser/model.py:27)."""
     z = logits - logits.max(axis=1, keepdims=True)

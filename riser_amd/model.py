@@ -56,10 +56,11 @@ class Model:
         if logger is not None:
             logger.info('Using %s device', self.device)
         cnn = config.cnn
-        if getattr(cnn, "classifier", "gap_fc") != "gap_fc" or int(getattr(cnn, "depth", 1)) != 1 \
-                or any(int(k) != 3 for k in cnn.kernels):
-            raise ValueError("riser_amd supports the shipped ConvNet configuration only: "
-                             "depth 1, kernel 3, classifier gap_fc (riser/model/*.yaml)")
+        if getattr(cnn, "classifier", "gap_fc") != "gap_fc":
+            # 'fc' hard-codes Linear(67 * 753, 4096) for one input length of one 4-layer net (riser/nets/cnn.py:22-27,
+            # "TODO: Hardcoded"); 'gap' cannot pass Model.classify at all: x.squeeze() (cnn.py:48-49) drops the batch
+            # dimension at batch 1 and softmax(dim=1) (riser/model.py:27) then raises
+            raise ValueError("riser_amd supports the `gap_fc` classifier (every shipped config, riser/model/*.yaml)")
         if isinstance(state, dict):
             sd = state
         else:
@@ -70,6 +71,18 @@ class Model:
         self.min_length = 1 << self.n_layers
         self.dtype = dtype
         self._keep = []
+        self._seq = None
+        self.model = self            # the reference exposes the nn.Module here; kept as an alias
+        if int(getattr(cnn, "depth", 1)) != 1 or any(int(k) != 3 for k in list(cnn.kernels)[: self.n_layers]):
+            # outside the shipped class (depth > 1 or kernels other than 3, riser/nets/cnn.py:17,52-65): the generic
+            # conv / max-pool program of csrc/seqnet.hip (f32-input MFMA, reads grouped by length)
+            from .resnet import SeqNet, build_convnet_program
+            if int(cnn.n_classes) != 2:
+                raise ValueError("riser_amd supports two-class heads only")
+            self._seq = SeqNet(*build_convnet_program(sd, cnn), device=self.device)
+            self._h = None
+            self._ws = Workspace(self.device)
+            return
         conv_w, conv_b = [], []
         c_in = 1
         for i, c_out in enumerate(self.channels):
@@ -94,7 +107,6 @@ class Model:
                  "rs_model_create")
         self._h = h
         self._ws = Workspace(self.device)
-        self.model = self            # the reference exposes the nn.Module here; kept as an alias
 
     # ------------------------------------------------------------------------------------
     def _get_device(self, device=None):
@@ -110,6 +122,22 @@ class Model:
         h, self._h = getattr(self, "_h", None), None
         if h:
             nv.lib().rs_model_destroy(h)
+        seq, self._seq = getattr(self, "_seq", None), None
+        if seq is not None:
+            seq.close()
+
+    def _seq_forward(self, x: torch.Tensor, lens_host: np.ndarray, return_logits: bool, out):
+        """generic program: one uniform length per launch, so reads are grouped by length"""
+        B = x.shape[0]
+        probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
+        logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
+        for L in np.unique(lens_host):
+            idx = torch.from_numpy(np.flatnonzero(lens_host == L)).to(self.device)
+            r = self._seq.forward(x[idx, : int(L)].contiguous(), return_logits)
+            probs[idx] = r[0] if return_logits else r
+            if return_logits:
+                logits[idx] = r[1]
+        return (probs, logits) if return_logits else probs
 
     def __del__(self):
         try:
@@ -118,6 +146,8 @@ class Model:
             pass
 
     def padded_length(self, lmax: int) -> int:
+        if self._seq is not None:
+            return int(lmax)
         return nv.lib().rs_padded_length(self._h, int(lmax))
 
     def layer_info(self):
@@ -193,6 +223,8 @@ class Model:
         lmax = int(lens_host.max())
         if lmax > ldx:
             raise ValueError("a length exceeds the row pitch")
+        if self._seq is not None:
+            return self._seq_forward(x, np.asarray(lens_host), return_logits, out)
         mb = self.max_batch(lmax)
         if B > mb:                                                     # split: reads are independent
             probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
@@ -223,6 +255,12 @@ class Model:
         self._check_lengths(lens_host)
         B = int(lens_host.shape[0])
         lmax = int(lens_host.max())
+        if self._seq is not None:                                      # generic program: normalise, then group by length
+            xn = torch.empty((B, lmax), dtype=torch.float32, device=self.device)
+            nv.check(nv.lib().rs_normalise(sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), B, lmax,
+                                           xn.data_ptr(), lmax, lmax, None, 0, None, _stream_ptr(self.device)),
+                     "rs_normalise")
+            return self._seq_forward(xn, np.asarray(lens_host), return_logits, out)
         mb = self.max_batch(lmax)
         if B > mb:                                                     # split: reads are independent
             probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)

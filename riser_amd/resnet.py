@@ -43,7 +43,7 @@ def build_program(sd, c):
     # stem (resnet.py:79-84): conv(bias) + BN + ReLU, MaxPool1d(2, 2, padding 1)
     w, b = _fold(sd["conv_block.0.weight"], sd, "conv_block.1", sd["conv_block.0.bias"])
     conv(0, 1, w, b, int(c.stride), int(c.padding), True)
-    ops.append(dict(kind=1, src=1, dst=2, add=-1))
+    ops.append(dict(kind=1, src=1, dst=2, add=-1, pad=1))
     cur, in_ch = 2, int(c.channels[0])
     bottleneck = c.block == "bottleneck"
     n_buffers = 7
@@ -78,19 +78,29 @@ def build_program(sd, c):
     return ops, n_buffers, fw, fb, in_ch
 
 
-class ResNetModel:
-    def __init__(self, state, config, logger, target, device=None):
-        self.target, self.logger = target, logger
+def program_flops(prog, L: int) -> float:
+    """conv FLOPs of one chunk of L samples through a program of build_program / build_convnet_program:
+    2 * c_in * c_out * k per output position of every conv."""
+    T, fl = {0: L}, 0.0
+    for o in prog:
+        if o["kind"] == 0:
+            co, ci, k = o["w"].shape
+            t_out = (T[o["src"]] + 2 * o["pad"] - k) // o["stride"] + 1
+            fl += 2.0 * ci * co * k * t_out
+        else:
+            t_out = T[o["src"]] // 2 + (1 if o.get("pad", 1) else 0)
+        T[o["dst"]] = t_out
+    return fl
+
+
+class SeqNet:
+    """A conv / max-pool program on the device (rs_seqnet_*): uniform-length batches [B, L] -> probabilities."""
+
+    def __init__(self, prog, n_buffers, fw, fb, c_last, device):
         nv.require_gpu()
         d = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
-        c = config.resnet
-        sd = state if isinstance(state, dict) else torch.load(state, map_location="cpu")
-        sd = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
-        if int(c.n_classes) != 2:
-            raise ValueError("riser_amd supports two-class heads only")
-        prog, n_buffers, fw, fb, c_last = build_program(sd, c)
-        self._keep = prog
+        self._keep = (prog, fw, fb)
         ops = []
         for o in prog:
             if o["kind"] == 0:
@@ -98,7 +108,7 @@ class ResNetModel:
                 ops.append(nv.SeqOp(0, o["src"], o["dst"], o["add"], w.shape[1], w.shape[0], w.shape[2], o["stride"],
                                     o["pad"], o["relu"], w.ctypes.data, b.ctypes.data))
             else:
-                ops.append(nv.SeqOp(1, o["src"], o["dst"], -1, 0, 0, 0, 0, 0, 0, None, None))
+                ops.append(nv.SeqOp(1, o["src"], o["dst"], -1, 0, 0, 0, 0, int(o.get("pad", 1)), 0, None, None))
         arr = (nv.SeqOp * len(ops))(*ops)
         h = C.c_void_p()
         nv.check(nv.lib().rs_seqnet_create(arr, len(ops), n_buffers, fw.ctypes.data, fb.ctypes.data, c_last,
@@ -117,12 +127,8 @@ class ResNetModel:
         except Exception:
             pass
 
-    def classify(self, signal):
-        return self.classify_batch(np.asarray(signal)[None, :])[0]
-
-    def classify_batch(self, signals, return_logits: bool = False):
-        """signals: [B, L] normalised (one common length).  Returns fp32 [B, 2] on the device."""
-        x = torch.as_tensor(np.ascontiguousarray(signals)).to(self.device, dtype=torch.float).contiguous()
+    def forward(self, x: torch.Tensor, return_logits: bool = False):
+        """x: fp32 device tensor [B, L] (one common length) -> fp32 [B, 2] on the device."""
         B, L = x.shape
         lib = nv.lib()
         need = lib.rs_seqnet_workspace_bytes(self._h, B, L)
@@ -136,3 +142,52 @@ class ResNetModel:
                                        probs.data_ptr(), logits.data_ptr() if return_logits else None,
                                        torch.cuda.current_stream(self.device).cuda_stream), "rs_seqnet_forward")
         return (probs, logits) if return_logits else probs
+
+
+def build_convnet_program(sd, cnn):
+    """(ops, n_buffers, fc_w, fc_b, c_last) of a reference ConvNet (riser/nets/cnn.py:8-65) of ANY depth and odd kernel
+    sizes with the `gap_fc` classifier: per layer `depth` x [Conv1d(k, stride 1, 'same') + ReLU], then MaxPool1d(2, 2).
+    State-dict keys: layers.{i}.{2 d}.weight / .bias (nn.Sequential indices of cnn.py:52-65), classifier.2.*"""
+    ops = []
+    n_buffers = 3
+    cur = 0
+    depth = int(getattr(cnn, "depth", 1))
+    for i in range(int(cnn.n_layers)):
+        k = int(cnn.kernels[i])
+        if k % 2 == 0:
+            raise ValueError("riser_amd: even conv kernels ('same' pads them asymmetrically) are not supported")
+        for d in range(depth):
+            w = np.ascontiguousarray(sd[f"layers.{i}.{2 * d}.weight"], dtype=np.float32)
+            b = np.ascontiguousarray(sd[f"layers.{i}.{2 * d}.bias"], dtype=np.float32)
+            dst = 1 if cur != 1 else 2
+            ops.append(dict(kind=0, src=cur, dst=dst, add=-1, w=w, b=b, stride=1, pad=(k - 1) // 2, relu=1))
+            cur = dst
+        dst = 1 if cur != 1 else 2
+        ops.append(dict(kind=1, src=cur, dst=dst, add=-1, pad=0))
+        cur = dst
+    fw = np.ascontiguousarray(sd["classifier.2.weight"], dtype=np.float32)
+    fb = np.ascontiguousarray(sd["classifier.2.bias"], dtype=np.float32)
+    return ops, n_buffers, fw, fb, int(cnn.channels[int(cnn.n_layers) - 1])
+
+
+class ResNetModel:
+    def __init__(self, state, config, logger, target, device=None):
+        self.target, self.logger = target, logger
+        c = config.resnet
+        sd = state if isinstance(state, dict) else torch.load(state, map_location="cpu")
+        sd = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
+        if int(c.n_classes) != 2:
+            raise ValueError("riser_amd supports two-class heads only")
+        self._net = SeqNet(*build_program(sd, c), device=device)
+        self.device = self._net.device
+
+    def close(self):
+        self._net.close()
+
+    def classify(self, signal):
+        return self.classify_batch(np.asarray(signal)[None, :])[0]
+
+    def classify_batch(self, signals, return_logits: bool = False):
+        """signals: [B, L] normalised (one common length).  Returns fp32 [B, 2] on the device."""
+        x = torch.as_tensor(np.ascontiguousarray(signals)).to(self.device, dtype=torch.float).contiguous()
+        return self._net.forward(x, return_logits)

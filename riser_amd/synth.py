@@ -255,3 +255,56 @@ def normalise_float_cases(seed: int = 20260103):
         for dt in (np.float32, np.float64):
             out.append((f"{name}.{np.dtype(dt).name}", (s.astype(np.float64) * 0.17548 + 3.25).astype(dt)))
     return out
+
+
+RESNET_BENCH_CFG = dict(channels=[20, 30, 45, 67], kernel=19, padding=5, stride=3, block="basic", n_layers=4,
+                        blocks=[2, 2, 2, 2], n_classes=2)
+
+
+def make_resnet_state_dict(seed: int, cfg: dict = None) -> dict:
+    """Reference-format ResNet state dict (riser/nets/resnet.py:72-99) from the integer hash: He-style conv weights,
+    BatchNorm with non-trivial running statistics (so that folding is exercised).  The reference ships no ResNet config
+    or weights; the default shape is the SquiggleNet-like stack the ConvNet's channel list descends from."""
+    cfg = cfg or RESNET_BENCH_CFG
+    sd, stream = {}, [0]
+
+    def u(n):
+        stream[0] += 1
+        return uniform_pm1(seed, 5000 + stream[0], n)
+
+    def conv(name, co, ci, k, bias=False):
+        sd[name + ".weight"] = (u(co * ci * k) * np.float32(np.sqrt(3.0 / (ci * k)))).reshape(co, ci, k).astype(np.float32)
+        if bias:
+            sd[name + ".bias"] = (u(co) * np.float32(0.05)).astype(np.float32)
+
+    def bn(name, c):
+        sd[name + ".weight"] = (1.0 + 0.3 * u(c)).astype(np.float32)
+        sd[name + ".bias"] = (0.1 * u(c)).astype(np.float32)
+        sd[name + ".running_mean"] = (0.2 * u(c)).astype(np.float32)
+        sd[name + ".running_var"] = (1.0 + 0.5 * u(c)).astype(np.float32)
+
+    ch = cfg["channels"]
+    conv("conv_block.0", ch[0], 1, cfg["kernel"], bias=True)
+    bn("conv_block.1", ch[0])
+    in_ch = ch[0]
+    bottleneck = cfg["block"] == "bottleneck"
+    for i in range(cfg["n_layers"]):
+        out_ch = ch[i]
+        for j in range(cfg["blocks"][i]):
+            stride = 2 if (i > 0 and j == 0) else 1
+            pre = f"layers.{i}.{j}"
+            if in_ch != out_ch or stride != 1:
+                conv(pre + ".shortcut.0", out_ch, in_ch, 1)
+                bn(pre + ".shortcut.1", out_ch)
+            if bottleneck:
+                mid = out_ch // 4
+                conv(pre + ".blocks.0.0", mid, in_ch, 1); bn(pre + ".blocks.0.1", mid)
+                conv(pre + ".blocks.1.0", mid, mid, 3); bn(pre + ".blocks.1.1", mid)
+                conv(pre + ".blocks.2.0", out_ch, mid, 1); bn(pre + ".blocks.2.1", out_ch)
+            else:
+                conv(pre + ".blocks.0.0", out_ch, in_ch, 3); bn(pre + ".blocks.0.1", out_ch)
+                conv(pre + ".blocks.1.0", out_ch, out_ch, 3); bn(pre + ".blocks.1.1", out_ch)
+            in_ch = out_ch
+    sd["decoder.2.weight"] = (u(cfg["n_classes"] * in_ch) * np.float32(0.3)).reshape(cfg["n_classes"], in_ch).astype(np.float32)
+    sd["decoder.2.bias"] = (u(cfg["n_classes"]) * np.float32(0.1)).astype(np.float32)
+    return sd

@@ -357,6 +357,48 @@ def test_oversized_batches_are_split(dev, monkeypatch):
     m.close()
 
 
+def test_convnet_variants_against_reference(dev, golden_dir):
+    """ConvNet configurations outside the shipped class - depth 2 / 3, kernels 5 and 7 (riser/nets/cnn.py:17,52-65) -
+    run the generic MFMA conv program (csrc/seqnet.hip) behind the same Model surface: classify(signal), batched
+    mixed-length calls and the fused raw-read entry, against the reference's own probabilities; the scalar conv kernel
+    (RS_SEQ_SCALAR=1) must agree with the MFMA one to fp32 round-off; unsupported classifiers are refused."""
+    import json
+    from conftest import hooked_model
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    g = np.load(os.path.join(golden_dir, "convnet_variants.npz"))
+    for name in ("depth2_k5373", "depth1_k7", "depth3_k3"):
+        cfg = json.loads(str(g[f"{name}.cfg"]))
+        sd = {k[len(name) + 4:]: g[k] for k in g.files if k.startswith(name + ".sd.")}
+        config = synth.Config(synth.CnnConfig(channels=cfg["channels"], kernels=cfg["kernels"], depth=cfg["depth"]))
+        m = Model(sd, config, None, "x", device=dev)
+        lens, want = g[f"{name}.lens"], g[f"{name}.probs"]
+        sigs = [synth.make_signals(SIG_SEED, 1, int(L), first_read=60 + j)[0] for j, L in enumerate(lens)]
+        xs = [ro.mad_normalise(s) for s in sigs]
+        for j, x in enumerate(xs):
+            one = m.classify(x)
+            assert one.shape == (2,) and np.abs(one.cpu().numpy() - want[j]).max() < 1e-3, (name, j)
+        got = m.classify_batch(xs + xs[::-1]).cpu().numpy()                  # mixed lengths: grouped by length inside
+        assert np.abs(got[: len(xs)] - want).max() < 1e-3 and np.array_equal(got[len(xs):], got[: len(xs)][::-1])
+        sig, off, ln, lh = pack_reads(sigs, dev)
+        assert np.abs(m.classify_raw(sig, off, ln, lh).cpu().numpy() - want).max() < 1e-3
+        with pytest.raises(ValueError):
+            m.classify(np.zeros((1 << cfg["n_layers"]) - 1))
+        os.environ["RS_SEQ_SCALAR"] = "1"
+        try:
+            ms = Model(sd, config, None, "x", device=dev)
+        finally:
+            del os.environ["RS_SEQ_SCALAR"]
+        assert np.abs(ms.classify_batch(xs).cpu().numpy() - got[: len(xs)]).max() < 1e-5
+        ms.close()
+        m.close()
+    for clf in ("gap", "fc"):
+        with pytest.raises(ValueError):
+            Model(synth.make_state_dict(1), synth.Config(synth.CnnConfig(classifier=clf)), None, "x", device=dev)
+    with pytest.raises(ValueError):                                           # even kernels: 'same' pads asymmetrically
+        Model({}, synth.Config(synth.CnnConfig(channels=[4, 4], kernels=[4, 3])), None, "x", device=dev)
+
+
 def test_promethion_per_gpu_shape(dev):
     """BASELINE config 4, the per-GPU share: 18 000 x 16000-sample chunks resident in HBM, walked in sub-batches
     (riser_amd.stream.classify_resident).  No oracle at this size, so: (a) a sample against the oracle, (b) bit

@@ -84,6 +84,26 @@ def test_polya_edge_cases(golden_dir):
     assert want["plateau_never_ends"] == -1 and want["rolling_mean_zero"] > 0 and want["end_beyond_65536"] > 65536
 
 
+def _variant_cases(golden_dir):
+    import json
+    g = np.load(os.path.join(golden_dir, "convnet_variants.npz"))
+    for name in ("depth2_k5373", "depth1_k7", "depth3_k3"):
+        cfg = json.loads(str(g[f"{name}.cfg"]))
+        sd = {k[len(name) + 4:]: g[k] for k in g.files if k.startswith(name + ".sd.")}
+        yield name, cfg, sd, g[f"{name}.lens"], g[f"{name}.probs"]
+
+
+def test_convnet_variants_oracle_vs_reference(golden_dir):
+    """depth > 1 and kernels other than 3 (riser/nets/cnn.py:17,52-65): the general restatement against the reference's
+    Model.classify on reads of 2^n_layers .. 4096 samples"""
+    for name, cfg, sd, lens, want in _variant_cases(golden_dir):
+        for j, L in enumerate(lens):
+            sig = synth.make_signals(20260103, 1, int(L), first_read=60 + j)[0]
+            x = ro.mad_normalise(sig).astype(np.float32)[None, :]
+            got = ro.softmax(ro.convnet_forward_general(sd, x, cfg["depth"]))[0]
+            assert np.abs(got - want[j]).max() < 2e-5, (name, int(L))
+
+
 @pytest.fixture(scope="module")
 def net(golden_dir):
     return np.load(os.path.join(golden_dir, "network.npz"))

@@ -226,6 +226,50 @@ def f3_control():
 
 
 # --------------------------------------------------------------------------------------
+def f2b_convnet_variants():
+    """ConvNet configurations outside the shipped class (riser/nets/cnn.py:17,52-65): depth 2 and mixed odd kernels,
+    through the reference's own Model.classify (one read at a time)."""
+    rng = np.random.default_rng(20260104)
+    cfgs = {"depth2_k5373": dict(n_layers=4, depth=2, channels=[6, 9, 14, 20], kernels=[5, 3, 7, 3]),
+            "depth1_k7": dict(n_layers=5, depth=1, channels=[8, 12, 18, 27, 40], kernels=[7, 7, 7, 7, 7]),
+            "depth3_k3": dict(n_layers=3, depth=3, channels=[5, 10, 15], kernels=[3, 3, 3])}
+    out = {}
+    for name, c in cfgs.items():
+        cnn = synth.CnnConfig(channels=c["channels"], kernels=c["kernels"], depth=c["depth"])
+        sd, c_in = {}, 1
+        for i, co in enumerate(c["channels"]):
+            ci = c_in
+            for d in range(c["depth"]):
+                k = c["kernels"][i]
+                sd[f"layers.{i}.{2 * d}.weight"] = (rng.standard_normal((co, ci, k)) * np.sqrt(2.0 / (k * ci))).astype(np.float32)
+                sd[f"layers.{i}.{2 * d}.bias"] = (rng.standard_normal(co) * 0.1).astype(np.float32)
+                ci = co
+            c_in = co
+        sd["classifier.2.weight"] = rng.standard_normal((2, c_in)).astype(np.float32)
+        sd["classifier.2.bias"] = rng.standard_normal(2).astype(np.float32)
+        with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as f:
+            torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, f.name)
+            path = f.name
+        try:
+            m = Model(path, synth.Config(cnn), LOG, "x")
+        finally:
+            os.unlink(path)
+        proc = SignalProcessor(Kit.create_from_version("RNA004"))
+        lens = [1 << c["n_layers"], (1 << c["n_layers"]) + 1, 1000, 2049, 4096]
+        probs = []
+        for j, L in enumerate(lens):
+            sig = synth.make_signals(SIG_SEED, 1, L, first_read=60 + j)[0]
+            probs.append(m.classify(proc.mad_normalise(sig.copy())).numpy())
+        out[f"{name}.cfg"] = np.array(json.dumps(c))
+        out[f"{name}.lens"] = np.array(lens)
+        out[f"{name}.probs"] = np.stack(probs)
+        for k, v in sd.items():
+            out[f"{name}.sd.{k}"] = v
+        print("F2b:", name, np.stack(probs)[:, 1])
+    np.savez_compressed(os.path.join(OUT, "convnet_variants.npz"), **out)
+
+
+# --------------------------------------------------------------------------------------
 def f4_polya():
     proc = SignalProcessor(Kit.create_from_version("RNA004"))
     cases = []
@@ -312,6 +356,8 @@ if __name__ == "__main__":
         f4_polya()
     if "f2" in which:
         f2_network()
+    if "f2b" in which or "f2" in which:
+        f2b_convnet_variants()
     if "f3" in which:
         f3_control()
     if "f5" in which:
