@@ -48,7 +48,6 @@ Hooks Hooks::from_env() {
     text("RS_H16_PANEL", h.h16_panel, sizeof(h.h16_panel));
     text("RS_FORCE_SHAPE_RING", h.force_ring, sizeof(h.force_ring));
     if (const char* e = getenv("RS_H16_RING")) h.h16_ring = atoi(e) != 0;
-    if (const char* e = getenv("RS_WINO4_RING")) h.wino4_ring = atoi(e) != 0;     // "0": the register-staged tiled kernel
     return h;
 }
 
@@ -376,21 +375,6 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             float* dw = nullptr;
             rc = upload(&dw, wp);
             L.d_w = dw;
-            // ring packing [chunk of 16 channels][component][n_alloc][16] (conv_ring_wino4.hip)
-            L.ring_panels = (L.c_in + 15) / 16;
-            if (rc == RS_OK) {
-                std::vector<float> wr((size_t)L.ring_panels * 6 * p.n_alloc * 16, 0.0f);
-                for (int n = 0; n < L.c_out; ++n)
-                    for (int ci = 0; ci < L.c_in; ++ci) {
-                        const int c = ci / 16, cc = ci - c * 16;
-                        for (int j = 0; j < 6; ++j)
-                            wr[(((size_t)c * 6 + j) * p.n_alloc + n) * 16 + cc] =
-                                wp[(((size_t)n * p.nch + ci / p.kc) * 6 + j) * p.kc + ci % p.kc];
-                    }
-                float* dw2 = nullptr;
-                rc = upload(&dw2, wr);
-                L.d_w2 = dw2;
-            }
         } else if (dtype == RS_F32W) {
             // Winograd F(2,3) filter transform (fp64, rounded once): U0 = g0, U1 = (g0+g1+g2)/2,
             // U2 = (g0-g1+g2)/2, U3 = g2; packed [n_alloc][nch][4][kc]
@@ -616,10 +600,7 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                                             m->num_cu, st);
                 m->last_bm[i] = 32;
                 m->last_bn[i] = round_up(L.c_out, 16);
-            } else if (m->dtype == RS_F32W && L.wino_m == 4 && m->hooks.wino4_ring && L.d_w2)
-                rc = launch_conv_ring_wino4(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len, B,
-                                            P_in, i, m->num_cu, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
-            else if (m->dtype == RS_F32W && L.wino_m == 4)
+            } else if (m->dtype == RS_F32W && L.wino_m == 4)
                 rc = launch_conv_wino4(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len, B,
                                        P_in, i, m->num_cu, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
             else if (m->dtype == RS_F32W)

@@ -22,7 +22,6 @@ sig, off, ln, lens = pack_reads(list(sigs), dev)
 m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=DT)
 RING = [(8,1,2,2),(8,1,2,3),(8,1,2,5),(8,1,2,7),(8,1,4,2),(8,1,4,3),(8,1,4,4),(4,2,4,3),(4,2,4,4),(4,2,4,5),(4,2,4,6),(4,2,2,4),(4,2,2,6),(2,4,4,4),(2,4,2,4),(2,4,4,3)]
 IS_RING = DT in ("bf16x3", "f16x3") or os.environ.get("RS_H16_RING")
-if os.environ.get("RS_WINO4_RING") and DT == "f32w": W4 = True
 if DT == "f32w": shapes = WINO4 if W4 else WINO
 if IS_RING: shapes = RING
 ROWMUL = 4 if W4 else 2 if DT == "f32w" else 1
