@@ -4,34 +4,41 @@
 //
 //   Conv1d(C_in -> C_out, k=3, 'same', bias) -> ReLU -> MaxPool1d(2,2)   (riser/nets/cnn.py:52-65)
 //
-// These layers are HBM-bound on the 16-bit MFMA (AI 5-40 flop/B against a ridge of ~310): the
-// tiled kernel of conv_h16.hip spends its time on LDS staging, a workgroup barrier per 512-row tile
-// and 2-byte stores.  Here every WAVE streams an independent run of 16-row sub-tiles:
+// These layers are HBM-bound on the 16-bit MFMA (AI 5-40 flop/B against a ridge of ~310): the tiled kernel spends its
+// time on LDS staging, a workgroup barrier per tile and narrow stores.  Here every WAVE streams an independent run of
+// 32-row blocks (16 pooled output rows each):
 //   * the 3 x NT weight fragments (A operand: rows = output channels) and the bias stay in registers;
-//   * the wave PRODUCES one 16-row sub-tile of input rows per step - loaded from HBM (64-byte rows,
-//     16 bytes per lane: one fully coalesced 1 KiB wave load) or, for layer 1, COMPUTED from the
-//     normalised fp32 signal (layer 0: 8 channels per lane from 4 samples, fp32 FMAs, one rounding to
-//     16 bit) - and parks it in a wave-private LDS ring of 256 rows; no other wave ever touches the
-//     ring, so there is no barrier anywhere in the kernel;
-//   * one step later it CONSUMES the previous sub-tile: the three taps are three ds_read_b128
-//     fragments at ring rows r-1, r, r+1 (B operand: columns = positions), 3 x NT MFMAs
-//     (v_mfma_f32_16x16x32_{f16,bf16}), and the epilogue in registers: MaxPool = max with the
-//     neighbouring lane (DPP quad_perm), + bias, ReLU, length mask, pack to 16 bit; even lanes
-//     store channels {0,1}, odd lanes {2,3} of their 4-channel group: 4-byte stores that tile
-//     whole output rows.
-// Ring rows are 64 bytes, XOR-swizzled at 16-byte granularity exactly as in conv_h16.hip
-// (conflict-free ds_read_b128 for all three tap shifts).
+//   * the wave PRODUCES 16-row sub-tiles of input rows - loaded from HBM (one fully coalesced 1 KiB wave load) or, for
+//     layer 1, COMPUTED from the normalised fp32 signal: layer 0 runs on the f32-input MFMA (v_mfma_f32_16x16x4_f32,
+//     K = 3 taps; exact fmaf chains from the bias in the accumulator input, bit-identical to conv0_kernel), columns =
+//     pooled rows, one MFMA for the even and one for the odd conv position, so MaxPool + ReLU is one v_max3_f32 -
+//     and parks them in a wave-private LDS ring of 64 rows; no other wave ever touches the ring, so there is no
+//     barrier anywhere in the kernel;
+//   * it CONSUMES a block when the sub-tile behind it is parked: lane (c, kq) owns pooled row c, with one accumulator
+//     set for its even conv position and one for the odd one, so four ds_read_b128 row fragments (ring rows
+//     2c-1 .. 2c+2) serve 6 x NT MFMAs (v_mfma_f32_16x16x32_{f16,bf16}) and MaxPool is a max of two registers of
+//     the same lane; + bias, ReLU, length mask, pack to 16 bit; v_permlane16_swap_b32 gathers 8 consecutive channels
+//     per lane and the wave stores 64 contiguous bytes per output row and instruction.
+// Ring rows are 64 (X3: 128) bytes at a pitch of 80 (144): with that pitch the consumer's reads of every second row
+// and the producer's writes of consecutive rows are free of bank conflicts without a swizzle.
+// Blocks never span reads (P_in % 32 == 0); interior blocks (everything valid) take a path without any masking or
+// row bookkeeping, the blocks at a read's end the general one.  Both paths issue the same memory operations in the
+// same order and there is no branch around a block, which keeps the compiler's vmcnt bookkeeping exact.
+// Measured (MI355X, 512 x 16000, f16): layers 0+1 0.097 -> 0.060 ms, layer 2 0.058 -> 0.048 ms; split precision 0.165
+// -> 0.125 and 0.123 -> 0.120 ms.  What is left in layers 0+1 is issue time: the f32-input MFMA shares the FP32 data
+// path with the VALU (the two never overlap, SQ counters: MFMA busy + VALU active = kernel time), so layer 0 costs
+// the same 256 cycles per block on either; v_pk_fma_f32 / v_pk_add_f32 issue at half rate and buy nothing.
 //
 // SPLIT PRECISION (X3, rs_dtype RS_BF16X3 / RS_F16X3; layout and arithmetic of conv_ring_h16.hip): activations are
-// hi + lo pairs stored per 32-channel panel as [hi x 32 | lo x 32] (128-byte rows in HBM and in the ring, swizzle
-// slot ^ (row & 7)), weights come from the ring packing [tap][n_alloc][hi x 32 | lo x 32], a product is three MFMAs
-// (hi*hi, lo*hi, hi*lo) and the epilogue splits every output once more.  Twice the weight registers: two waves per
-// SIMD instead of four.
+// hi + lo pairs stored per 32-channel panel as [hi x 32 | lo x 32] (128-byte rows in HBM and in the ring), weights
+// come from the ring packing [tap][n_alloc][hi x 32 | lo x 32], a product is three MFMAs (hi*hi, lo*hi, hi*lo) and
+// the epilogue splits every output once more.  Twice the weight registers: two waves per SIMD instead of four.
 #include "common.hpp"
 
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <utility>
 
 namespace rs {
@@ -43,6 +50,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef RS_STREAM_WGS
+#define RS_STREAM_WGS 4
+#endif
 constexpr int kWaves = 4;                     // per workgroup; each wave is independent
 constexpr int kRing = 64;                     // ring rows per wave (64 bytes each): 4 sub-tiles, 3 are live
 constexpr unsigned kOob = 0x80000000u;
@@ -72,7 +82,7 @@ struct StreamArgs {
     int cp_in, cp_out;
     int n_alloc;
     int shift_in;             // valid input rows of read b: len[b] >> shift_in   (output: >> (shift_in + 1))
-    int n_sub;                // number of 16-row sub-tiles = ceil(rows_in / 16)
+    int n_sub;                // number of 32-row blocks (16 output rows each) = rows_in / 32
     int sub_per_wave;
 };
 
@@ -100,11 +110,6 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
         return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
-template <bool X3>
-__device__ __forceinline__ int swz(int row) {
-    return X3 ? (row & 7) : ((row >> 2) & 1) << 1;
-}
-
 template <bool F16>
 __device__ __forceinline__ float widen16(unsigned short u) {
     if constexpr (F16)
@@ -118,26 +123,24 @@ __device__ __forceinline__ unsigned pack2_lo(float a, float b, unsigned hi) {
     return pack2<F16>(a - widen16<F16>((unsigned short)(hi & 0xffffu)), b - widen16<F16>((unsigned short)(hi >> 16)));
 }
 
-// max of x and the value of the lane that holds the other position of the pooling pair (lane ^ 1)
-__device__ __forceinline__ float max_pair(float x) {
-    const int o = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
-    return fmaxf(x, __builtin_bit_cast(float, o));
-}
-
 template <bool FUSE0, int NT, bool F16, bool X3>
-__global__ __launch_bounds__(kWaves * 64, X3 ? 2 : 4) void conv_stream_h16_kernel(const StreamArgs a) {
+__global__ __launch_bounds__(kWaves * 64, X3 ? 2 : NT == 3 ? 3 : RS_STREAM_WGS) void conv_stream_h16_kernel(const StreamArgs a) {
     constexpr int ROWB = X3 ? 128 : 64;                         // ring row / input row of one panel
     constexpr int NH = X3 ? 2 : 1;                              // 16-byte halves a lane handles per row: hi (and lo)
-    __shared__ __attribute__((aligned(16))) unsigned char ring_all[kWaves * kRing * ROWB];
+    // ring row pitch: 16 bytes more than a row, so that the consumer's ds_read_b128 of every SECOND row (rows 2c + d of
+    // lane group c) and the producer's ds_write_b128 of consecutive rows are both free of bank conflicts without a
+    // swizzle (slot = (5 row + kq) mod 16 resp. (9 row + kq) mod 16 over the 16-lane groups of ds_read_b128)
+    constexpr int ROWP = ROWB + 16;
+    __shared__ __attribute__((aligned(16))) unsigned char ring_all[kWaves * kRing * ROWP];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, kq = lane >> 4;
-    unsigned char* ring = ring_all + wave * (kRing * ROWB);
+    unsigned char* ring = ring_all + wave * (kRing * ROWP);
 
     const int gw = blockIdx.x * kWaves + wave;                 // global wave index
-    const int u0 = gw * a.sub_per_wave;                         // first sub-tile of this wave's run
-    const int u1 = min(u0 + a.sub_per_wave, a.n_sub);
-    if (u0 >= u1) return;
+    const int u0 = gw * a.sub_per_wave;                         // first block of this wave's run
+    const int u1 = u0 + a.sub_per_wave;                         // a multiple of 4 blocks; blocks >= n_sub are dropped
+    if (u0 >= a.n_sub) return;
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
         FUSE0 ? (void*)(a.xs - 4) : const_cast<void*>(a.x), 0, FUSE0 ? a.xs_bytes + 16u : a.x_bytes, 0x00020000);
@@ -155,214 +158,300 @@ __global__ __launch_bounds__(kWaves * 64, X3 ? 2 : 4) void conv_stream_h16_kerne
     f32x4 bias[NT];                                             // channels 16j + 4kq + q of this lane's accumulators
 #pragma unroll
     for (int j = 0; j < NT; ++j) bias[j] = *reinterpret_cast<const f32x4*>(a.bias + 16 * j + 4 * kq);
-    f32x4 w0r[FUSE0 ? 8 : 1];                                   // layer 0: this lane's channels 8kq .. 8kq+7
+    // layer 0 on the f32-input MFMA (v_mfma_f32_16x16x4_f32, K = 3 taps + one zero column; bit-exact fmaf chains from
+    // the accumulator input, which carries the bias: the same chain as conv0_kernel): A = W0[channel 16m + r][tap kq],
+    // C = bias of channels 16m + 4kq + i
+    float w0t[2] = {0.f, 0.f};
+    f32x4 cb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if constexpr (FUSE0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int ch = 8 * kq + q;
-            w0r[q] = ch < a.c0 ? *reinterpret_cast<const f32x4*>(a.w0 + 4 * ch) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 2; ++m) {
+            w0t[m] = (kq < 3 && 16 * m + r < a.c0) ? a.w0[4 * (16 * m + r) + kq] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = 16 * m + 4 * kq + i;
+                cb[m][i] = ch < a.c0 ? a.w0[4 * ch + 3] : 0.0f;
+            }
         }
     }
+    // ring slot (16 bytes = 8 channels) this lane writes: a loaded row arrives as channels 8kq .., a computed layer-0
+    // row as channels 16 (kq & 1) + 8 (kq >> 1) .. (see conv0)
+    const int wslot = FUSE0 ? 2 * (kq & 1) + (kq >> 1) : kq;
 
-    // per-sub-tile row bookkeeping: read index / position of the sub-tile's first row by one scalar
-    // division, lanes add their offset (a sub-tile is 16 rows < P_in, so it spans at most two reads).
-    // Two wave-uniform fast paths: every row valid (no masking), every row beyond its read's length
-    // (mixed-length batches: no layer-0 arithmetic, no MFMAs, zeros in / zeros out).
+    // ---- row bookkeeping ------------------------------------------------------------------------------
+    // P_in is a multiple of 32, so neither a 16-row sub-tile nor a 32-row block spans two reads.  The wave carries the
+    // (read, first position, valid rows) of the block it consumes next in scalar registers and advances them by 32
+    // rows per block; a sub-tile is described by the position of its first row in its read and the read's valid rows.
     const const_len_ptr clen = as_const_len(a.len);
     struct SubInfo {
-        int t0, l0, l1, b;
+        int t0, l0;                                             // first row's position in its read; valid rows of the read
     };
-    // the (read, position, lengths) of the sub-tile being produced is carried in scalar registers and
-    // advanced incrementally: a look-up per step (division + two dependent scalar loads, used at once
-    // by a branch) put ~2 k cycles of exposed latency into every step
-    auto sub_info = [&](int u) {
-        const int g0 = 16 * u;
-        const int b0 = g0 / a.P_in;
-        SubInfo si;
-        si.t0 = g0 - b0 * a.P_in;
-        si.b = b0;
-        si.l0 = b0 < a.n_reads ? clen[b0] >> a.shift_in : 0;
-        si.l1 = b0 + 1 < a.n_reads ? clen[b0 + 1] >> a.shift_in : 0;
-        return si;
-    };
-    auto advance = [&](SubInfo& si) {
-        si.t0 += 16;
-        if (si.t0 >= a.P_in) {
-            si.t0 -= a.P_in;
-            ++si.b;
-            si.l0 = si.l1;
-            si.l1 = si.b + 1 < a.n_reads ? clen[si.b + 1] >> a.shift_in : 0;
-        }
-    };
-    auto lane_info = [&](const SubInfo& si, int& t, int& lim) {  // position of row 16u + r in its read; its valid rows
-        const int tt = si.t0 + r;
-        const bool hi = tt >= a.P_in;
-        t = hi ? tt - a.P_in : tt;
-        lim = hi ? si.l1 : si.l0;
-    };
+    auto len_of = [&](int b) { return (b >= 0 && b < a.n_reads) ? clen[b] >> a.shift_in : 0; };
 
-    // ---- producer: one sub-tile of input rows into the ring ------------------------------------------
-    constexpr int D = 4;
+    // ---- producer: one 16-row sub-tile of input rows into the ring -----------------------------------
+    // prefetch depth in sub-tiles.  vmcnt counts loads and stores in one queue, in order: with 4 sub-tiles in flight
+    // the wait for a prefetched load also waited for the store of the block before
+    constexpr int D = (X3 && !FUSE0) ? 4 : 8;
     constexpr int NL = (X3 && !FUSE0) ? 2 : 1;                  // raw 16-byte loads per lane and sub-tile
     struct Raw {
-        u32x4 v[NL];
+        u32x4 v[NL];                                            // FUSE0: two floats in v[0][0 .. 1]
     };
     Raw pre[D];                                                 // raw loads, D sub-tiles ahead of the producer
+    // Loads are bounds-checked by the buffer resource alone: a sub-tile before the first row gives offsets that wrap
+    // to >= 2^31, one behind the last row offsets >= num_records, and both read as zeros.  Lanes of channel groups the
+    // layer does not have carry an offset of 2^31 from the start.
+    //   FUSE0: layer-0 B operands of this lane, x[2g - 1 + kq] (even conv position of pooled row g, tap kq) and
+    //          x[2g + kq] (odd position); tap 3 meets a zero weight
+    const unsigned lane_off = FUSE0 ? (unsigned)(2 * r - 1 + kq + 4) * 4u
+                                    : ((X3 || 8 * kq < a.cp_in) ? (unsigned)(r * a.cp_in + 8 * kq) * 2u : kOob);
+    const unsigned sub_bytes = FUSE0 ? 128u : 32u * (unsigned)a.cp_in;   // bytes from one sub-tile to the next
     auto issue_load = [&](int u, Raw& dst) {
-        const int g = 16 * u + r;
-        unsigned off;
-        if constexpr (FUSE0)
-            off = (u >= 0 && g < a.rows_in) ? (unsigned)(2 * g - 1 + 4) * 4u : kOob;        // x[2g-1 .. 2g+2]
-        else if constexpr (X3)
-            off = (u >= 0 && g < a.rows_in) ? ((unsigned)g * a.cp_in + 8 * kq) * 2u : kOob;  // hi piece; lo 64 bytes on
-        else
-            off = (u >= 0 && g < a.rows_in && 8 * kq < a.cp_in) ? ((unsigned)g * a.cp_in + 8 * kq) * 2u : kOob;
-        dst.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
-        if constexpr (NL == 2) dst.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off == kOob ? kOob : off + 64u, 0, 0);
+        const unsigned off = lane_off + (unsigned)u * sub_bytes;
+        if constexpr (FUSE0) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, off, 0, 0);
+            dst.v[0][0] = v[0];
+            dst.v[0][1] = v[1];
+        } else {
+            dst.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+            if constexpr (NL == 2) dst.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off + 64u, 0, 0);
+        }
     };
     struct Row {
         u32x4 v[NH];                                            // this lane's 8 channels of its row: hi (and lo)
     };
-    auto conv0 = [&](const u32x4& raw, bool valid) {
-        const f32x4 xv = __builtin_bit_cast(f32x4, raw);
-        float o[8];
+    // Layer 0 of 16 pooled rows on the matrix pipe: columns = pooled rows, one MFMA for their even conv positions and
+    // one for the odd ones per 16-channel tile, so MaxPool + ReLU is one v_max3_f32 per value, in-lane.  The lane
+    // then holds channels 4kq .. +3 and 16 + 4kq .. +3 of its row; v_permlane16_swap_b32 turns that into 8
+    // consecutive channels (16 (kq & 1) + 8 (kq >> 1) ..), which is a 16-byte slot of the ring row in natural order.
+    auto conv0 = [&](const u32x4& raw) {
+        const unsigned ue = raw[0], uo = raw[1];               // (bit_cast of a vector ELEMENT lvalue reads element 0)
+        const float xe = __builtin_bit_cast(float, ue), xo = __builtin_bit_cast(float, uo);
+        float o[2][4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {                           // same fmaf chains as conv0_kernel, rounded once
-            const float e = fmaf(w0r[q][2], xv[2], fmaf(w0r[q][1], xv[1], fmaf(w0r[q][0], xv[0], w0r[q][3])));
-            const float f = fmaf(w0r[q][2], xv[3], fmaf(w0r[q][1], xv[2], fmaf(w0r[q][0], xv[1], w0r[q][3])));
-            o[q] = valid ? fmaxf(fmaxf(e, f), 0.0f) : 0.0f;
+        for (int m = 0; m < 2; ++m) {
+#ifdef RS_ABL_NOCONV0
+            const f32x4 e = cb[m] * xe, f = cb[m] * xo;
+#else
+            const f32x4 e = __builtin_amdgcn_mfma_f32_16x16x4f32(w0t[m], xe, cb[m], 0, 0, 0);
+            const f32x4 f = __builtin_amdgcn_mfma_f32_16x16x4f32(w0t[m], xo, cb[m], 0, 0, 0);
+#endif
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[m][i] = fmaxf(fmaxf(e[i], f[i]), 0.0f);
+        }
+        unsigned w[NH][2][2];                                   // [hi / lo][tile][dword]
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            w[0][m][0] = pack2<F16>(o[m][0], o[m][1]);
+            w[0][m][1] = pack2<F16>(o[m][2], o[m][3]);
+            if constexpr (X3) {
+                w[1][m][0] = pack2_lo<F16>(o[m][0], o[m][1], w[0][m][0]);
+                w[1][m][1] = pack2_lo<F16>(o[m][2], o[m][3], w[0][m][1]);
+            }
         }
         Row out;
-        out.v[0] = (u32x4){pack2<F16>(o[0], o[1]), pack2<F16>(o[2], o[3]), pack2<F16>(o[4], o[5]), pack2<F16>(o[6], o[7])};
-        if constexpr (X3)
-            out.v[1] = (u32x4){pack2_lo<F16>(o[0], o[1], out.v[0][0]), pack2_lo<F16>(o[2], o[3], out.v[0][1]),
-                               pack2_lo<F16>(o[4], o[5], out.v[0][2]), pack2_lo<F16>(o[6], o[7], out.v[0][3])};
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const auto s0 = __builtin_amdgcn_permlane16_swap(w[h][0][0], w[h][1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(w[h][0][1], w[h][1][1], false, false);
+            out.v[h] = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+        }
         return out;
     };
+    const unsigned ring_w = (unsigned)(r * ROWP + (wslot << 4));   // this lane's byte in ring row 0 of a sub-tile
+    auto park = [&](int u, const Row& v) {                     // sub-tile u occupies ring rows 16 (u & 3) ..
+        unsigned char* dst = ring + ring_w + (unsigned)((u & 3) * 16 * ROWP);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) *reinterpret_cast<u32x4*>(dst + 64 * h) = v.v[h];
+    };
+    // INTERIOR: every row of the sub-tile is a valid row of its read
+    auto produce_fast = [&](int u, const Raw& raw) {
+        Row v;
+        if constexpr (FUSE0) {
+            v = conv0(raw.v[0]);
+        } else {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) v.v[h] = raw.v[h];
+        }
+        park(u, v);
+    };
+    // GENERAL: rows beyond the read's length are zero rows (loaded rows already are; computed ones are masked); a
+    // sub-tile wholly beyond it costs no arithmetic
     auto produce = [&](int u, const Raw& raw, const SubInfo& si) {
         Row v;
         if constexpr (FUSE0) {
-            if (u >= 0 && si.t0 + 16 <= si.l0) {
-                v = conv0(raw.v[0], true);
-            } else if (u < 0 || (si.t0 >= si.l0 && si.t0 + 16 <= a.P_in)) {
+            if (si.t0 >= si.l0) {
 #pragma unroll
                 for (int h = 0; h < NH; ++h) v.v[h] = (u32x4){0u, 0u, 0u, 0u};
             } else {
-                int t, lim;
-                lane_info(si, t, lim);
-                v = conv0(raw.v[0], t < lim);
+                v = conv0(raw.v[0]);
+                const unsigned keep = si.t0 + r < si.l0 ? ~0u : 0u;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) v.v[h] &= (u32x4){keep, keep, keep, keep};
             }
         } else {
 #pragma unroll
             for (int h = 0; h < NH; ++h) v.v[h] = raw.v[h];
         }
-        const int rr = (16 * u + r) & (kRing - 1);
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-            *reinterpret_cast<u32x4*>(ring + rr * ROWB + (((4 * h + kq) ^ swz<X3>(rr)) << 4)) = v.v[h];
+        park(u, v);
     };
 
-    // ---- consumer: outputs of sub-tile u from ring rows 16u - 1 .. 16u + 16 ---------------------------
-    auto consume = [&](int u, const SubInfo& si) {
-        const unsigned rowoff = (unsigned)((16 * u + r) >> 1) * (unsigned)(a.cp_out * 2);
-        const bool odd = r & 1;
-        const bool dead = (si.t0 >> 1) >= (si.l0 >> 1) && si.t0 + 16 <= a.P_in;       // uniform: all outputs are zero
-        // byte offset of logical channel ch inside an output row (X3: 32-channel panels of [hi x 32 | lo x 32]) and
-        // the number of logical channel slots of a row
-        auto ch_off = [&](int ch) { return (unsigned)(X3 ? ((ch >> 5) << 6) + (ch & 31) : ch) * 2u; };
-        const int ch_lim = X3 ? a.cp_out / 2 : a.cp_out;
-        // X3: a row holds 32 channel slots per panel but only NT * 16 channels are computed: the slots behind them are
-        // written as zeros (the next layer multiplies them by zero weights, so they must be finite), and a lane stores
-        // 8 bytes: the even lane of a pooling pair the hi halves of its 4 channels, the odd lane the lo halves
-        auto zero_tail = [&]() {
-            if constexpr (X3)
-                for (int j = NT; 16 * j < ch_lim; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){0u, 0u}, rs_y,
-                                                          rowoff + ch_off(16 * j + 4 * kq) + (odd ? 64u : 0u), 0, 0);
-        };
-        if (dead) {
+    // ---- consumer: the 16 pooled outputs of block v (input rows 32v .. 32v+31) from ring rows 32v - 1 .. 32v + 32.
+    // Lane (c = lane & 15, kq) owns pooled position c of the block: one accumulator set for its even conv position
+    // (input rows 2c-1, 2c, 2c+1), one for the odd one (2c, 2c+1, 2c+2), so MaxPool is a max of two registers of the
+    // same lane, the four row fragments serve six operands, and every lane stores whole channel groups.
+    // byte offset of logical channel ch inside an output row (X3: 32-channel panels of [hi x 32 | lo x 32]) and the
+    // number of logical channel slots of a row
+    auto ch_off = [&](int ch) { return (unsigned)(X3 ? ((ch >> 5) << 6) + (ch & 31) : ch) * 2u; };
+    const int ch_lim = X3 ? a.cp_out / 2 : a.cp_out;
+    // Stores.  A lane holds channels 16j + 4kq .. +3 of its row for every channel tile j (8 bytes of 16-bit values).
+    // Two tiles j, j+1 are exchanged between the lane rows with v_permlane16_swap_b32 so that every lane ends up with
+    // 8 CONSECUTIVE channels - 16j + 16 (kq & 1) + 8 (kq >> 1) .. +7 - and the wave writes 64 contiguous bytes per
+    // output row and instruction (X3: the hi half-row, then the lo half-row 64 bytes on).  X3 rows hold 32 channel
+    // slots per panel but only NT * 16 channels are computed: the slots behind them are written as zeros (the next
+    // layer multiplies them by zero weights, so they must be finite) - they ride in the pair.
+    constexpr int NTP = X3 ? 2 * ((NT + 1) / 2) : NT;           // channel tiles written per row
+    unsigned st_off[(NTP + 1) / 2];                             // this lane's byte in output row 0 per store, or out of range
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if constexpr (X3) {
-                    const int ch = 16 * j + 4 * kq;
-                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){0u, 0u}, rs_y,
-                                                          ch < ch_lim ? rowoff + ch_off(ch) + (odd ? 64u : 0u) : kOob, 0, 0);
-                } else {
-                    const int ch = 16 * j + 4 * kq + (odd ? 2 : 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(0u, rs_y, ch < ch_lim ? rowoff + ch_off(ch) : kOob, 0, 0);
-                }
+    for (int j = 0; j + 1 < NTP; j += 2) {
+        const int ch = 16 * j + 16 * (kq & 1) + 8 * (kq >> 1);
+        st_off[j / 2] = ch < ch_lim ? (unsigned)(r * a.cp_out * 2) + ch_off(ch) : kOob;
+    }
+    if constexpr (NTP & 1) {
+        const int ch = 16 * (NTP - 1) + 4 * kq;
+        st_off[NTP / 2] = ch < ch_lim ? (unsigned)(r * a.cp_out * 2) + ch_off(ch) : kOob;
+    }
+    const unsigned blk_bytes = 32u * (unsigned)a.cp_out;        // 16 output rows
+    auto store_rows = [&](int v, const u32x2 (&hi)[NTP], const u32x2 (&lo)[NTP]) {
+#ifdef RS_ABL_NOSTORE
+        const unsigned base = kOob;
+#else
+        const unsigned base = v < a.n_sub ? (unsigned)v * blk_bytes : kOob;   // blocks behind the grid are dropped
+#endif
+#pragma unroll
+        for (int j = 0; j + 1 < NTP; j += 2) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const u32x2 wa = h ? lo[j] : hi[j], wb = h ? lo[j + 1] : hi[j + 1];
+                const auto s0 = __builtin_amdgcn_permlane16_swap(wa[0], wb[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(wa[1], wb[1], false, false);
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){s0[0], s1[0], s0[1], s1[1]}, rs_y,
+                                                       ((base | st_off[j / 2]) & kOob) ? kOob : base + st_off[j / 2] + 64u * h, 0, 0);
             }
-            zero_tail();
+        }
+        if constexpr (NTP & 1)                                  // plain mode, odd tile count: the last tile alone
+            __builtin_amdgcn_raw_buffer_store_b64(hi[NTP - 1], rs_y,
+                                                  ((base | st_off[NTP / 2]) & kOob) ? kOob : base + st_off[NTP / 2], 0, 0);
+    };
+    const unsigned ring_r = (unsigned)(2 * r * ROWP + (kq << 4));   // this lane's byte in ring row 2c
+    // MASKED = false: every output of the block is a valid output of its read
+    auto consume = [&](int v, const SubInfo& si, auto MASKED) {
+        constexpr bool masked = decltype(MASKED)::value;
+        const int tp0 = si.t0 >> 1, out_len = si.l0 >> 1;
+        u32x2 hi[NTP], lo[NTP];
+#pragma unroll
+        for (int j = 0; j < NTP; ++j) hi[j] = lo[j] = (u32x2){0u, 0u};
+        if (masked && tp0 >= out_len) {                         // uniform: every output of the block is zero
+            store_rows(v, hi, lo);
             return;
         }
-        f32x4 acc[NT];
+        u32x4 xf[4][NH];                                        // ring rows 32v + 2c + d - 1, d = 0 .. 3
+        // block v = sub-tiles 2v, 2v+1 = ring rows 32 (v & 1) .. +31; row -1 and row 32 wrap inside the 64-row ring
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < 4; ++d) {
+            const unsigned row0 = (unsigned)((32 * v + d - 1) & (kRing - 1));       // ring row of lane group c = 0
+            // rows 2c + row0 stay below 64 except for d = 3 of the upper half's last lane group (row 64 -> 0)
+            unsigned off = row0 * ROWP + ring_r;
+            if (d == 3 || d == 0) off = (unsigned)(((32 * v + 2 * r + d - 1) & (kRing - 1)) * ROWP + (kq << 4));
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int rr = (16 * u + r + t - 1) & (kRing - 1);
-            u32x4 xf[NH];
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-                xf[h] = *reinterpret_cast<const u32x4*>(ring + rr * ROWB + (((4 * h + kq) ^ swz<X3>(rr)) << 4));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                acc[j] = mfma16<F16>(wf[0][t][j], xf[0], acc[j]);               // hi * hi
-                if constexpr (X3) {
-                    acc[j] = mfma16<F16>(wf[1][t][j], xf[0], acc[j]);           // w lo * x hi
-                    acc[j] = mfma16<F16>(wf[0][t][j], xf[1], acc[j]);           // w hi * x lo
-                }
-            }
+            for (int h = 0; h < NH; ++h) xf[d][h] = *reinterpret_cast<const u32x4*>(ring + off + 64 * h);
         }
-        int t, lim;
-        lane_info(si, t, lim);
-        const bool all_valid = si.t0 + 16 <= (si.l0 & ~1);      // uniform: no masking needed
-        const bool valid = all_valid || (t >> 1) < (lim >> 1);  // pooled position < output length of the read
+        f32x4 acc[2][NT];                                       // [even / odd conv position][channel tile]
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[e][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef RS_ABL_NOMFMA
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    acc[e][j] = mfma16<F16>(wf[0][t][j], xf[t + e][0], acc[e][j]);               // hi * hi
+                    if constexpr (X3) {
+                        acc[e][j] = mfma16<F16>(wf[1][t][j], xf[t + e][0], acc[e][j]);           // w lo * x hi
+                        acc[e][j] = mfma16<F16>(wf[0][t][j], xf[t + e][1], acc[e][j]);           // w hi * x lo
+                    }
+                }
+#else
+        for (int j = 0; j < NT; ++j) acc[0][j] = acc[1][j] = __builtin_bit_cast(f32x4, xf[0][0] ^ xf[1][0] ^ xf[2][0] ^ xf[3][0]);
+#endif
+        const unsigned keep = (!masked || tp0 + r < out_len) ? ~0u : 0u;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            float p[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float m = max_pair(acc[j][q]);
-                p[q] = valid ? fmaxf(m + bias[j][q], 0.0f) : 0.0f;
-            }
-            if constexpr (X3) {
-                const unsigned h0 = pack2<F16>(p[0], p[1]), h1 = pack2<F16>(p[2], p[3]);
-                const u32x2 word = odd ? (u32x2){pack2_lo<F16>(p[0], p[1], h0), pack2_lo<F16>(p[2], p[3], h1)} : (u32x2){h0, h1};
-                const int ch = 16 * j + 4 * kq;
-                const unsigned off = ch < ch_lim ? rowoff + ch_off(ch) + (odd ? 64u : 0u) : kOob;
-                __builtin_amdgcn_raw_buffer_store_b64(word, rs_y, off, 0, 0);
-            } else {
-                const unsigned word = odd ? pack2<F16>(p[2], p[3]) : pack2<F16>(p[0], p[1]);
-                const int ch = 16 * j + 4 * kq + (odd ? 2 : 0);
-                const unsigned off = ch < ch_lim ? rowoff + ch_off(ch) : kOob;           // rows past the end: out of range
-                __builtin_amdgcn_raw_buffer_store_b32(word, rs_y, off, 0, 0);
+            // MaxPool, + bias, ReLU: max(e, o) + b == max(e + b, o + b) bit for bit (rounding is monotonic), which is
+            // two v_pk_add_f32 and one v_max3_f32 per channel pair instead of max / add / max per channel
+            const f32x2 b01 = {bias[j][0], bias[j][1]}, b23 = {bias[j][2], bias[j][3]};
+            const f32x2 e01 = (f32x2){acc[0][j][0], acc[0][j][1]} + b01, e23 = (f32x2){acc[0][j][2], acc[0][j][3]} + b23;
+            const f32x2 o01 = (f32x2){acc[1][j][0], acc[1][j][1]} + b01, o23 = (f32x2){acc[1][j][2], acc[1][j][3]} + b23;
+            const float p0 = fmaxf(fmaxf(e01[0], o01[0]), 0.0f), p1 = fmaxf(fmaxf(e01[1], o01[1]), 0.0f);
+            const float p2 = fmaxf(fmaxf(e23[0], o23[0]), 0.0f), p3 = fmaxf(fmaxf(e23[1], o23[1]), 0.0f);
+            hi[j] = (u32x2){pack2<F16>(p0, p1), pack2<F16>(p2, p3)};
+            if constexpr (X3) lo[j] = (u32x2){pack2_lo<F16>(p0, p1, hi[j][0]), pack2_lo<F16>(p2, p3, hi[j][1])};
+            if constexpr (masked) {
+                hi[j] &= (u32x2){keep, keep};
+                lo[j] &= (u32x2){keep, keep};
             }
         }
-        zero_tail();
+        store_rows(v, hi, lo);
     };
 
-    // ---- run: step s produces sub-tile v = u0 - 1 + s (the first one only for its last row, the last one
-    // only for its first row) and consumes v - 1; the raw loads run D sub-tiles ahead of the producer
-    // (HBM latency is several thousand cycles, a step a few hundred) --------------------------------------
-    static_for<D>([&](auto K) { issue_load(u0 - 1 + decltype(K)::value, pre[decltype(K)::value]); });
-    const int S = u1 - u0 + 2;
-    int cur_v = u0 > 0 ? u0 - 1 : 0;                          // sub-tile that `cur` describes
-    SubInfo cur = sub_info(cur_v), prev = cur;
-    for (int s0 = 0; s0 < S; s0 += D) {
-        static_for<D>([&](auto K) {
+    // ---- run: the wave owns blocks u0 .. u1-1, i.e. 16-row sub-tiles 2 u0 .. 2 u1 - 1, and also produces the sub-tile
+    // before (for its last row) and the one after (for its first row).  Iteration v produces sub-tiles 2v+1 and 2v+2
+    // and consumes block v: exactly the four sub-tiles 2v-1 .. 2v+2 are live then, which is the whole ring.  The raw
+    // loads run D sub-tiles ahead of the producer (HBM latency is several thousand cycles, a step a few hundred).
+    // There is no branch around a block and both paths of a block issue the same memory operations in the same
+    // order, so the compiler's vmcnt bookkeeping stays exact; runs are multiples of D / 2 blocks (host), the blocks
+    // behind the last one of the grid are dropped by the store.
+    const int w_first = 2 * u0 - 1;
+    static_for<D>([&](auto K) { issue_load(w_first + decltype(K)::value, pre[decltype(K)::value]); });
+    int rb = (32 * u0) / a.P_in;                              // read of block u0, its first position in it, valid rows
+    int t0 = 32 * u0 - rb * a.P_in;
+    int l0 = len_of(rb), l1 = len_of(rb + 1);
+    {
+        // sub-tile 2 u0 - 1: the 16 rows before the block (of the read before when the block starts a read)
+        const SubInfo sp = t0 > 0 ? SubInfo{t0 - 16, l0} : SubInfo{a.P_in - 16, len_of(rb - 1)};
+        produce(w_first, pre[0], sp);
+        issue_load(w_first + D, pre[0]);
+        produce(w_first + 1, pre[1], SubInfo{t0, l0});
+        issue_load(w_first + 1 + D, pre[1]);
+    }
+    for (int v0 = u0; v0 < u1; v0 += D / 2) {
+        static_for<D / 2>([&](auto K) {
             constexpr int k = decltype(K)::value;
-            const int s = s0 + k;
-            if (s < S) {
-                const int v = u0 - 1 + s;
-                if (cur_v < v) {
-                    prev = cur;
-                    advance(cur);
-                    ++cur_v;
-                }
-                produce(v, pre[k], cur);
-                issue_load(v + D, pre[k]);
-                if (s >= 2) consume(v - 1, prev);
+            const int v = v0 + k;
+            Raw& sa = pre[(2 + 2 * k) % D];
+            Raw& sb = pre[(3 + 2 * k) % D];
+            if (t0 + 48 <= l0) {                                // interior: the block and the sub-tile behind it are valid rows
+                produce_fast(2 * v + 1, sa);
+                issue_load(2 * v + 1 + D, sa);
+                produce_fast(2 * v + 2, sb);
+                issue_load(2 * v + 2 + D, sb);
+                consume(v, SubInfo{t0, l0}, std::false_type{});
+            } else {
+                const bool wrap = t0 + 32 >= a.P_in;
+                produce(2 * v + 1, sa, SubInfo{t0 + 16, l0});
+                issue_load(2 * v + 1 + D, sa);
+                produce(2 * v + 2, sb, wrap ? SubInfo{0, l1} : SubInfo{t0 + 32, l0});
+                issue_load(2 * v + 2 + D, sb);
+                consume(v, SubInfo{t0, l0}, std::true_type{});
+            }
+            t0 += 32;
+            if (t0 >= a.P_in) {
+                t0 = 0;
+                ++rb;
+                l0 = l1;
+                l1 = len_of(rb + 1);
             }
         });
     }
@@ -383,7 +472,7 @@ KernelFn pick(int nt, bool f16) {
 
 // a layer qualifies when its input is one MFMA k-step wide and its weights fit the register budget
 bool conv_stream_h16_ok(const ConvLayerDev& L, int P_in) {
-    return L.c_in <= 32 && L.plan.nch == 1 && L.c_out <= 48 && P_in >= 32 && !L.hooks->no_stream_h16;
+    return L.c_in <= 32 && L.plan.nch == 1 && L.c_out <= 48 && P_in >= 32 && P_in % 32 == 0 && !L.hooks->no_stream_h16;
 }
 
 int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
@@ -420,11 +509,11 @@ int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, co
     a.cp_out = L.cp_out;
     a.n_alloc = L.plan.n_alloc;
     a.shift_in = layer_index;
-    a.n_sub = (int)((rows64 + 15) / 16);
-    // 4 workgroups (16 waves) per CU - 2 in split precision (register budget); runs of at least 32 sub-tiles so the
-    // two warm-up sub-tiles stay cheap
-    const int waves = num_cu * (x3 ? 2 : 4) * kWaves;
-    a.sub_per_wave = std::max(32, (a.n_sub + waves - 1) / waves);
+    a.n_sub = (int)(rows64 / 32);                               // blocks of 32 input rows = 16 output rows
+    // 4 workgroups (16 waves) per CU - 3 with three channel tiles, 2 in split precision (register budget); runs of at
+    // least 16 blocks so the two warm-up sub-tiles stay cheap
+    const int waves = num_cu * (x3 ? 2 : L.c_out > 32 ? 3 : RS_STREAM_WGS) * kWaves;
+    a.sub_per_wave = round_up(std::max(16, (a.n_sub + waves - 1) / waves), 4);   // the kernel walks 4 blocks per iteration
     const int n_waves = (a.n_sub + a.sub_per_wave - 1) / a.sub_per_wave;
     const int grid = (n_waves + kWaves - 1) / kWaves;
     const int nt = (round_up(L.c_out, 16)) / 16;
