@@ -40,6 +40,7 @@ Hooks Hooks::from_env() {
     h.no_fuse0 = flag("RS_NO_FUSE0");
     h.no_stream_f32 = flag("RS_NO_STREAM_F32");
     h.no_stream_h16 = flag("RS_NO_STREAM_H16");
+    h.no_stream012 = flag("RS_NO_STREAM012");
     h.conv_stamps = flag("RS_CONV_STAMPS");
     text("RS_FORCE_SHAPE_F32", h.force_f32, sizeof(h.force_f32));
     text("RS_FORCE_SHAPE_WINO", h.force_wino, sizeof(h.force_wino));
@@ -582,6 +583,21 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
     for (int i = 1; i < m->n_layers; ++i) {
         ConvLayerDev& L = m->layers[i];
         const int P_in = w.P0 >> i;
+        if (i == 1 && fuse0h && m->n_layers > 2 && !(m->dbg_dst && m->dbg_layer <= 2) &&
+            conv_stream012_h16_ok(L, m->layers[2], m->channels[0], P_in)) {
+            // layers 0 + 1 + 2 of the 16-bit modes in one streaming kernel; its output takes the place of layer 2's
+            rc = launch_conv_stream012_h16(L, m->layers[2], d_x, m->d_w0, m->channels[0], buf[cur], d_len, B, P_in, m->num_cu,
+                                           f16, x3, st);
+            if (rc != RS_OK) return rc;
+            for (int k = 1; k <= 2; ++k) {
+                m->last_ring[k] = false;
+                m->last_bm[k] = 16;
+                m->last_bn[k] = round_up(m->layers[k].c_out, 16);
+                prof_mark(m, 1 + k, st);
+            }
+            i = 2;
+            continue;
+        }
         // a tile of >= 64 rows can only be all padding if some read leaves >= 64 rows of its slot
         // unused at this layer; Lmin == 0 means "unknown": keep the test
         const int check_dead = (Lmin <= 0 || (w.P0 >> i) - (Lmin >> i) >= 64) ? 1 : 0;

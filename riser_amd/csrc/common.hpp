@@ -58,6 +58,7 @@ struct Hooks {
     bool no_fuse0 = false;           // RS_NO_FUSE0: layer 0 as its own launch on the fp32 Winograd path
     bool no_stream_f32 = false;      // RS_NO_STREAM_F32 / _H16: tiled kernels instead of the streaming ones
     bool no_stream_h16 = false;
+    bool no_stream012 = false;       // RS_NO_STREAM012: layers 0+1 and 2 of the 16-bit modes as two launches instead of one
     bool conv_stamps = false;        // RS_CONV_STAMPS: in-kernel clock stamps of the direct fp32 kernel
     char force_f32[256] = "";        // RS_FORCE_SHAPE_F32 / _WINO / _WINO4 / _H16: "layer:wm,wn,mt,nt;..."
     char force_wino[256] = "";
@@ -143,6 +144,9 @@ int conv_wino_max_bn();
 // narrow 16-bit layers (C_in <= 32, C_out <= 48): per-wave streaming kernel, optionally with ConvNet
 // layer 0 folded in (fuse_xs = normalised signals at the padded pitch behind 16 zero bytes)
 bool conv_stream_h16_ok(const ConvLayerDev& L, int P_in);
+bool conv_stream012_h16_ok(const ConvLayerDev& L1, const ConvLayerDev& L2, int c0, int P_in1);
+int launch_conv_stream012_h16(const ConvLayerDev& L1, const ConvLayerDev& L2, const float* d_xs, const float* d_w0, int c0,
+                              void* d_y, const int32_t* d_len, int B, int P_in1, int num_cu, bool f16, bool x3, hipStream_t st);
 int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
                            int layer_index, int num_cu, bool f16, hipStream_t st, const float* fuse_xs,
                            const float* fuse_w0, int fuse_c0, bool x3 = false);

@@ -379,8 +379,8 @@ __global__ __launch_bounds__(kWaves * 64, X3 ? 2 : NT == 3 ? 3 : RS_STREAM_WGS) 
                 for (int e = 0; e < 2; ++e) {
                     acc[e][j] = mfma16<F16>(wf[0][t][j], xf[t + e][0], acc[e][j]);               // hi * hi
                     if constexpr (X3) {
-                        acc[e][j] = mfma16<F16>(wf[1][t][j], xf[t + e][0], acc[e][j]);           // w lo * x hi
                         acc[e][j] = mfma16<F16>(wf[0][t][j], xf[t + e][1], acc[e][j]);           // w hi * x lo
+                        acc[e][j] = mfma16<F16>(wf[1][t][j], xf[t + e][0], acc[e][j]);           // w lo * x hi  (order of conv_ring_h16)
                     }
                 }
 #else
@@ -457,6 +457,367 @@ __global__ __launch_bounds__(kWaves * 64, X3 ? 2 : NT == 3 ? 3 : RS_STREAM_WGS) 
     }
 }
 
+// ======================================================================================================
+// Layers 0 + 1 + 2 in ONE streaming kernel: the activations of layers 0 and 1 never exist in memory.
+//
+// The wave-private pipeline of the kernel above with a second stage: a consumed block of layer 1 (16 pooled rows x
+// 32 channels) is not stored but parked as a 16-row sub-tile of a SECOND ring, and every second block a block of
+// layer 2 is consumed from that ring and stored.  Per layer-2 block w (32 layer-2 input rows -> 16 output rows):
+//     layer-0 sub-tiles 4w+3, 4w+4 -> layer-1 block 2w+1 -> ring 2;  sub-tiles 4w+5, 4w+6 -> block 2w+2 -> ring 2;
+//     layer-2 block w from ring-2 sub-tiles 2w-1 .. 2w+2 -> HBM.
+// HBM traffic of the three layers: the normalised signal in, layer 2's output out (33 + 131 MB instead of 33 + 131 +
+// 131 + 131 MB at 512 x 16000 in f16; twice the activation bytes in split precision).
+// Layer 1 has two channel tiles (16 < C1 <= 32), layer 2 one to three; layer-2 weights: hi halves in registers, the lo
+// halves of split precision in LDS (swizzled 64-byte rows).  Split precision runs one workgroup of 8 waves per CU (two
+// 36 KB rings per 4 waves), plain 16-bit three workgroups of 4.  Same arithmetic, same order: bit-identical to
+// the separate launches.
+struct Stream2Args {
+    const float* xs;          // normalised signals, flat [B * P0], preceded by 16 zero bytes
+    const float* w0;          // layer 0 (w0, w1, w2, bias) per channel, [cp0][4] fp32
+    int c0;
+    const unsigned short* w1; // layer 1: [tap][n_alloc1][32]; X3: [tap][n_alloc1][64] = hi x 32 | lo x 32
+    const float* bias1;
+    int n_alloc1;
+    const unsigned short* w2; // layer 2, same packing
+    const float* bias2;
+    int n_alloc2;
+    void* y;                  // layer 2 output [B * P2 / 2][cp_out] 16-bit
+    const int32_t* len;
+    unsigned xs_bytes, y_bytes;
+    int P2;                   // layer-2 input rows per read slot (P0 / 4), a multiple of 32
+    int n_reads;
+    int cp_out;
+    int n_sub;                // layer-2 blocks = B * P2 / 32
+    int sub_per_wave;         // even
+};
+
+template <int NT2, bool F16, bool X3>
+__global__ __launch_bounds__((X3 ? 8 : 4) * 64, X3 ? 1 : 3) void conv_stream012_h16_kernel(const Stream2Args a) {
+    constexpr int NW = X3 ? 8 : 4;                              // waves per workgroup
+    constexpr int NT1 = 2;
+    constexpr int ROWB = X3 ? 128 : 64;
+    constexpr int NH = X3 ? 2 : 1;
+    constexpr int ROWP = ROWB + 16;
+    constexpr int W2ROWS = 3 * 16 * NT2;
+    __shared__ __attribute__((aligned(16))) unsigned char ring_all[NW * 2 * kRing * ROWP];
+    __shared__ __attribute__((aligned(16))) unsigned char w2lo[X3 ? W2ROWS * 64 : 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    unsigned char* ring1 = ring_all + wave * (2 * kRing * ROWP);
+    unsigned char* ring2 = ring1 + kRing * ROWP;
+
+    if constexpr (X3) {
+        // lo halves of the layer-2 weights: row = tap * 16 NT2 + channel, 64 bytes, 16-byte slots swizzled by
+        // 2 ((row >> 2) & 1) (conflict-free ds_read_b128 of 16 consecutive rows)
+        for (int i = threadIdx.x; i < W2ROWS * 4; i += NW * 64) {
+            const int row = i >> 2, slot = i & 3, t = row / (16 * NT2), n = row - t * (16 * NT2);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(a.w2 + ((size_t)t * a.n_alloc2 + n) * 64 + 32 + 8 * slot);
+            *reinterpret_cast<u32x4*>(w2lo + row * 64 + ((slot ^ (((row >> 2) & 1) << 1)) << 4)) = v;
+        }
+        __syncthreads();
+    }
+    const int gw = blockIdx.x * NW + wave;
+    const int U0 = gw * a.sub_per_wave, U1 = U0 + a.sub_per_wave;
+    if (U0 >= a.n_sub) return;
+
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.xs - 4), 0, a.xs_bytes + 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+
+    // ---- resident operands ---------------------------------------------------------------------------
+    u32x4 wf1[NH][3][NT1];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < NT1; ++j)
+                wf1[h][t][j] = *reinterpret_cast<const u32x4*>(a.w1 + ((size_t)t * a.n_alloc1 + 16 * j + r) * (32 * NH) + 32 * h + 8 * kq);
+    u32x4 wf2[3][NT2];                                          // hi halves (plain: the weights)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < NT2; ++j)
+            wf2[t][j] = *reinterpret_cast<const u32x4*>(a.w2 + ((size_t)t * a.n_alloc2 + 16 * j + r) * (32 * NH) + 8 * kq);
+    f32x4 bias1[NT1], bias2[NT2];
+#pragma unroll
+    for (int j = 0; j < NT1; ++j) bias1[j] = *reinterpret_cast<const f32x4*>(a.bias1 + 16 * j + 4 * kq);
+#pragma unroll
+    for (int j = 0; j < NT2; ++j) bias2[j] = *reinterpret_cast<const f32x4*>(a.bias2 + 16 * j + 4 * kq);
+    float w0t[2];
+    f32x4 cb[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        w0t[m] = (kq < 3 && 16 * m + r < a.c0) ? a.w0[4 * (16 * m + r) + kq] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = 16 * m + 4 * kq + i;
+            cb[m][i] = ch < a.c0 ? a.w0[4 * ch + 3] : 0.0f;
+        }
+    }
+    const int wslot = 2 * (kq & 1) + (kq >> 1);                 // ring slot of the 8 consecutive channels a lane gathers
+
+    const const_len_ptr clen = as_const_len(a.len);
+    struct SubInfo {
+        int t0, l0;                                             // first input row's position in its read; valid input rows
+    };
+    auto len_of = [&](int b) { return (b >= 0 && b < a.n_reads) ? clen[b] : 0; };   // raw samples
+
+    // ---- layer 0: sub-tiles of 16 layer-1 input rows into ring 1 ---------------------------------------
+    constexpr int D = 8;
+    u32x2 pre[D];
+    const unsigned lane_off = (unsigned)(2 * r - 1 + kq + 4) * 4u;
+    auto issue_load = [&](int u, u32x2& dst) { dst = __builtin_amdgcn_raw_buffer_load_b64(rs_x, lane_off + (unsigned)u * 128u, 0, 0); };
+    struct Row {
+        u32x4 v[NH];
+    };
+    auto conv0 = [&](const u32x2& raw) {
+        const unsigned ue = raw[0], uo = raw[1];
+        const float xe = __builtin_bit_cast(float, ue), xo = __builtin_bit_cast(float, uo);
+        float o[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const f32x4 e = __builtin_amdgcn_mfma_f32_16x16x4f32(w0t[m], xe, cb[m], 0, 0, 0);
+            const f32x4 f = __builtin_amdgcn_mfma_f32_16x16x4f32(w0t[m], xo, cb[m], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[m][i] = fmaxf(fmaxf(e[i], f[i]), 0.0f);
+        }
+        unsigned w[NH][2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            w[0][m][0] = pack2<F16>(o[m][0], o[m][1]);
+            w[0][m][1] = pack2<F16>(o[m][2], o[m][3]);
+            if constexpr (X3) {
+                w[1][m][0] = pack2_lo<F16>(o[m][0], o[m][1], w[0][m][0]);
+                w[1][m][1] = pack2_lo<F16>(o[m][2], o[m][3], w[0][m][1]);
+            }
+        }
+        Row out;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const auto s0 = __builtin_amdgcn_permlane16_swap(w[h][0][0], w[h][1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(w[h][0][1], w[h][1][1], false, false);
+            out.v[h] = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+        }
+        return out;
+    };
+    const unsigned ring_w = (unsigned)(r * ROWP + (wslot << 4));
+    auto park = [&](unsigned char* ring, int u, const Row& v) {   // sub-tile u occupies ring rows 16 (u & 3) ..
+        unsigned char* dst = ring + ring_w + (unsigned)((u & 3) * 16 * ROWP);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) *reinterpret_cast<u32x4*>(dst + 64 * h) = v.v[h];
+    };
+    auto produce_fast = [&](int u, const u32x2& raw) { park(ring1, u, conv0(raw)); };
+    auto produce = [&](int u, const u32x2& raw, const SubInfo& si) {
+        Row v;
+        if (si.t0 >= si.l0) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) v.v[h] = (u32x4){0u, 0u, 0u, 0u};
+        } else {
+            v = conv0(raw);
+            const unsigned keep = si.t0 + r < si.l0 ? ~0u : 0u;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) v.v[h] &= (u32x4){keep, keep, keep, keep};
+        }
+        park(ring1, u, v);
+    };
+
+    // ---- a conv block: 16 pooled outputs of block v from the 34 ring rows 32v - 1 .. 32v + 32 ------------
+    const unsigned ring_r = (unsigned)(2 * r * ROWP + (kq << 4));
+    auto block = [&](const unsigned char* ring, int v, const SubInfo& si, auto MASKED, auto NTc, const auto& whi, const auto& wlo,
+                     const auto& bias, auto&& sink) {
+        constexpr bool masked = decltype(MASKED)::value;
+        constexpr int NT = decltype(NTc)::value;
+        constexpr int NTP = X3 ? 2 * ((NT + 1) / 2) : NT;
+        const int tp0 = si.t0 >> 1, out_len = si.l0 >> 1;
+        u32x2 hi[NTP], lo[NTP];
+#pragma unroll
+        for (int j = 0; j < NTP; ++j) hi[j] = lo[j] = (u32x2){0u, 0u};
+        if (masked && tp0 >= out_len) {
+            sink(hi, lo);
+            return;
+        }
+        u32x4 xf[4][NH];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned off = (unsigned)((32 * v + d - 1) & (kRing - 1)) * ROWP + ring_r;
+            if (d == 3 || d == 0) off = (unsigned)(((32 * v + 2 * r + d - 1) & (kRing - 1)) * ROWP + (kq << 4));
+#pragma unroll
+            for (int h = 0; h < NH; ++h) xf[d][h] = *reinterpret_cast<const u32x4*>(ring + off + 64 * h);
+        }
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[e][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    acc[e][j] = mfma16<F16>(whi(t, j), xf[t + e][0], acc[e][j]);                 // hi * hi
+                    if constexpr (X3) {
+                        acc[e][j] = mfma16<F16>(whi(t, j), xf[t + e][1], acc[e][j]);             // w hi * x lo
+                        acc[e][j] = mfma16<F16>(wlo(t, j), xf[t + e][0], acc[e][j]);             // w lo * x hi  (order of conv_ring_h16)
+                    }
+                }
+        const unsigned keep = (!masked || tp0 + r < out_len) ? ~0u : 0u;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const f32x2 b01 = {bias[j][0], bias[j][1]}, b23 = {bias[j][2], bias[j][3]};
+            const f32x2 e01 = (f32x2){acc[0][j][0], acc[0][j][1]} + b01, e23 = (f32x2){acc[0][j][2], acc[0][j][3]} + b23;
+            const f32x2 o01 = (f32x2){acc[1][j][0], acc[1][j][1]} + b01, o23 = (f32x2){acc[1][j][2], acc[1][j][3]} + b23;
+            const float p0 = fmaxf(fmaxf(e01[0], o01[0]), 0.0f), p1 = fmaxf(fmaxf(e01[1], o01[1]), 0.0f);
+            const float p2 = fmaxf(fmaxf(e23[0], o23[0]), 0.0f), p3 = fmaxf(fmaxf(e23[1], o23[1]), 0.0f);
+            hi[j] = (u32x2){pack2<F16>(p0, p1), pack2<F16>(p2, p3)};
+            if constexpr (X3) lo[j] = (u32x2){pack2_lo<F16>(p0, p1, hi[j][0]), pack2_lo<F16>(p2, p3, hi[j][1])};
+            if constexpr (masked) {
+                hi[j] &= (u32x2){keep, keep};
+                lo[j] &= (u32x2){keep, keep};
+            }
+        }
+        sink(hi, lo);
+    };
+    // layer 1: weights in registers, the block becomes sub-tile v of ring 2 (8 consecutive channels per lane)
+    auto w1hi = [&](int t, int j) -> const u32x4& { return wf1[0][t][j]; };
+    auto w1lo = [&](int t, int j) -> const u32x4& { return wf1[NH - 1][t][j]; };
+    auto block1 = [&](int v, const SubInfo& si, auto MASKED) {
+        block(ring1, v, si, MASKED, std::integral_constant<int, NT1>{}, w1hi, w1lo, bias1, [&](const auto& hi, const auto& lo) {
+            Row row;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const u32x2 wa = h ? lo[0] : hi[0], wb = h ? lo[1] : hi[1];
+                const auto s0 = __builtin_amdgcn_permlane16_swap(wa[0], wb[0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(wa[1], wb[1], false, false);
+                row.v[h] = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+            }
+            park(ring2, v, row);
+        });
+    };
+    // layer 2: hi weights in registers, lo weights from LDS; the block is stored
+    const int ch_lim = X3 ? a.cp_out / 2 : a.cp_out;
+    auto ch_off = [&](int ch) { return (unsigned)(X3 ? ((ch >> 5) << 6) + (ch & 31) : ch) * 2u; };
+    constexpr int NTP2 = X3 ? 2 * ((NT2 + 1) / 2) : NT2;
+    unsigned st_off[(NTP2 + 1) / 2];
+#pragma unroll
+    for (int j = 0; j + 1 < NTP2; j += 2) {
+        const int ch = 16 * j + 16 * (kq & 1) + 8 * (kq >> 1);
+        st_off[j / 2] = ch < ch_lim ? (unsigned)(r * a.cp_out * 2) + ch_off(ch) : kOob;
+    }
+    if constexpr (NTP2 & 1) {
+        const int ch = 16 * (NTP2 - 1) + 4 * kq;
+        st_off[NTP2 / 2] = ch < ch_lim ? (unsigned)(r * a.cp_out * 2) + ch_off(ch) : kOob;
+    }
+    const unsigned blk_bytes = 32u * (unsigned)a.cp_out;
+    auto w2hi = [&](int t, int j) -> const u32x4& { return wf2[t][j]; };
+    auto block2 = [&](int v, const SubInfo& si, auto MASKED) {
+        u32x4 wl[3][NT2];
+        if constexpr (X3) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < NT2; ++j) {
+                    const int row = t * 16 * NT2 + 16 * j + r;
+                    wl[t][j] = *reinterpret_cast<const u32x4*>(w2lo + row * 64 + ((kq ^ (((row >> 2) & 1) << 1)) << 4));
+                }
+        }
+        auto w2l = [&](int t, int j) -> const u32x4& { return wl[t][j]; };
+        block(ring2, v, si, MASKED, std::integral_constant<int, NT2>{}, w2hi, w2l, bias2, [&](const auto& hi, const auto& lo) {
+            const unsigned base = v < a.n_sub ? (unsigned)v * blk_bytes : kOob;
+#pragma unroll
+            for (int j = 0; j + 1 < NTP2; j += 2) {
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const u32x2 wa = h ? lo[j] : hi[j], wb = h ? lo[j + 1] : hi[j + 1];
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(wa[0], wb[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(wa[1], wb[1], false, false);
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){s0[0], s1[0], s0[1], s1[1]}, rs_y,
+                                                           ((base | st_off[j / 2]) & kOob) ? kOob : base + st_off[j / 2] + 64u * h, 0, 0);
+                }
+            }
+            if constexpr (NTP2 & 1)
+                __builtin_amdgcn_raw_buffer_store_b64(hi[NTP2 - 1], rs_y,
+                                                      ((base | st_off[NTP2 / 2]) & kOob) ? kOob : base + st_off[NTP2 / 2], 0, 0);
+        });
+    };
+
+    // ---- run ---------------------------------------------------------------------------------------------
+    // positions are tracked in layer-2 input rows (T0, a multiple of 32, in read rb); a layer-1 input row is twice
+    // that, valid rows are len >> 1 (layer-1 input), len >> 2 (layer-2 input)
+    const int s_first = 4 * U0 - 3;
+    static_for<D>([&](auto K) { issue_load(s_first + decltype(K)::value, pre[decltype(K)::value]); });
+    int rb = (32 * U0) / a.P2;
+    int T0 = 32 * U0 - rb * a.P2;
+    int len0 = len_of(rb), len1 = len_of(rb + 1);
+    {
+        // the six sub-tiles and two layer-1 blocks in front of the run's first layer-2 block
+        const int lp = T0 > 0 ? len0 >> 1 : len_of(rb - 1) >> 1;
+        const int bp = T0 > 0 ? 2 * T0 : 2 * a.P2;             // position of the row after them in THEIR read
+        const int l0 = len0 >> 1;
+        produce(s_first, pre[0], SubInfo{bp - 48, lp});
+        issue_load(s_first + D, pre[0]);
+        produce(s_first + 1, pre[1], SubInfo{bp - 32, lp});
+        issue_load(s_first + 1 + D, pre[1]);
+        produce(s_first + 2, pre[2], SubInfo{bp - 16, lp});
+        issue_load(s_first + 2 + D, pre[2]);
+        produce(s_first + 3, pre[3], SubInfo{2 * T0, l0});
+        issue_load(s_first + 3 + D, pre[3]);
+        block1(2 * U0 - 1, SubInfo{bp - 32, lp}, std::true_type{});
+        produce(s_first + 4, pre[4], SubInfo{2 * T0 + 16, l0});
+        issue_load(s_first + 4 + D, pre[4]);
+        produce(s_first + 5, pre[5], SubInfo{2 * T0 + 32, l0});
+        issue_load(s_first + 5 + D, pre[5]);
+        block1(2 * U0, SubInfo{2 * T0, l0}, std::true_type{});
+    }
+    for (int w0 = U0; w0 < U1; w0 += 2) {
+        static_for<2>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            const int w = w0 + k;
+            u32x2& sa = pre[(6 + 4 * k) % D];
+            u32x2& sb = pre[(7 + 4 * k) % D];
+            u32x2& sc = pre[(8 + 4 * k) % D];
+            u32x2& sd = pre[(9 + 4 * k) % D];
+            const bool wrap = T0 + 32 >= a.P2;
+            if (2 * T0 + 112 <= (len0 >> 1)) {                  // interior: everything this iteration touches is valid
+                produce_fast(4 * w + 3, sa);
+                issue_load(4 * w + 3 + D, sa);
+                produce_fast(4 * w + 4, sb);
+                issue_load(4 * w + 4 + D, sb);
+                block1(2 * w + 1, SubInfo{0, 0}, std::false_type{});
+                produce_fast(4 * w + 5, sc);
+                issue_load(4 * w + 5 + D, sc);
+                produce_fast(4 * w + 6, sd);
+                issue_load(4 * w + 6 + D, sd);
+                block1(2 * w + 2, SubInfo{0, 0}, std::false_type{});
+                block2(w, SubInfo{0, 0}, std::false_type{});
+            } else {
+                const int tn = wrap ? 0 : 2 * (T0 + 32);       // layer-1 input position of the next layer-2 block
+                const int ln = (wrap ? len1 : len0) >> 1, l0 = len0 >> 1;
+                produce(4 * w + 3, sa, SubInfo{2 * T0 + 48, l0});
+                issue_load(4 * w + 3 + D, sa);
+                produce(4 * w + 4, sb, SubInfo{tn, ln});
+                issue_load(4 * w + 4 + D, sb);
+                block1(2 * w + 1, SubInfo{2 * T0 + 32, l0}, std::true_type{});
+                produce(4 * w + 5, sc, SubInfo{tn + 16, ln});
+                issue_load(4 * w + 5 + D, sc);
+                produce(4 * w + 6, sd, SubInfo{tn + 32, ln});
+                issue_load(4 * w + 6 + D, sd);
+                block1(2 * w + 2, SubInfo{tn, ln}, std::true_type{});
+                block2(w, SubInfo{T0, len0 >> 2}, std::true_type{});
+            }
+            T0 += 32;
+            if (wrap) {
+                T0 = 0;
+                ++rb;
+                len0 = len1;
+                len1 = len_of(rb + 1);
+            }
+        });
+    }
+}
+
 using KernelFn = void (*)(const StreamArgs);
 
 template <bool FUSE0, bool X3>
@@ -520,6 +881,65 @@ int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, co
     KernelFn fn = x3 ? (fuse_xs ? pick<true, true>(nt, f16) : pick<false, true>(nt, f16))
                      : (fuse_xs ? pick<true, false>(nt, f16) : pick<false, false>(nt, f16));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kWaves * 64), 0, st, a);
+    RS_HIP(hipGetLastError());
+    return RS_OK;
+}
+
+// layers 1 and 2 qualify for the three-layer kernel when both would stream on their own, layer 1 has two channel tiles
+// and the read slots of layer 2 are whole blocks
+bool conv_stream012_h16_ok(const ConvLayerDev& L1, const ConvLayerDev& L2, int c0, int P_in1) {
+    return c0 <= 32 && conv_stream_h16_ok(L1, P_in1) && conv_stream_h16_ok(L2, P_in1 / 2) && L1.c_out > 16 && L1.c_out <= 32 &&
+           (P_in1 / 2) % 32 == 0 && !L1.hooks->no_stream012;
+}
+
+int launch_conv_stream012_h16(const ConvLayerDev& L1, const ConvLayerDev& L2, const float* d_xs, const float* d_w0, int c0,
+                              void* d_y, const int32_t* d_len, int B, int P_in1, int num_cu, bool f16, bool x3, hipStream_t st) {
+    const int P2 = P_in1 / 2;
+    const int64_t rows2 = (int64_t)B * P2;
+    const int64_t sb = rows2 * 4 * 4, yb = rows2 / 2 * L2.cp_out * 2;
+    if (sb >= 0x80000000LL || yb >= 0x80000000LL) {
+        set_error("conv_stream012_h16: batch too large for the 2 GiB buffer window, split it");
+        return RS_ERR_ARG;
+    }
+    Stream2Args a;
+    a.xs = d_xs;
+    a.w0 = d_w0;
+    a.c0 = c0;
+    a.w1 = static_cast<const unsigned short*>(x3 ? L1.d_w2 : L1.d_w);
+    a.w2 = static_cast<const unsigned short*>(x3 ? L2.d_w2 : L2.d_w);
+    if (!a.w1 || !a.w2) {
+        set_error("conv_stream012_h16: no packed weights for this mode");
+        return RS_ERR_ARG;
+    }
+    a.bias1 = L1.d_bias;
+    a.bias2 = L2.d_bias;
+    a.n_alloc1 = L1.plan.n_alloc;
+    a.n_alloc2 = L2.plan.n_alloc;
+    a.y = d_y;
+    a.len = d_len;
+    a.xs_bytes = (unsigned)sb;
+    a.y_bytes = (unsigned)yb;
+    a.P2 = P2;
+    a.n_reads = B;
+    a.cp_out = L2.cp_out;
+    a.n_sub = (int)(rows2 / 32);
+    const int nw = x3 ? 8 : 4;
+    const int waves = num_cu * (x3 ? 8 : 12);                   // one workgroup of 8 waves, or three of 4, per CU
+    a.sub_per_wave = round_up(std::max(8, (a.n_sub + waves - 1) / waves), 2);
+    const int n_waves = (a.n_sub + a.sub_per_wave - 1) / a.sub_per_wave;
+    const int grid = (n_waves + nw - 1) / nw;
+    const int nt2 = round_up(L2.c_out, 16) / 16;
+    using Fn = void (*)(const Stream2Args);
+    Fn fn;
+    if (x3)
+        fn = nt2 == 1 ? (f16 ? conv_stream012_h16_kernel<1, true, true> : conv_stream012_h16_kernel<1, false, true>)
+           : nt2 == 2 ? (f16 ? conv_stream012_h16_kernel<2, true, true> : conv_stream012_h16_kernel<2, false, true>)
+                      : (f16 ? conv_stream012_h16_kernel<3, true, true> : conv_stream012_h16_kernel<3, false, true>);
+    else
+        fn = nt2 == 1 ? (f16 ? conv_stream012_h16_kernel<1, true, false> : conv_stream012_h16_kernel<1, false, false>)
+           : nt2 == 2 ? (f16 ? conv_stream012_h16_kernel<2, true, false> : conv_stream012_h16_kernel<2, false, false>)
+                      : (f16 ? conv_stream012_h16_kernel<3, true, false> : conv_stream012_h16_kernel<3, false, false>);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(nw * 64), 0, st, a);
     RS_HIP(hipGetLastError());
     return RS_OK;
 }

@@ -246,11 +246,12 @@ def test_stream_classifier_matches_direct(dev):
     m.close()
 
 
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16x3", "f16x3"])
 def test_h16_streaming_layers_and_layer0_fold(dev, dtype):
-    """16-bit narrow layers: the per-wave streaming kernel (layers 1-2), with and without ConvNet layer 0
-    folded in, must reproduce the tiled 16-bit kernel bit for bit (same MFMA sequence, same roundings),
-    on full-length and mixed-length batches, and stay within the 16-bit tolerance of the oracle."""
+    """16-bit narrow layers: the per-wave streaming kernels - layers 0+1+2 in one launch (the default), layers 0+1
+    and 2 as two launches (RS_NO_STREAM012), layers 1 and 2 behind the stand-alone layer-0 kernel - must reproduce
+    the tiled 16-bit kernel bit for bit (same MFMA sequence, same roundings; layer 0 on the f32-input MFMA is the
+    same fmaf chain), on full-length and mixed-length batches, and stay within the mode's tolerance of the oracle."""
     import os
     from riser_amd.model import Model
     from riser_amd.preprocess import pack_reads
@@ -258,7 +259,8 @@ def test_h16_streaming_layers_and_layer0_fold(dev, dtype):
     from conftest import hooked_model
     m = Model(sd, synth.Config(), None, "m", dtype=dtype, device=dev)
     m_tiled = hooked_model({"RS_NO_STREAM_H16": "1"}, sd, dtype, dev)
-    tol = {"f16": 2e-2, "bf16": 1.5e-1}[dtype]
+    m_two = hooked_model({"RS_NO_STREAM012": "1"}, sd, dtype, dev)
+    tol = {"f16": 2e-2, "bf16": 1.5e-1, "bf16x3": 1e-3, "f16x3": 1e-3}[dtype]
     for lens in ([16000] * 6, [4096, 16000, 8615, 5000, 12001, 4097, 16383, 9999]):
         sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=300 + i)[0] for i, n in enumerate(lens)]
         sig, off, ln, lh = pack_reads(sigs, dev)
@@ -266,12 +268,15 @@ def test_h16_streaming_layers_and_layer0_fold(dev, dtype):
         fused = m.classify_raw(sig, off, ln, lh).cpu().numpy()               # layer 0 folded into layer 1
         stream = m.classify_batch(xs).cpu().numpy()                          # conv0 kernel + streaming layers 1-2
         tiled = m_tiled.classify_raw(sig, off, ln, lh).cpu().numpy()     # conv0 kernel + tiled kernel everywhere
+        two = m_two.classify_raw(sig, off, ln, lh).cpu().numpy()             # layers 0+1, then layer 2
+        assert np.array_equal(fused, two), np.abs(fused - two).max()
         assert np.array_equal(fused, stream), np.abs(fused - stream).max()
         assert np.array_equal(fused, tiled), np.abs(fused - tiled).max()
         want = np.stack([ro.classify(sd, x) for x in xs])
         assert np.abs(fused - want).max() < tol
     m.close()
     m_tiled.close()
+    m_two.close()
 
 
 def test_config3_ensemble_split_precision_full_size(dev):
