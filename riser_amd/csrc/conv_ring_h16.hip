@@ -394,25 +394,27 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int orow0 = (q.m0 + (wm * MT + i) * 16) >> 1;      // first of the block's 8 pooled rows
-            bool valid[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                // read and position of pooled row 2g + h: float quotient, exact for t < 2^16 (conv_f32.hip)
-                const int t = p0 + (orow0 + 2 * g + h - pr0);
+            // the lane ends up with channels (r & ~1, r | 1) of pooled row 2g + odd: that row's validity masks the packed
+            // words (read and position of the row: float quotient, exact for t < 2^16, as in conv_f32.hip)
+            unsigned keep;
+            {
+                const int t = p0 + (orow0 + 2 * g + (odd ? 1 : 0) - pr0);
                 const int e = (int)(((float)t + 0.5f) * a.inv_P_out);
-                valid[h] = t - e * a.P_out < (llen[e] >> a.shift_out);
+                keep = t - e * a.P_out < (llen[e] >> a.shift_out) ? ~0u : 0u;
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const float v0 = valid[0] ? fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]) + bias[j], 0.0f) : 0.0f;
-                const float v1 = valid[1] ? fmaxf(fmaxf(acc[i][j][2], acc[i][j][3]) + bias[j], 0.0f) : 0.0f;
+                // MaxPool, + bias, ReLU: max(a, b) + c == max(a + c, b + c) bit for bit (rounding is monotonic); the sums
+                // are canonical, so the compiler emits one v_max3_f32 instead of two canonicalising v_max + max + max
+                const float v0 = fmaxf(fmaxf(acc[i][j][0] + bias[j], acc[i][j][1] + bias[j]), 0.0f);
+                const float v1 = fmaxf(fmaxf(acc[i][j][2] + bias[j], acc[i][j][3] + bias[j]), 0.0f);
                 const float got = swap_pair(odd ? v0 : v1);
                 const float ca = odd ? got : v0, cb_ = odd ? v1 : got;          // channels (r & ~1, r | 1) of row 2g + odd
                 const unsigned hi = pack2<F16>(ca, cb_);
                 unsigned char* dst = scr + (2 * g + (odd ? 1 : 0)) * PITCH + j * PW * 16 + (r & ~1) * 2;
-                *reinterpret_cast<unsigned*>(dst) = hi;
+                *reinterpret_cast<unsigned*>(dst) = hi & keep;
                 if constexpr (X3)
-                    *reinterpret_cast<unsigned*>(dst + 32) =
+                    *reinterpret_cast<unsigned*>(dst + 32) = keep &
                         pack2<F16>(ca - widen16<F16>((unsigned short)(hi & 0xffffu)), cb_ - widen16<F16>((unsigned short)(hi >> 16)));
                 acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
