@@ -71,7 +71,13 @@ __device__ void block_select2(KeyFn key, int n, int R, int k_lo, int k_hi, unsig
     for (int i = tid; i < kBins; i += kThreads) hist[i] = 0u;
     if (tid < 2 * kSubBins) (&sc->sub[0][0])[tid] = 0u;
     __syncthreads();
-    for (int i = tid; i < n; i += kThreads) atomicAdd(&hist[key(i) >> shift], 1u);
+    // Every thread walks its own contiguous run of the read (odd length: neighbouring lanes' 2-byte LDS reads fall
+    // into different banks): the lanes of one ds_add then hold samples ~chunk apart.  Nanopore signal dwells on a
+    // level for tens of samples, so with lanes on CONSECUTIVE samples most lanes of an instruction hit the same bin and
+    // the LDS atomic unit serialises them.
+    const int chunk = ((n + kThreads - 1) / kThreads) | 1;
+    for (int k = 0, i = tid * chunk; k < chunk; ++k, ++i)
+        if (i < n) atomicAdd(&hist[key(i) >> shift], 1u);
     __syncthreads();
     int loc[8];
     int s = 0;
@@ -104,7 +110,8 @@ __device__ void block_select2(KeyFn key, int n, int R, int k_lo, int k_hi, unsig
         return;
     }
     const int mask = (1 << shift) - 1;
-    for (int i = tid; i < n; i += kThreads) {
+    for (int k = 0, i = tid * chunk; k < chunk; ++k, ++i) {
+        if (i >= n) break;
         const int kk = key(i);
         const int hb = kk >> shift;
         if (hb == bin_lo) atomicAdd(&sc->sub[0][kk & mask], 1u);
