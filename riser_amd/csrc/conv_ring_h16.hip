@@ -75,6 +75,8 @@ struct RingArgs {
     float inv_P_out;
     int cpx_in, cpx_out;         // row pitches in 16-bit elements
     int cols_out;                // logical output columns that exist in a row (plain: cpx_out; x3: 32 x panels)
+    int cols_tiled;              // columns the tile grid covers (a multiple of BN); x3: the slots from here to cols_out are
+                                 // written as zeros by the last tile of a row of tiles, not computed
     int n_panels;
     int n_alloc;
     int n_reads;
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
                 const int t0 = tm0 - b * P_in_;
                 if (!(t0 + BM <= P_in_ && t0 >= (as_const_len(a.len)[b] >> (a.shift_out - 1)))) break;
                 // zero-fill the BM/2 x BN output tile in 16-byte pieces (x3: the hi and the lo half of every piece)
-                const int pieces_per_row = BN / 8;
+                const int pieces_per_row = (tn0 + BN == a.cols_tiled ? max(a.cols_out - tn0, BN) : BN) / 8;
                 for (int f = threadIdx.x; f < (BM / 2) * pieces_per_row; f += blockDim.x) {
                     const int rr = f / pieces_per_row, cc = (f - rr * pieces_per_row) * 8;
                     const int orow = (tm0 >> 1) + rr, col = tn0 + cc;
@@ -429,6 +431,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
                 const bool ok = qi < NPIECE && 2 * orow < a.rows_in && col < a.cols_out;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(scr + row8 * PITCH + w * 16);
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, ok ? (unsigned)(orow * a.cpx_out + elem) * 2u : kOob, 0, 0);
+            }
+            if constexpr (X3) {
+                // the slots between the last computed 16-column tile and the end of its 32-slot panel: zeros (the next layer
+                // multiplies them by zero weights, so they must be finite); 8 rows x 2 pieces x (hi, lo) = one store of 32 lanes
+                if (wn == WN - 1 && q.n0 + BN == a.cols_tiled && a.cols_tiled < a.cols_out) {
+                    const int row8 = lane >> 2, part = lane & 3;
+                    const int orow = orow0 + row8;
+                    const int col = a.cols_tiled + 8 * (part & 1);
+                    const int elem = phys_col<X3>(col) + 32 * (part >> 1);
+                    const bool ok = lane < 32 && 2 * orow < a.rows_in && col < a.cols_out;
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){0u, 0u, 0u, 0u}, rs_y,
+                                                           ok ? (unsigned)(orow * a.cpx_out + elem) * 2u : kOob, 0, 0);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -613,8 +628,9 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
         return RS_ERR_ARG;
     }
     // split precision: a row holds 32 channel slots per panel and EVERY slot must be written (the next layer multiplies
-    // the slots behind the last channel by zero weights: they have to be finite), so the tiles cover all of them
-    const int n16 = x3 ? L.cp_out / 32 : round_up(L.c_out, 16) / 16;
+    // the slots behind the last channel by zero weights: they have to be finite): the tiles cover the 16-column groups
+    // that hold channels, the last tile of a row of tiles stores zeros into what is left of the last panel
+    const int n16 = round_up(L.c_out, 16) / 16;
     const int n_panels = L.ring_panels;
     const Shape* s = choose_shape(rows64, n16, n_panels, num_cu, x3);
     if (const char* force = L.hooks->force_ring; *force) {          // tuning aid: "layer:wm,wn,mt,nt;..."
@@ -662,6 +678,11 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     a.n_reads = B;
     a.shift_out = layer_index + 1;
     const int n_mtiles = (a.rows_in + BM - 1) / BM, n_ntiles = (n16 * 16 + BN - 1) / BN;
+    a.cols_tiled = n_ntiles * BN;
+    if (a.cols_out - a.cols_tiled > 16) {                          // cannot happen: a panel is 32 slots, a column group 16
+        set_error("conv_ring_h16: %d slots behind the tiles of layer %d", a.cols_out - a.cols_tiled, layer_index);
+        return RS_ERR_ARG;
+    }
     const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
     a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, BM, 3.0 * BN, check_dead, !L.hooks->no_rect_order);
