@@ -295,7 +295,7 @@ def side_variants(args, device, wl, ref):
         return {"max_abs_dprob_vs_f32": float(np.abs(p - ref).max()),
                 "label_flips_at_0.9_vs_f32": int(((p[:, 1] > 0.9) != (ref[:, 1] > 0.9)).sum())}
 
-    for dt in ("f32", "bf16x3", "f16", "bf16"):
+    for dt in ("f32", "bf16x3", "f16x3", "f16", "bf16"):
         if dt not in Model.dtypes():
             continue
         mv = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dt, device=device)
