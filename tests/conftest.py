@@ -19,7 +19,7 @@ def golden_dir():
     return GOLDEN
 
 
-def hooked_model(env, state, dtype, device, target="m"):
+def hooked_model(env, state, dtype, device, target="m", config=None):
     """A Model created while the RS_* tuning / diagnostic variables of `env` are set: the library reads them
     once, in rs_model_create, never on the launch path."""
     from riser_amd import synth
@@ -27,7 +27,7 @@ def hooked_model(env, state, dtype, device, target="m"):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        return Model(state, synth.Config(), None, target, dtype=dtype, device=device)
+        return Model(state, config or synth.Config(), None, target, dtype=dtype, device=device)
     finally:
         for k, v in old.items():
             if v is None:

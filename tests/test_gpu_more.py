@@ -463,3 +463,33 @@ def test_classify_population_shards_by_read_id(dev):
         assert np.array_equal(pr[0], full[0][ix])
     assert (seen == 1).all()
     m.close()
+
+
+@pytest.mark.parametrize("channels", [(12, 24, 33, 40, 50), (20, 30, 16, 70), (20, 32, 32, 96, 130, 200), (8, 17, 48)])
+def test_other_channel_widths_all_modes(dev, channels):
+    """ConvNets of the shipped class (depth 1, kernel 3, gap_fc) with OTHER channel widths: every width class of the
+    streaming kernels (layer 1 with 17..32 channels, layer 2 with one, two or three 16-channel tiles, layer 0 below 20
+    channels), the tiled kernels on odd widths, 3- to 6-layer nets; fp32, plain 16-bit and split precision against the
+    oracle on a mixed-length batch, and the one-launch streaming form against the two-launch one bit for bit."""
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    from conftest import hooked_model
+    cfg = synth.Config(synth.CnnConfig(channels=list(channels), kernels=[3] * len(channels)))
+    sd = synth.make_state_dict(7, channels=channels)
+    lens = [4096, 8000, 5000, 8191, 4097, 6024, 7777]
+    sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=700 + i)[0] for i, n in enumerate(lens)]
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    want = ro.classify_reads(sd, sigs)
+    for dtype, tol in (("f32w", 1e-4), ("f32", 1e-4), ("f16x3", 1e-3), ("bf16x3", 1e-3), ("f16", 3e-2)):
+        m = Model(sd, cfg, None, "m", dtype=dtype, device=dev)
+        got = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+        assert np.abs(got - want).max() < tol, (dtype, channels, np.abs(got - want).max())
+        if dtype in ("f16x3", "bf16x3", "f16"):
+            m2 = hooked_model({"RS_NO_STREAM012": "1"}, sd, dtype, dev, config=cfg)
+            assert np.array_equal(got, m2.classify_raw(sig, off, ln, lh).cpu().numpy()), (dtype, channels)
+            m2.close()
+        # batch composition: a sub-batch reproduces its rows bit for bit
+        idx = torch.tensor([5, 0, 3], device=dev)
+        part = m.classify_raw(sig, off[idx].contiguous(), ln[idx].contiguous(), lh[[5, 0, 3]]).cpu().numpy()
+        assert np.array_equal(part, got[[5, 0, 3]]), (dtype, channels)
+        m.close()
