@@ -75,7 +75,7 @@ struct StreamArgs {
     const float* bias;        // [n_alloc]
     void* y;                  // [rows_in / 2][cp_out] 16-bit
     const int32_t* len;
-    unsigned x_bytes, xs_bytes, y_bytes, w_bytes, bias_bytes;
+    unsigned x_bytes, xs_bytes, y_bytes;
     int rows_in;              // B * P_in
     int P_in;
     int n_reads;
@@ -861,8 +861,6 @@ int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, co
     a.x_bytes = (unsigned)xb;
     a.xs_bytes = (unsigned)sb;
     a.y_bytes = (unsigned)yb;
-    a.w_bytes = 0;
-    a.bias_bytes = 0;
     a.rows_in = (int)rows64;
     a.P_in = P_in;
     a.n_reads = B;
