@@ -82,6 +82,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="reads per library call (sub-batch for promethion)")
     ap.add_argument("--chunk", type=int, default=CHUNK)
     ap.add_argument("--reads-per-gpu", type=int, default=READS_PER_GPU)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="promethion: sub-batches in flight on separate HIP streams (2: idle CUs of one run the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=18.0)
     ap.add_argument("--no-latency", action="store_true", help="skip the per-batch latency loop (profiling runs)")
@@ -185,7 +187,8 @@ class Workload:
             self.reads_per_step = n
             self.workload = (f"PromethION-scale population of {args.reads_per_gpu * world} x {L}-sample (4 s) int16 chunks, "
                              f"sharded by read id over {world} GPU(s) ({n} on rank 0), HBM-resident, walked in sub-batches of "
-                             f"{B}: MAD-normalise + 12-layer ConvNet forward + softmax, {args.dtype}")
+                             f"{B}" + (f" with {args.streams} in flight on separate HIP streams" if args.streams > 1 else "") +
+                             f": MAD-normalise + 12-layer ConvNet forward + softmax, {args.dtype}")
         else:
             sigs = synth.make_signals(SIG_SEED, B, L, first_read=rank * B)   # each rank owns a different shard
             self.sample_sigs = sigs
@@ -206,7 +209,7 @@ class Workload:
         if self.args.config == "promethion":
             from riser_amd.stream import classify_resident
             classify_resident([self.model], self.sig, self.n_reads, self.args.chunk, self.lens_host, self.sub,
-                              out=self.probs)
+                              out=self.probs, streams=self.args.streams)
         else:
             self.model.classify_raw(self.sig, self.off, self.ln, self.lens_host, out=self.probs)
 
@@ -248,7 +251,10 @@ def roofline_object(args, model, wl, conv_ms_total, conv_calls, stage_ms, detail
                      "layers %s, f32-input MFMA)" % (",".join(f23), ",".join(f43)),
              "f32": "conv_f32_kernel (direct, f32-input MFMA)"}.get(lib_dtype, "16-bit MFMA conv kernels (%s)" % lib_dtype)
     conv_ms_detail = float(stage_ms[2:2 + nl - 1].sum()) / max(detail_calls, 1)
-    return {"bound": "mfma", "kernel": kname + f", {nl - 1} launches per call, layers 1-{nl - 1}",
+    overlap = ({"streams_note": f"{args.streams} sub-batches in flight: the per-call HIP-event times overlap, so `achieved` / `frac` "
+                                "(FLOPs over the SUM of those times) understate the pipe's share; use --streams 1 for the roofline"}
+               if getattr(args, "streams", 1) > 1 else {})
+    return {**overlap, "bound": "mfma", "kernel": kname + f", {nl - 1} launches per call, layers 1-{nl - 1}",
             "achieved": round(exe_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(exe_tf / peak, 4),
             "traffic": None,
             "traffic_note": "HBM bytes are not measurable from inside the run; FETCH_SIZE / WRITE_SIZE passes of this tree "
@@ -305,6 +311,27 @@ def side_variants(args, device, wl, ref):
         dtv = timed(lambda: mv.classify_raw(sig, off, ln, lens, out=pv))
         variants["f32_direct" if dt == "f32" else dt] = {
             "chunks_per_s": round(B / dtv, 1), "ms_per_step": round(dtv * 1e3, 4), "batch": B, **versus_ref(pv.cpu().numpy())}
+        mv.close()
+    # two batches in flight: the same 512-read call alternately on two HIP streams (per-stream workspaces).  The idle CUs
+    # of one batch's tile rounds, prologues and launch boundaries run the other's work; throughput-oriented callers
+    # (stream.classify_resident(streams=2), BASELINE config 4) use it, the headline and the control loop do not
+    for dt in ("f32", "bf16x3"):
+        mv = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=LIB_DTYPE.get(dt, dt), device=device)
+        pv2 = [torch.empty((B, 2), dtype=torch.float32, device=device) for _ in range(2)]
+        side = [torch.cuda.Stream(device=device) for _ in range(2)]
+        turn = [0]
+
+        def two():
+            k = turn[0] = turn[0] ^ 1
+            with torch.cuda.stream(side[k]):
+                mv.classify_raw(sig, off, ln, lens, out=pv2[k])
+        for st_ in side:
+            st_.wait_stream(torch.cuda.current_stream(device))
+        dt2 = timed(two)
+        for st_ in side:
+            torch.cuda.current_stream(device).wait_stream(st_)
+        variants["two_batches_in_flight_" + dt] = {"chunks_per_s": round(B / dt2, 1), "ms_per_step": round(dt2 * 1e3, 4),
+                                                   "batch": B, "streams": 2, **versus_ref(pv2[0].cpu().numpy())}
         mv.close()
     # BASELINE config 3: three-model ensemble, normalise once + three forwards + decision on the device
     for dt in ("bf16x3", "bf16"):

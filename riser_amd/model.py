@@ -25,17 +25,23 @@ def _stream_ptr(device) -> int:
 
 
 class Workspace:
-    """Grow-only device scratch owned by the caller side of the ABI."""
+    """Grow-only device scratch owned by the caller side of the ABI: ONE BUFFER PER STREAM, so that calls issued on
+    different HIP streams (two batches in flight: stream.classify_resident) never share activations.  Keyed by the
+    stream that is current when the call is made; a library call only ever touches the workspace it is handed."""
 
     def __init__(self, device):
         self.device = device
-        self.buf = None
+        self._bufs = {}
 
     def get(self, nbytes: int) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < nbytes:
-            self.buf = None
-            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self.buf
+        key = _stream_ptr(self.device)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            self._bufs[key] = None
+            with torch.cuda.stream(torch.cuda.current_stream(self.device)):
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._bufs[key] = buf
+        return buf
 
 
 class Model:

@@ -418,6 +418,8 @@ def test_promethion_per_gpu_shape(dev):
     idx = np.arange(N)
     sig = torch.from_numpy(np.ascontiguousarray(base[idx % 512].reshape(-1))).to(dev)
     probs = classify_resident([m], sig, N, L, None, SUB).cpu().numpy()
+    # two sub-batches in flight on two HIP streams (per-stream workspaces): the same bits
+    assert np.array_equal(probs, classify_resident([m], sig, N, L, None, SUB, streams=2).cpu().numpy())
     assert probs.shape == (1, N, 2) and np.isfinite(probs).all()
     p = probs[0]
     assert np.array_equal(p, p[idx % 512]), "a read's result depends on its position in the population"

@@ -1,41 +1,33 @@
-"""Probe: one 512-read batch as two concurrent half batches on two HIP streams (two Model instances = two workspaces)
-against the single-stream step.  python tools/two_stream_probe.py [dtype] [parts]"""
-import sys, os, time
+#!/usr/bin/env python3
+"""Throughput with TWO batches in flight (two HIP streams, two model handles = two workspaces) against one:
+    python tools/two_stream_probe.py [dtype ...]      (default f32w f16 bf16x3)
+Each call is a full 512 x 16000 rs_classify; nothing is shared between the two streams but the device."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from riser_amd import synth
 from riser_amd.model import Model
 from riser_amd.preprocess import pack_reads
-dt = sys.argv[1] if len(sys.argv) > 1 else "f32w"
-parts = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-B, L = 512, 16000
+B, L = int(os.environ.get("RS_B", 512)), 16000
 dev = torch.device("cuda", 0)
 sigs = synth.make_signals(20260103, B, L)
 sig, off, ln, lens = pack_reads(list(sigs), dev)
-models = [Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dt) for _ in range(parts)]
-streams = [torch.cuda.Stream(dev) for _ in range(parts)]
-probs = torch.empty((B, 2), dtype=torch.float32, device=dev)
-cuts = [B * i // parts for i in range(parts + 1)]
-offs = [off[cuts[i]:cuts[i + 1]].contiguous() for i in range(parts)]
-lns = [ln[cuts[i]:cuts[i + 1]].contiguous() for i in range(parts)]
-
-def single():
-    models[0].classify_raw(sig, off, ln, lens, out=probs)
-
-def split():
-    for i in range(parts):
-        with torch.cuda.stream(streams[i]):
-            models[i].classify_raw(sig, offs[i], lns[i], lens[cuts[i]:cuts[i + 1]], out=probs[cuts[i]:cuts[i + 1]])
-
-def timeit(fn, n=30):
-    for _ in range(5): fn()
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(n): fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t) / n * 1e3
-
-single(); torch.cuda.synchronize(); ref = probs.cpu().numpy().copy()
-split(); torch.cuda.synchronize(); print("bit-identical:", np.array_equal(ref, probs.cpu().numpy()))
-for k in range(2):
-    print("single %.3f ms   %d-way split on %d streams %.3f ms" % (timeit(single), parts, parts, timeit(split)))
+for dt in (sys.argv[1:] or ["f32w", "f16", "bf16x3"]):
+    ms = [Model(synth.make_state_dict(1), synth.Config(), None, "m", dtype=dt, device=dev) for _ in range(2)]
+    outs = [torch.empty((B, 2), device=dev) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    def run(n_streams, steps):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for k in range(steps):
+            j = k % n_streams
+            with torch.cuda.stream(streams[j]):
+                ms[j].classify_raw(sig, off, ln, lens, out=outs[j])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / steps
+    for n in (1, 2): run(n, 30)
+    t1, t2 = run(1, 100), run(2, 100)
+    ref = outs[0].clone()
+    print("%-7s one stream %.4f ms/step = %.0f chunks/s; two streams %.4f ms/step = %.0f chunks/s (x%.3f); results equal: %s" % (
+        dt, t1 * 1e3, B / t1, t2 * 1e3, B / t2, t1 / t2, bool(torch.equal(outs[0], outs[1]))))
+    for m in ms: m.close()
