@@ -21,6 +21,12 @@
  *     riser/client.py:47 (np.frombuffer(read.raw_data, signal_dtype)).
  *   - a batch is B reads; read b is the `d_len[b]` samples starting at element
  *     `d_off[b]` of `d_sig` (so a trim is just an offset: riser/preprocess.py:100,105).
+ *   - `h_len` (rs_forward / rs_classify / rs_classify_ensemble / rs_autotune) is the HOST's copy of d_len, or NULL.
+ *     With it the conv stack lays the batch out in packed blocks (each read occupies len / U + 1 blocks of
+ *     U = rs_block_samples() samples, work proportional to every read's own length) - the host needs the block count to
+ *     size the launches; without it every read takes the blocks of an Lmax-sample read.  Results are bit-identical
+ *     either way.  It must mirror d_len: a device length that disagrees can only cost that read its result (NaN
+ *     probabilities), never a write outside the workspace.
  *   - reads shorter than 2^n_layers samples (4096 for the shipped 12-layer net,
  *     riser/preprocess.py:8) cannot be classified: RS_ERR_LENGTH, matching the
  *     RuntimeError torch raises in max_pool1d for the reference.
@@ -101,8 +107,17 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes,
 int rs_model_destroy(rs_model* m);
 
 /* Bytes of device workspace rs_forward / rs_classify need for a batch of B reads of at
- * most Lmax samples (0 on bad arguments). */
+ * most Lmax samples (0 on bad arguments): the block table, the normalised signals and two activation buffers. */
 size_t rs_workspace_bytes(const rs_model* m, int B, int Lmax);
+
+/* Largest B one call accepts for reads of up to Lmax samples: every activation buffer is addressed through a 2 GiB
+ * buffer-resource window (32-bit offsets, hardware bounds checking).  Reads are independent: split bigger batches. */
+int rs_max_batch(const rs_model* m, int Lmax);
+
+/* Block size U of the packed activation layout in samples: 2^n_layers (4096 for the shipped net; doubled when
+ * RS_WINO4 puts the last layer on the F(4,3) lowering).  Read b of a batch starts at sample U * sum_{i<b}(len_i / U + 1)
+ * of the normalised-signal region and at row (that >> (layer + 1)) of conv layer `layer`'s output buffer. */
+int rs_block_samples(const rs_model* m);
 
 /*
  * MAD normalisation + outlier smoothing of B reads.
@@ -137,21 +152,18 @@ int rs_normalise_float(const void* d_sig, int elem_bytes, const int64_t* d_off, 
  * Forward pass + softmax on already normalised fp32 signals.
  * Replaces Model.classify (riser/model.py:22-28) -> ConvNet.forward
  * (riser/nets/cnn.py:43-65) for a batch: B independent reads of individual length.
- *   d_x       fp32 [B, ldx]; row b holds d_len[b] samples followed by zeros up to
- *             the padded pitch returned by rs_padded_length(m, Lmax) (<= ldx)
+ *   d_x       fp32 [B, ldx]; row b holds d_len[b] samples (what follows them is not read)
+ *   h_len     host copy of d_len or NULL (see the conventions above)
  *   d_probs   fp32 [B, 2] = (p_off_target, p_on_target), the order of riser/control.py:69
  *   d_logits  fp32 [B, 2] or NULL
- *   Lmin      host-known lower bound of d_len (0 if unknown).  Only a speed hint: reads are laid
- *             out in slots of rs_padded_length(Lmax) rows and tiles that fall entirely into a
- *             shorter read's padding are skipped; when Lmin says no such tile can exist the
- *             per-tile test is not even compiled into the walk.
+ *   Lmin      host-known lower bound of d_len (0 if unknown; ignored when h_len is given).  Only a speed hint:
+ *             tiles that fall entirely into the padding behind a read are skipped; when Lmin says no such tile
+ *             can exist the per-tile test is not even compiled into the walk.
  */
-int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmin, int Lmax,
-               void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream);
+int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, const int32_t* h_len, int B, int Lmin,
+               int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream);
 
-/* Row pitch (in samples) the conv stack uses for reads of at most Lmax samples: the smallest multiple of
- * 2^n_layers (2^(n_layers + 1) when the last layer runs the F(4,3) lowering, as in the default fp32 mode of the
- * shipped net) that is >= Lmax + 1.  rs_normalise's pad_to. */
+/* Samples a read of Lmax samples occupies in the packed layout: (Lmax / U + 1) * U, U = rs_block_samples(). */
 int rs_padded_length(const rs_model* m, int Lmax);
 
 /*
@@ -159,7 +171,7 @@ int rs_padded_length(const rs_model* m, int Lmax);
  * Equivalent to the pair of calls at riser/control.py:63 and :69 for every read of the
  * batch; the normalised signals live in the workspace.
  */
-int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len,
+int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, const int32_t* h_len,
                 int B, int Lmin, int Lmax, void* d_ws, size_t ws_bytes,
                 float* d_probs, float* d_logits, void* stream);
 
@@ -168,13 +180,13 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
  * Runs rs_classify on the given batch and, for every conv layer that runs a tiled kernel, times each feasible
  * entry of that kernel's tile-shape table in place (HIP events on `stream`, which is synchronised repeatedly);
  * a shape more than 3 % faster than the launch planner's choice is remembered for launches with the same number of
- * rows (B x padded length) of that layer.  Results are bit-identical whatever shape runs (the accumulation order
+ * rows (blocks x block length) of that layer.  Results are bit-identical whatever shape runs (the accumulation order
  * over channels does not depend on the tile shape; 16-bit: on the panel width it does, within fp32 round-off).
  * d_probs receives the batch's probabilities as rs_classify would produce them; *n_changed (optional) the number
  * of layers whose choice changed.  Costs a few hundred launches: call once per deployment batch size, not per batch.
  */
-int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmin,
-                int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, int32_t* n_changed, void* stream);
+int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, const int32_t* h_len, int B,
+                int Lmin, int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, int32_t* n_changed, void* stream);
 
 /*
  * Ensemble form of rs_classify: the model loop of riser/control.py:68-71 for a whole batch.
@@ -187,8 +199,8 @@ int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
  * The workspace is shared by the models: rs_workspace_bytes(models[0], B, Lmax).
  */
 int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d_sig, const int64_t* d_off,
-                         const int32_t* d_len, int B, int Lmin, int Lmax, void* d_ws, size_t ws_bytes,
-                         float* d_probs, uint8_t* d_decision, int max_len, float threshold, int mode,
+                         const int32_t* d_len, const int32_t* h_len, int B, int Lmin, int Lmax, void* d_ws,
+                         size_t ws_bytes, float* d_probs, uint8_t* d_decision, int max_len, float threshold, int mode,
                          void* stream);
 
 /*
@@ -251,7 +263,8 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x /* fp32 [B, L] */, int B, i
 
 /*
  * Test hook: every following forward pass of `m` also copies the output buffer of conv layer `layer`
- * (1 <= layer < n_layers; position-major [B * (P0 >> (layer + 1)), cp_out], fp32 or 16-bit) into d_dst
+ * (1 <= layer < n_layers; position-major [NB * (U >> (layer + 1)), cp_out] in the packed block layout - see
+ * rs_block_samples - fp32 or 16-bit) into d_dst
  * (at most `bytes`).  d_dst = NULL switches it off.  Used by the layer-wise parity tests.
  */
 int rs_debug_capture_layer(rs_model* m, int layer, void* d_dst, size_t bytes);

@@ -20,7 +20,7 @@ DECISION_NAMES = ("try_again", "accept", "reject", "no_decision")
 # every symbol include/riser_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = (
     "rs_last_error", "rs_version", "rs_device_count", "rs_model_create", "rs_model_destroy",
-    "rs_workspace_bytes", "rs_normalise", "rs_normalise_float", "rs_forward", "rs_padded_length", "rs_classify",
+    "rs_workspace_bytes", "rs_max_batch", "rs_block_samples", "rs_normalise", "rs_normalise_float", "rs_forward", "rs_padded_length", "rs_classify",
     "rs_classify_ensemble", "rs_autotune", "rs_decide", "rs_polya_end", "rs_model_layer_info", "rs_profile_enable", "rs_profile_read",
     "rs_debug_capture_layer",
     "rs_seqnet_create", "rs_seqnet_destroy", "rs_seqnet_workspace_bytes", "rs_seqnet_forward",
@@ -70,18 +70,22 @@ def lib():
     L.rs_workspace_bytes.argtypes = [vp, i32, i32]
     L.rs_padded_length.restype = i32
     L.rs_padded_length.argtypes = [vp, i32]
+    L.rs_max_batch.restype = i32
+    L.rs_max_batch.argtypes = [vp, i32]
+    L.rs_block_samples.restype = i32
+    L.rs_block_samples.argtypes = [vp]
     L.rs_normalise.restype = i32
     L.rs_normalise.argtypes = [vp, vp, vp, i32, i32, vp, i64, C.c_int32, vp, i64, vp, vp]
     L.rs_normalise_float.restype = i32
     L.rs_normalise_float.argtypes = [vp, i32, vp, vp, i32, vp, i64, vp, vp]
     L.rs_forward.restype = i32
-    L.rs_forward.argtypes = [vp, vp, i64, vp, i32, i32, i32, vp, sz, vp, vp, vp]
+    L.rs_forward.argtypes = [vp, vp, i64, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp]
     L.rs_classify.restype = i32
-    L.rs_classify.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp]
+    L.rs_classify.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, vp]
     L.rs_autotune.restype = i32
-    L.rs_autotune.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, C.POINTER(C.c_int32), vp]
+    L.rs_autotune.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, C.POINTER(C.c_int32), vp]
     L.rs_classify_ensemble.restype = i32
-    L.rs_classify_ensemble.argtypes = [C.POINTER(vp), i32, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, i32, C.c_float,
+    L.rs_classify_ensemble.argtypes = [C.POINTER(vp), i32, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, i32, C.c_float,
                                        i32, vp]
     L.rs_decide.restype = i32
     L.rs_decide.argtypes = [vp, i32, i32, vp, i32, C.c_float, i32, vp, vp]

@@ -184,7 +184,7 @@ ConvPlan plan_static_wino4(int cp_in, int c_out, int layer, int num_cu) {
 // epilogue), plus narrower layers whose output channels fill the 80-wide F(4,3) tile exactly (16 * 5 | padded
 // C_out: layer 3 of the shipped net, 45 -> 67 channels, measured -8 %).  RS_WINO4 = comma list of layer indices
 // overrides it when the model is created ("none" = F(2,3) everywhere).
-bool use_wino4(int layer, int c_in, int c_out) {
+bool use_wino4(int layer, int n_layers, int c_in, int c_out) {
     if (const char* e = getenv("RS_WINO4")) {
         for (const char* q = e; *q;) {
             char* end = nullptr;
@@ -195,29 +195,85 @@ bool use_wino4(int layer, int c_in, int c_out) {
         }
         return false;
     }
+    // F(4,3) groups four input rows: every read must start on a group boundary in such a layer (see pad_shift in
+    // rs_model_create), i.e. blocks of 2^(layer + 2) samples.  The last layer would double the block size of the packed
+    // layout (2^13 samples for the 12-layer net: an 8615-sample read would occupy 16384) for ~5 % of that layer's time,
+    // so it stays on F(2,3) unless RS_WINO4 names it.
+    if (layer + 2 > n_layers) return false;
     return c_in >= 96 || (c_in >= 32 && (round_up(c_out, 16) / 16) % 5 == 0);
 }
 
+// Workspace: [block table][16 zero bytes | normalised signals, NB blocks of U floats][activation buffer A][B].
+// Laid out for the upper bound NB = B * (Lmax / U + 1) blocks, so the offsets depend on (B, Lmax) only; a batch of
+// mixed lengths uses a prefix of every region.
 struct WsLayout {
-    size_t xnorm_off, bufa_off, bufb_off, total;
-    int P0;
+    size_t rbase_off, blen_off, bread_off, xnorm_off, bufa_off, bufb_off, total;
+    int U;                  // block size in samples (1 << pad_shift)
+    int nblk_max;           // blocks of a read of Lmax samples
+    int64_t nb_max;         // B * nblk_max
 };
 
 WsLayout ws_layout(const rs_model* m, int B, int Lmax) {
     WsLayout w{};
-    const int unit = 1 << m->pad_shift;
-    w.P0 = round_up(Lmax + 1, unit);
+    w.U = 1 << m->pad_shift;
+    w.nblk_max = (Lmax >> m->pad_shift) + 1;
+    w.nb_max = (int64_t)B * w.nblk_max;
     size_t buf = 0;
     for (int i = 0; i < m->n_layers; ++i) {
-        const size_t rows = (size_t)B * (w.P0 >> (i + 1));
+        const size_t rows = (size_t)w.nb_max * (w.U >> (i + 1));
         buf = std::max(buf, rows * m->cp[i] * esize(m));
     }
     buf = align_up(buf + kAlign);
-    w.xnorm_off = kAlign;                                   // the last 16 bytes before the rows are a zero prefix
-    w.bufa_off = align_up(w.xnorm_off + (size_t)B * w.P0 * sizeof(float));
+    w.rbase_off = 0;
+    w.blen_off = align_up((size_t)(B + 1) * 4);
+    w.bread_off = w.blen_off + align_up((size_t)w.nb_max * 4);
+    w.xnorm_off = w.bread_off + align_up((size_t)w.nb_max * 4) + kAlign;   // the last 16 bytes before the rows are a zero prefix
+    w.bufa_off = align_up(w.xnorm_off + (size_t)w.nb_max * w.U * sizeof(float));
     w.bufb_off = w.bufa_off + buf;
     w.total = w.bufb_off + buf;
     return w;
+}
+
+// What one call runs on: the block table in the workspace and the number of blocks in use (host-known: from the host's
+// copy of the lengths, or nblk_max blocks for every read when it has none)
+struct Batch {
+    BlockPlan plan;
+    int NB = 0;             // blocks in use
+    int Lmin_blk = 0;       // lower bound of blen over the blocks (dead-tile hint), 0 = unknown
+};
+
+// h_len may be NULL.  Returns RS_OK or RS_ERR_LENGTH (a host length outside [2^n_layers, Lmax]).
+int make_batch(const rs_model* m, const WsLayout& w, void* d_ws, const int32_t* h_len, int B, int Lmin, int Lmax, Batch* out) {
+    char* ws = static_cast<char*>(d_ws);
+    Batch bt;
+    bt.plan.rbase = reinterpret_cast<int32_t*>(ws + w.rbase_off);
+    bt.plan.blen = reinterpret_cast<int32_t*>(ws + w.blen_off);
+    bt.plan.bread = reinterpret_cast<int32_t*>(ws + w.bread_off);
+    bt.plan.shift = m->pad_shift;
+    if (h_len) {
+        int64_t nb = 0;
+        int lmin_blk = w.U;
+        for (int b = 0; b < B; ++b) {
+            const int n = h_len[b];
+            if (n < (1 << m->n_layers) || n > Lmax) {
+                set_error("read %d has %d samples, outside [%d, Lmax = %d]", b, n, 1 << m->n_layers, Lmax);
+                return RS_ERR_LENGTH;
+            }
+            nb += (n >> m->pad_shift) + 1;
+            lmin_blk = std::min(lmin_blk, n & (w.U - 1));            // the read's last block holds len mod U samples
+        }
+        bt.plan.uniform_nblk = 0;
+        bt.NB = (int)nb;
+        bt.Lmin_blk = lmin_blk;
+    } else {
+        bt.plan.uniform_nblk = w.nblk_max;
+        bt.NB = (int)w.nb_max;
+        // every read has nblk_max blocks: the last one of the shortest read holds max(Lmin - (nblk_max - 1) U, 0) samples
+        bt.Lmin_blk = Lmin > 0 ? std::max(0, std::min(w.U, Lmin - (w.nblk_max - 1) * w.U)) : 0;
+    }
+    bt.plan.nb_total = bt.NB;
+    *out = bt;
+    return RS_OK;
 }
 
 // record an event tagged `stage` (-1 opens a call) on the stream, if profiling is on
@@ -269,7 +325,7 @@ extern "C" {
 
 const char* rs_last_error(void) { return g_err; }
 
-int rs_version(void) { return (1 << 16) | 0; }
+int rs_version(void) { return (2 << 16) | 0; }
 
 int rs_device_count(void) {
     int n = 0;
@@ -357,7 +413,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             float* dw = nullptr;
             rc = upload(&dw, wp);
             L.d_w = dw;
-        } else if (dtype == RS_F32W && use_wino4(i, L.c_in, L.c_out)) {
+        } else if (dtype == RS_F32W && use_wino4(i, n_layers, L.c_in, L.c_out)) {
             // Winograd F(4,3) filter transform U = G g (fp64, rounded once); packed [n_alloc][nch][6][kc]
             L.wino_m = 4;
             L.plan = plan_static_wino4(L.cp_in, L.c_out, i, m->num_cu);
@@ -491,7 +547,18 @@ int rs_model_destroy(rs_model* m) {
 
 int rs_padded_length(const rs_model* m, int Lmax) {
     if (!m || Lmax < 1) return 0;
-    return round_up(Lmax + 1, 1 << m->pad_shift);
+    return ((Lmax >> m->pad_shift) + 1) << m->pad_shift;
+}
+
+int rs_block_samples(const rs_model* m) { return m ? 1 << m->pad_shift : 0; }
+
+int rs_max_batch(const rs_model* m, int Lmax) {
+    if (!m || Lmax < 1) return 0;
+    // every activation buffer (and the normalised signals) is addressed through a 2 GiB buffer-resource window
+    const int64_t U = 1 << m->pad_shift, nblk = (Lmax >> m->pad_shift) + 1;
+    int64_t per_block = U * 4;
+    for (int i = 0; i < m->n_layers; ++i) per_block = std::max<int64_t>(per_block, (U >> (i + 1)) * m->cp[i] * esize(m));
+    return (int)std::max<int64_t>(1, ((1LL << 31) - (1 << 16)) / (per_block * nblk));
 }
 
 size_t rs_workspace_bytes(const rs_model* m, int B, int Lmax) {
@@ -526,17 +593,23 @@ int rs_normalise_float(const void* d_sig, int elem_bytes, const int64_t* d_off, 
     return launch_normalise_float(d_sig, elem_bytes, d_off, d_len, B, d_out, ld, d_stats, static_cast<hipStream_t>(stream));
 }
 
-static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmin, int Lmax,
-                        void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream, bool zero_prefix);
+static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, const Batch& bt,
+                        const WsLayout& w, void* d_ws, float* d_probs, float* d_logits, void* stream, bool packed_x);
 
-int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmin, int Lmax,
-               void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream) {
-    return forward_impl(m, d_x, ldx, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs, d_logits, stream, false);
+static int check_call(const char* who, const rs_model* m, int B, int Lmax, const WsLayout& w, size_t ws_bytes) {
+    if (ws_bytes < w.total) {
+        set_error("%s: workspace %zu < required %zu", who, ws_bytes, w.total);
+        return RS_ERR_WORKSPACE;
+    }
+    if (w.nb_max * (w.U / 2) > 0x7fffffffLL) {
+        set_error("%s: batch too large, split it (%d reads of up to %d samples)", who, B, Lmax);
+        return RS_ERR_ARG;
+    }
+    return RS_OK;
 }
 
-// zero_prefix: d_x[-4 .. -1] are readable zeros and the rows sit at the padded pitch (rs_classify's layout)
-static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, int Lmin, int Lmax,
-                        void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream, bool zero_prefix) {
+int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, const int32_t* h_len, int B, int Lmin,
+               int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream) {
     if (!m || !d_x || !d_len || !d_ws || !d_probs || B < 1) {
         set_error("rs_forward: null argument or empty batch");
         return RS_ERR_ARG;
@@ -550,43 +623,54 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         return RS_ERR_ARG;
     }
     const WsLayout w = ws_layout(m, B, Lmax);
-    if (ws_bytes < w.total) {
-        set_error("rs_forward: workspace %zu < required %zu", ws_bytes, w.total);
-        return RS_ERR_WORKSPACE;
-    }
-    if ((int64_t)B * w.P0 / 2 > 0x7fffffffLL) {
-        set_error("rs_forward: batch too large, split it (B * pitch = %lld)", (long long)B * w.P0);
-        return RS_ERR_ARG;
-    }
+    int rc = check_call("rs_forward", m, B, Lmax, w, ws_bytes);
+    if (rc != RS_OK) return rc;
+    Batch bt;
+    rc = make_batch(m, w, d_ws, h_len, B, Lmin, Lmax, &bt);
+    if (rc != RS_OK) return rc;
     DeviceGuard guard(m->device);         // launches go to the model's device whatever the caller's current one is
     RS_HIP(guard.err);
+    if (!m->prof_open) prof_mark(m, -1, static_cast<hipStream_t>(stream));
+    rc = launch_plan(d_len, B, Lmax, bt.plan, static_cast<hipStream_t>(stream));
+    if (rc != RS_OK) return rc;
+    return forward_impl(m, d_x, ldx, d_len, B, bt, w, d_ws, d_probs, d_logits, stream, false);
+}
+
+// The conv stack + head on a planned batch.  packed_x: d_x is the workspace's own normalised-signal region in the packed
+// block layout behind 16 zero bytes (rs_classify); otherwise rows of ldx floats, one per read (rs_forward).
+static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, int B, const Batch& bt,
+                        const WsLayout& w, void* d_ws, float* d_probs, float* d_logits, void* stream, bool packed_x) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(d_ws);
     void* buf[2] = {ws + w.bufa_off, ws + w.bufb_off};
+    // from here on the kernels see NB blocks of U samples as NB reads in slots of U (common.hpp: BlockPlan)
+    const int NB = bt.NB, U = w.U;
+    const int32_t* d_blen = bt.plan.blen;
+    const int Lmin = bt.Lmin_blk;
 
-    if (!m->prof_open) prof_mark(m, -1, st);
     // Winograd fp32 path: ConvNet layer 0 (one input channel) is folded into the staging of layer 1
-    // when the signal rows are laid out at the padded pitch (always true via rs_classify)
-    const bool fuse0 = zero_prefix && m->dtype == RS_F32W && ldx == w.P0 && conv_wino_can_fuse0(m->layers[1], w.P0 >> 1);
+    // when the signal rows are in the packed layout (always true via rs_classify)
+    const bool fuse0 = packed_x && m->dtype == RS_F32W && conv_wino_can_fuse0(m->layers[1], U >> 1);
     // 16-bit paths: the narrow layers 1 and 2 run the per-wave streaming kernel; on the rs_classify path
     // layer 0 is folded into layer 1 there as well ("fused preprocess + conv")
     const bool x3 = is_x3(m->dtype);
     const bool is16 = m->dtype == RS_BF16 || m->dtype == RS_F16;          // plain 16-bit
     const bool f16 = is_f16_family(m->dtype);
-    const bool fuse0h = (is16 || x3) && zero_prefix && ldx == w.P0 && m->channels[0] <= 32 &&
-                        conv_stream_h16_ok(m->layers[1], w.P0 >> 1);
+    const bool fuse0h = (is16 || x3) && packed_x && m->channels[0] <= 32 && conv_stream_h16_ok(m->layers[1], U >> 1);
     int rc = RS_OK;
-    if (!fuse0 && !fuse0h) rc = launch_conv0(d_x, ldx, d_len, B, w.P0, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
+    // unfused layer 0: ldx < 0 tells the kernel that read b's samples start at block rbase[b] of d_x
+    if (!fuse0 && !fuse0h)
+        rc = launch_conv0(d_x, packed_x ? -1 : ldx, d_len, bt.plan, NB, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
     if (rc != RS_OK) return rc;
     prof_mark(m, 1, st);
     int cur = 0;
     for (int i = 1; i < m->n_layers; ++i) {
         ConvLayerDev& L = m->layers[i];
-        const int P_in = w.P0 >> i;
+        const int P_in = U >> i;
         if (i == 1 && fuse0h && m->n_layers > 2 && !(m->dbg_dst && m->dbg_layer <= 2) &&
             conv_stream012_h16_ok(L, m->layers[2], m->channels[0], P_in)) {
             // layers 0 + 1 + 2 of the 16-bit modes in one streaming kernel; its output takes the place of layer 2's
-            rc = launch_conv_stream012_h16(L, m->layers[2], d_x, m->d_w0, m->channels[0], buf[cur], d_len, B, P_in, m->num_cu,
+            rc = launch_conv_stream012_h16(L, m->layers[2], d_x, m->d_w0, m->channels[0], buf[cur], d_blen, NB, P_in, m->num_cu,
                                            f16, x3, st);
             if (rc != RS_OK) return rc;
             for (int k = 1; k <= 2; ++k) {
@@ -598,9 +682,9 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
             i = 2;
             continue;
         }
-        // a tile of >= 64 rows can only be all padding if some read leaves >= 64 rows of its slot
-        // unused at this layer; Lmin == 0 means "unknown": keep the test
-        const int check_dead = (Lmin <= 0 || (w.P0 >> i) - (Lmin >> i) >= 64) ? 1 : 0;
+        // a tile of >= 64 rows can only be all padding if some block leaves >= 64 rows unused at this layer;
+        // Lmin == 0 means "unknown": keep the test
+        const int check_dead = (Lmin <= 0 || (U >> i) - (Lmin >> i) >= 64) ? 1 : 0;
         // kind of kernel this layer runs: 0 streaming (not tuned), 1 F(4,3), 2 F(2,3), 3 direct fp32, 4 tiled 16-bit
         const bool stream32 = m->dtype == RS_F32W && fuse0 && i == 1 && conv_stream_f32_ok(L, m->channels[0], P_in);
         const bool stream16 = (is16 || x3) && i <= 2 && conv_stream_h16_ok(L, P_in);
@@ -611,38 +695,32 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         m->last_ring[i] = ring;
         auto launch_layer = [&]() -> int {
             int rc;
-            if (m->dtype == RS_F32W && fuse0 && i == 1 && conv_stream_f32_ok(L, m->channels[0], P_in)) {
-                rc = launch_conv_stream_f32(L, d_x, m->d_w0, m->channels[0], static_cast<float*>(buf[cur ^ 1]), d_len, B, P_in,
+            if (stream32) {
+                rc = launch_conv_stream_f32(L, d_x, m->d_w0, m->channels[0], static_cast<float*>(buf[cur ^ 1]), d_blen, NB, P_in,
                                             m->num_cu, st);
                 m->last_bm[i] = 32;
                 m->last_bn[i] = round_up(L.c_out, 16);
             } else if (m->dtype == RS_F32W && L.wino_m == 4)
-                rc = launch_conv_wino4(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len, B,
+                rc = launch_conv_wino4(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_blen, NB,
                                        P_in, i, m->num_cu, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
             else if (m->dtype == RS_F32W)
-                rc = launch_conv_wino(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
-                                      B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i],
+                rc = launch_conv_wino(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_blen,
+                                      NB, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i],
                                       (fuse0 && i == 1) ? d_x : nullptr, m->d_w0);
             else if (m->dtype == RS_F32)
-                rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_len,
-                                     B, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
+                rc = launch_conv_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_blen,
+                                     NB, P_in, i, m->num_cu, m->d_zero, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
             else if (stream16) {
                 const bool f0 = fuse0h && i == 1;
-                rc = launch_conv_stream_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, f16, st,
+                rc = launch_conv_stream_h16(L, buf[cur], buf[cur ^ 1], d_blen, NB, P_in, i, m->num_cu, f16, st,
                                             f0 ? d_x : nullptr, m->d_w0, m->channels[0], x3);
                 m->last_bm[i] = 16;
                 m->last_bn[i] = round_up(L.c_out, 16);
             } else if (ring)
-                rc = launch_conv_ring_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, f16, x3, check_dead, st,
+                rc = launch_conv_ring_h16(L, buf[cur], buf[cur ^ 1], d_blen, NB, P_in, i, m->num_cu, f16, x3, check_dead, st,
                                           &m->last_bm[i], &m->last_bn[i]);
-            else if (is16 && i <= 2 && conv_stream_h16_ok(L, P_in)) {
-                const bool f0 = fuse0h && i == 1;
-                rc = launch_conv_stream_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, f16, st,
-                                            f0 ? d_x : nullptr, m->d_w0, m->channels[0]);
-                m->last_bm[i] = 16;
-                m->last_bn[i] = round_up(L.c_out, 16);
-            } else
-                rc = launch_conv_h16(L, buf[cur], buf[cur ^ 1], d_len, B, P_in, i, m->num_cu, m->d_zero,
+            else
+                rc = launch_conv_h16(L, buf[cur], buf[cur ^ 1], d_blen, NB, P_in, i, m->num_cu, m->d_zero,
                                      f16, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
             return rc;
         };
@@ -669,7 +747,7 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                 L.force_shape = -1;
                 return r;
             };
-            const int64_t rows = (int64_t)B * P_in;
+            const int64_t rows = (int64_t)NB * P_in;
             for (size_t t = 0; t < L.tuned.size(); ++t)                       // re-tuning a geometry: forget the old entry
                 if (L.tuned[t].first == rows) L.tuned.erase(L.tuned.begin() + t--);
             float base_ms = 0.f, best_ms = 1e30f;
@@ -696,19 +774,26 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         if (rc != RS_OK) return rc;
         prof_mark(m, 1 + i, st);
         if (m->dbg_dst && m->dbg_layer == i) {
-            const size_t nb = std::min(m->dbg_bytes, (size_t)B * (P_in / 2) * L.cp_out * esize(m));
+            const size_t nb = std::min(m->dbg_bytes, (size_t)NB * (P_in / 2) * L.cp_out * esize(m));
             RS_HIP(hipMemcpyAsync(m->dbg_dst, buf[cur ^ 1], nb, hipMemcpyDeviceToDevice, st));
         }
         cur ^= 1;
     }
     rc = launch_head(buf[cur], act_dtype(m), m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
-                     w.P0 >> m->n_layers, m->n_layers, d_len, B, m->d_fcw, m->d_fcb, d_probs, d_logits, st);
+                     U >> m->n_layers, m->n_layers, d_len, B, bt.plan, m->d_fcw, m->d_fcb, d_probs, d_logits, st);
     if (rc == RS_OK) prof_mark(m, m->n_layers + 1, st);
     return rc;
 }
 
-int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmin,
-                int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream) {
+// normalise + block plan of one batch into the workspace (the first launch of rs_classify / rs_classify_ensemble)
+static int normalise_packed(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
+                            const WsLayout& w, const Batch& bt, void* d_ws, hipStream_t st) {
+    float* xn = reinterpret_cast<float*>(static_cast<char*>(d_ws) + w.xnorm_off);
+    return launch_normalise(d_sig, d_off, d_len, B, Lmax, xn, 0, 0, nullptr, 0, nullptr, st, /*zero_prefix=*/1, &bt.plan);
+}
+
+int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, const int32_t* h_len, int B,
+                int Lmin, int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream) {
     if (!m || !d_sig || !d_off || !d_len || !d_ws || !d_probs || B < 1) {
         set_error("rs_classify: null argument or empty batch");
         return RS_ERR_ARG;
@@ -718,23 +803,24 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
         return RS_ERR_LENGTH;
     }
     const WsLayout w = ws_layout(m, B, Lmax);
-    if (ws_bytes < w.total) {
-        set_error("rs_classify: workspace %zu < required %zu", ws_bytes, w.total);
-        return RS_ERR_WORKSPACE;
-    }
+    int rc = check_call("rs_classify", m, B, Lmax, w, ws_bytes);
+    if (rc != RS_OK) return rc;
+    Batch bt;
+    rc = make_batch(m, w, d_ws, h_len, B, Lmin, Lmax, &bt);
+    if (rc != RS_OK) return rc;
     DeviceGuard guard(m->device);
     RS_HIP(guard.err);
-    float* xn = reinterpret_cast<float*>(static_cast<char*>(d_ws) + w.xnorm_off);
-    prof_mark(m, -1, static_cast<hipStream_t>(stream));
-    int rc = launch_normalise(d_sig, d_off, d_len, B, Lmax, xn, w.P0, w.P0, nullptr, 0, nullptr,
-                              static_cast<hipStream_t>(stream), /*zero_prefix=*/1);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    prof_mark(m, -1, st);
+    rc = normalise_packed(m, d_sig, d_off, d_len, B, Lmax, w, bt, d_ws, st);
     if (rc != RS_OK) return rc;
-    prof_mark(m, 0, static_cast<hipStream_t>(stream));
-    return forward_impl(m, xn, w.P0, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs, d_logits, stream, true);
+    prof_mark(m, 0, st);
+    const float* xn = reinterpret_cast<const float*>(static_cast<char*>(d_ws) + w.xnorm_off);
+    return forward_impl(m, xn, w.U, d_len, B, bt, w, d_ws, d_probs, d_logits, stream, true);
 }
 
-int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmin,
-                int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, int32_t* n_changed, void* stream) {
+int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, const int32_t* h_len, int B,
+                int Lmin, int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, int32_t* n_changed, void* stream) {
     if (!m) {
         set_error("rs_autotune: null model");
         return RS_ERR_ARG;
@@ -743,7 +829,7 @@ int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
     m->prof_on = false;
     m->tuning = true;
     m->tuned_changed = 0;
-    const int rc = rs_classify(m, d_sig, d_off, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs, nullptr, stream);
+    const int rc = rs_classify(m, d_sig, d_off, d_len, h_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs, nullptr, stream);
     m->tuning = false;
     m->prof_on = prof;
     if (n_changed) *n_changed = m->tuned_changed;
@@ -751,8 +837,8 @@ int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
 }
 
 int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d_sig, const int64_t* d_off,
-                         const int32_t* d_len, int B, int Lmin, int Lmax, void* d_ws, size_t ws_bytes, float* d_probs,
-                         uint8_t* d_decision, int max_len, float threshold, int mode, void* stream) {
+                         const int32_t* d_len, const int32_t* h_len, int B, int Lmin, int Lmax, void* d_ws, size_t ws_bytes,
+                         float* d_probs, uint8_t* d_decision, int max_len, float threshold, int mode, void* stream) {
     if (!models || n_models < 1 || !d_sig || !d_off || !d_len || !d_ws || !d_probs || B < 1) {
         set_error("rs_classify_ensemble: null argument or empty batch");
         return RS_ERR_ARG;
@@ -772,25 +858,29 @@ int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d
         set_error("rs_classify_ensemble: Lmax %d outside [%d, %d]", Lmax, 1 << m0->n_layers, kMaxNormLen);
         return RS_ERR_LENGTH;
     }
-    size_t need = 0;
-    for (int k = 0; k < n_models; ++k) need = std::max(need, ws_layout(models[k], B, Lmax).total);
-    if (ws_bytes < need) {
-        set_error("rs_classify_ensemble: workspace %zu < required %zu", ws_bytes, need);
-        return RS_ERR_WORKSPACE;
+    // the models share one plan and one copy of the normalised signals: same block size, same element size (checked
+    // above), so one layout serves them all except for the width of the activation buffers
+    WsLayout w = ws_layout(m0, B, Lmax);
+    for (int k = 1; k < n_models; ++k) {
+        const WsLayout wk = ws_layout(models[k], B, Lmax);
+        if (wk.bufb_off - wk.bufa_off > w.bufb_off - w.bufa_off) w = wk;
     }
-    const WsLayout w = ws_layout(m0, B, Lmax);
+    int rc = check_call("rs_classify_ensemble", m0, B, Lmax, w, ws_bytes);
+    if (rc != RS_OK) return rc;
+    Batch bt;
+    rc = make_batch(m0, w, d_ws, h_len, B, Lmin, Lmax, &bt);
+    if (rc != RS_OK) return rc;
     DeviceGuard guard(m0->device);
     RS_HIP(guard.err);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    float* xn = reinterpret_cast<float*>(static_cast<char*>(d_ws) + w.xnorm_off);
     prof_mark(m0, -1, st);
-    int rc = launch_normalise(d_sig, d_off, d_len, B, Lmax, xn, w.P0, w.P0, nullptr, 0, nullptr, st, /*zero_prefix=*/1);
+    rc = normalise_packed(m0, d_sig, d_off, d_len, B, Lmax, w, bt, d_ws, st);
     if (rc != RS_OK) return rc;
     prof_mark(m0, 0, st);
+    const float* xn = reinterpret_cast<const float*>(static_cast<char*>(d_ws) + w.xnorm_off);
     for (int k = 0; k < n_models; ++k) {
-        // every model keeps the normalised rows at the head of the workspace and ping-pongs behind them
-        rc = forward_impl(models[k], xn, w.P0, d_len, B, Lmin, Lmax, d_ws, ws_bytes, d_probs + (size_t)k * B * 2, nullptr,
-                          stream, true);
+        // every model keeps the block table and the normalised rows at the head of the workspace and ping-pongs behind them
+        rc = forward_impl(models[k], xn, w.U, d_len, B, bt, w, d_ws, d_probs + (size_t)k * B * 2, nullptr, stream, true);
         if (rc != RS_OK) return rc;
     }
     if (d_decision) rc = launch_decide(d_probs, n_models, B, d_len, max_len, threshold, mode, d_decision, st);

@@ -80,16 +80,35 @@ constexpr int kMaxNormLen = 65536;
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Packed block layout of the conv stack.  A batch of B reads is laid out as NB BLOCKS of
+// U = 1 << shift samples: read b owns the nblk(b) = len[b] / U + 1 consecutive blocks from rbase[b] on (so at least one
+// zero sample follows every read), and the conv kernels run on the blocks as if each were a read of blen[k] samples in
+// a slot of U: work is proportional to every read's own length, whatever the longest read of the batch is.  The table
+// lives in the caller's workspace and is written on the device (normalise_kernel, or plan_kernel when the signals
+// arrive normalised); the host only needs NB, which it gets from its copy of the lengths - or, when it has none, from
+// uniform_nblk blocks for every read.
+struct BlockPlan {
+    int32_t* rbase = nullptr;    // [B + 1] first block of read b; rbase[B] = blocks in use
+    int32_t* blen = nullptr;     // [nb_total] valid samples of block k: clamp(len[b] - j * U, 0, U), j = k - rbase[b]
+    int32_t* bread = nullptr;    // [nb_total] read index b of block k
+    int shift = 12;              // log2 U
+    int uniform_nblk = 0;        // > 0: every read takes this many blocks
+    int nb_total = 0;            // blocks the workspace was laid out for
+};
+
 // ---- kernel launchers (each returns RS_OK or records an error) -------------------------
+// plan != nullptr: the fp32 rows go to the packed block layout (ld32 / pad_to ignored) and the block table is written
 int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
                      float* d_out32, int64_t ld32, int32_t pad_to, double* d_out64, int64_t ld64,
-                     double* d_stats, hipStream_t st, int zero_prefix = 0);
+                     double* d_stats, hipStream_t st, int zero_prefix = 0, const BlockPlan* plan = nullptr);
+// the block table alone (signals that arrive normalised: rs_forward)
+int launch_plan(const int32_t* d_len, int B, int Lmax, const BlockPlan& plan, hipStream_t st);
 
 int launch_normalise_float(const void* d_sig, int elem_bytes, const int64_t* d_off, const int32_t* d_len, int B, void* d_out,
                            int64_t ld, double* d_stats, hipStream_t st);
 
-// layer 0: x fp32 [B, ldx] -> y [B*P1, cp_out] (fp32 or bf16 rows), fused bias+ReLU+maxpool
-int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int P0,
+// layer 0: x fp32 [B, ldx] -> y [NB * U / 2, cp_out] (fp32 or 16-bit rows, packed block layout), fused bias+ReLU+maxpool
+int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, const BlockPlan& plan, int NB,
                  const float* d_w4 /* [cp_out][4] = w0,w1,w2,bias */, int cp_out,
                  void* d_y, int dtype, hipStream_t st);
 
@@ -168,8 +187,9 @@ int conv_h16_num_shapes();                      // shape index + table size * (p
 bool conv_h16_shape_ok(const ConvLayerDev& L, int k);
 int conv_f32_kc_max();
 
+// rows of read b: (rbase[b] * P_last) + t, t < len[b] >> n_layers (P_last = rows per block of the last buffer)
 int launch_head(const void* d_y, int dtype, int cp, int c, int P_last, int n_layers,
-                const int32_t* d_len, int B, const float* d_fcw, const float* d_fcb,
+                const int32_t* d_len, int B, const BlockPlan& plan, const float* d_fcw, const float* d_fcb,
                 float* d_probs, float* d_logits, hipStream_t st);
 
 int launch_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len,

@@ -134,10 +134,49 @@ __device__ void block_select2(KeyFn key, int n, int R, int k_lo, int k_hi, unsig
     __syncthreads();
 }
 
+// Block plan of the packed activation layout (common.hpp: BlockPlan).  Read b takes nblk(b) = len / U + 1 blocks of
+// U = 1 << shift samples (at least one zero sample behind the read: the conv's 'same' pad and the halo row of the
+// next read), its first block is the sum over the reads before it.  Called by every thread of a workgroup.
+__device__ __forceinline__ int plan_nblk(int n, const BlockPlan& pl) {
+    return pl.uniform_nblk > 0 ? pl.uniform_nblk : (n >> pl.shift) + 1;
+}
+
+// one workgroup of 1024 threads: the plan without a normalise launch (rs_forward: the signals arrive normalised)
+__global__ __launch_bounds__(1024) void plan_kernel(const int32_t* __restrict__ len, int B, int lmax, const BlockPlan pl) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 1024) {
+        const int b = b0 + tid;
+        const int n = b < B ? min(len[b], lmax) : 0;
+        const int nb = b < B ? plan_nblk(n, pl) : 0;
+        const int incl = wave_incl_scan(nb, lane);
+        if (lane == 63) wave_tot[w] = incl;
+        __syncthreads();
+        int base = carry_s;
+        for (int i = 0; i < w; ++i) base += wave_tot[i];
+        base += incl - nb;
+        __syncthreads();
+        if (tid == 1023) carry_s = base + nb;
+        if (b < B) {
+            pl.rbase[b] = base;
+            if (b == B - 1) pl.rbase[B] = base + nb;
+            if (base + nb <= pl.nb_total)
+                for (int j = 0; j < nb; ++j) {
+                    pl.blen[base + j] = max(0, min(n - (j << pl.shift), 1 << pl.shift));
+                    pl.bread[base + j] = b;
+                }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void normalise_kernel(
     const int16_t* __restrict__ sig, const int64_t* __restrict__ off, const int32_t* __restrict__ len,
     float* __restrict__ out32, int64_t ld32, int32_t pad_to, double* __restrict__ out64, int64_t ld64,
-    double* __restrict__ stats, int lmax, int zero_prefix) {
+    double* __restrict__ stats, int lmax, int zero_prefix, const BlockPlan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // rs_classify lays the fp32 rows out behind 16 zero bytes: the conv kernel that folds layer 0
     // into its staging reads x[-1] of the first read from there
@@ -155,6 +194,36 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
     int16_t* sx = sx0 + (int)((reinterpret_cast<uintptr_t>(src) >> 1) & 7);
     float* o32 = out32 ? out32 + (int64_t)b * ld32 : nullptr;
     double* o64 = out64 ? out64 + (int64_t)b * ld64 : nullptr;
+    if (pl.rbase) {
+        // packed block layout: this read's fp32 row starts at its first block, is zero-filled to the end of its last
+        // one, and the workgroup writes the read's entries of the block table the conv stack runs on
+        int base = b * pl.uniform_nblk;
+        if (pl.uniform_nblk <= 0) {
+            int s = 0;
+            for (int i = tid; i < b; i += kThreads) s += (min(len[i], lmax) >> pl.shift) + 1;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+            if (lane == 0) sc->red_a[w] = s;
+            __syncthreads();
+            base = 0;
+#pragma unroll
+            for (int i = 0; i < kWaves; ++i) base += sc->red_a[i];
+            __syncthreads();
+        }
+        const int nblk = plan_nblk(n, pl);
+        if (tid == 0) {
+            pl.rbase[b] = base;
+            if (b == (int)gridDim.x - 1) pl.rbase[b + 1] = base + nblk;
+        }
+        // device lengths that disagree with the host's copy (which sized the workspace): never write outside it
+        if (base + nblk > pl.nb_total) return;
+        if (tid < nblk) {
+            pl.blen[base + tid] = max(0, min(n - (tid << pl.shift), 1 << pl.shift));
+            pl.bread[base + tid] = b;
+        }
+        o32 = out32 + ((int64_t)base << pl.shift);
+        pad_to = nblk << pl.shift;
+    }
 
     // ---- stage the read into LDS, min / max on the way ------------------------------------
     // 16-byte loads over the 16-byte-aligned body of the read (the LDS copy is shifted by the same
@@ -296,9 +365,16 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
 
 }  // namespace
 
+int launch_plan(const int32_t* d_len, int B, int Lmax, const BlockPlan& plan, hipStream_t st) {
+    if (B <= 0) return RS_OK;
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, d_len, B, Lmax, plan);
+    RS_HIP(hipGetLastError());
+    return RS_OK;
+}
+
 int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
                      float* d_out32, int64_t ld32, int32_t pad_to, double* d_out64, int64_t ld64,
-                     double* d_stats, hipStream_t st, int zero_prefix) {
+                     double* d_stats, hipStream_t st, int zero_prefix, const BlockPlan* plan) {
     if (B <= 0) return RS_OK;
     if (Lmax < 1 || Lmax > kMaxNormLen) {
         set_error("rs_normalise: read length %d outside [1, %d]", Lmax, kMaxNormLen);
@@ -316,7 +392,7 @@ int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* 
         if (dev >= 0 && dev < kMaxDevices) attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(normalise_kernel, dim3(B), dim3(kThreads), lds, st, d_sig, d_off, d_len, d_out32, ld32,
-                       pad_to, d_out64, ld64, d_stats, Lmax, zero_prefix);
+                       pad_to, d_out64, ld64, d_stats, Lmax, zero_prefix, plan ? *plan : BlockPlan{});
     RS_HIP(hipGetLastError());
     return RS_OK;
 }

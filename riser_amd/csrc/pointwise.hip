@@ -37,25 +37,31 @@ __device__ __forceinline__ float from16(unsigned short u) {
 // a wave's stores are one contiguous run of 16-byte pieces.  32-bit index arithmetic only.
 constexpr int kC0PosPerBlock = 1024;
 
+// Packed block layout: blockIdx.y is a BLOCK k of U = 2 * P1 samples of read b = bread[k]; the block's pooled
+// positions are p = j * P1 + (0 .. P1) of the read (j = k - rbase[b]) and land in rows k * P1 + ... of y.
 template <int DT>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, int64_t ldx,
-                                                    const int32_t* __restrict__ len, int P1, int cq, int cp,
+                                                    const int32_t* __restrict__ len, const int32_t* __restrict__ rbase,
+                                                    const int32_t* __restrict__ bread, int P1, int cq, int cp,
                                                     const float4* __restrict__ w4, void* __restrict__ yv) {
     constexpr int CH = DT == 0 ? 4 : 8;
     const int ppi = 256 / cq;                                     // positions per iteration
     const int tid = threadIdx.x;
     if (tid >= ppi * cq) return;
     const int slot = tid / cq, q = tid - slot * cq;
-    const int b = blockIdx.y;
+    const int kb = blockIdx.y;
+    const int b = bread[kb];
     const int n = len[b];
     const int half = n >> 1;
     float4 w[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) w[j] = w4[q * CH + j];           // (w0, w1, w2, bias)
-    const float* xr0 = x + (int64_t)b * ldx;
+    const float* xr0 = x + (ldx < 0 ? (int64_t)rbase[b] * (2 * P1) : (int64_t)b * ldx);   // ldx < 0: packed signals
+    const int p_off = (kb - rbase[b]) * P1;                       // first pooled position of the block in its read
     const int p_begin = blockIdx.x * kC0PosPerBlock;
     const int p_end = min(p_begin + kC0PosPerBlock, P1);
-    for (int p = p_begin + slot; p < p_end; p += ppi) {
+    for (int pl = p_begin + slot; pl < p_end; pl += ppi) {
+        const int p = p_off + pl;
         float o[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) o[j] = 0.f;
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
                 o[j] = fmaxf(fmaxf(e, f), 0.0f);
             }
         }
-        const int64_t piece = ((int64_t)b * P1 + p) * cq + q;     // 16-byte piece index
+        const int64_t piece = ((int64_t)kb * P1 + pl) * cq + q;   // 16-byte piece index
         if constexpr (kX3<DT>) {
             // channels 8q .. 8q+7 of panel q >> 2: the hi piece, and the lo piece 64 bytes behind it
             unsigned short hi[8], lo[8];
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
                 hi[j] = to16<DT>(o[j]);
                 lo[j] = to16<DT>(o[j] - from16<DT>(hi[j]));
             }
-            const int64_t at = ((int64_t)b * P1 + p) * (2 * cq) + (q >> 2) * 8 + (q & 3);
+            const int64_t at = ((int64_t)kb * P1 + pl) * (2 * cq) + (q >> 2) * 8 + (q & 3);
             uint4 v;
             v.x = hi[0] | ((unsigned)hi[1] << 16);
             v.y = hi[2] | ((unsigned)hi[3] << 16);
@@ -117,19 +123,28 @@ constexpr int kHeadRowsUnroll = 4;
 template <int DT>
 __global__ __launch_bounds__(kHeadThreads) void head_kernel(const void* __restrict__ yv, int cp, int c, int P_last,
                                                            int n_layers, const int32_t* __restrict__ len,
+                                                           const int32_t* __restrict__ rbase, int nb_total,
                                                            const float* __restrict__ fcw, const float* __restrict__ fcb,
                                                            float* __restrict__ probs, float* __restrict__ logits) {
     __shared__ float red[kHeadThreads / 64][2];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int rows = len[b] >> n_layers;
     const float inv = 1.0f / (float)rows;
+    const int64_t row0 = (int64_t)rbase[b] * P_last;              // the read's first row (packed block layout)
+    if (rbase[b + 1] > nb_total) {                                // the read was dropped by the plan (see normalise_kernel)
+        if (tid < 2) {
+            probs[2 * b + tid] = __builtin_nanf("");
+            if (logits) logits[2 * b + tid] = __builtin_nanf("");
+        }
+        return;
+    }
     auto ld = [&](int t, int ch) -> float {
         if constexpr (kX3<DT>) {
-            const int64_t at = ((int64_t)b * P_last + t) * cp + ((ch >> 5) << 6) + (ch & 31);
+            const int64_t at = (row0 + t) * cp + ((ch >> 5) << 6) + (ch & 31);
             const unsigned short* y16 = reinterpret_cast<const unsigned short*>(yv);
             return from16<DT>(y16[at]) + from16<DT>(y16[at + 32]);
         }
-        const int64_t idx = ((int64_t)b * P_last + t) * cp + ch;
+        const int64_t idx = (row0 + t) * cp + ch;
         if constexpr (DT != 0)
             return from16<DT>(reinterpret_cast<const unsigned short*>(yv)[idx]);
         else
@@ -210,9 +225,9 @@ __global__ __launch_bounds__(256) void decide_kernel(const float* __restrict__ p
 
 }  // namespace
 
-int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int P0, const float* d_w4,
+int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, const BlockPlan& plan, int NB, const float* d_w4,
                  int cp_out, void* d_y, int dtype, hipStream_t st) {
-    const int P1 = P0 / 2;
+    const int P1 = (1 << plan.shift) / 2;
     // 16-byte pieces of 4 (fp32) / 8 (16-bit) channels per output row; split precision: per row cp_out / 2 logical
     // channel slots, each 8-channel group stored as a hi piece and a lo piece
     const int cq = is_x3(dtype) ? cp_out / 16 : cp_out / (dtype == RS_F32 ? 4 : 8);
@@ -220,21 +235,26 @@ int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, int B, int
         set_error("conv0: unsupported first-layer width %d", cp_out);
         return RS_ERR_ARG;
     }
-    dim3 grid((P1 + kC0PosPerBlock - 1) / kC0PosPerBlock, B);
+    if (NB > 65535) {
+        set_error("conv0: %d blocks exceed the launch grid, split the batch", NB);
+        return RS_ERR_ARG;
+    }
+    dim3 grid((P1 + kC0PosPerBlock - 1) / kC0PosPerBlock, NB);
     auto fn = dtype == RS_F16 ? conv0_kernel<2> : dtype == RS_BF16 ? conv0_kernel<1>
             : dtype == RS_BF16X3 ? conv0_kernel<RS_BF16X3> : dtype == RS_F16X3 ? conv0_kernel<RS_F16X3> : conv0_kernel<0>;
-    hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, d_x, ldx, d_len, P1, cq, cp_out,
+    hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, d_x, ldx, d_len, plan.rbase, plan.bread, P1, cq, cp_out,
                        reinterpret_cast<const float4*>(d_w4), d_y);
     RS_HIP(hipGetLastError());
     return RS_OK;
 }
 
 int launch_head(const void* d_y, int dtype, int cp, int c, int P_last, int n_layers, const int32_t* d_len,
-                int B, const float* d_fcw, const float* d_fcb, float* d_probs, float* d_logits, hipStream_t st) {
+                int B, const BlockPlan& plan, const float* d_fcw, const float* d_fcb, float* d_probs, float* d_logits,
+                hipStream_t st) {
     auto fn = dtype == RS_F16 ? head_kernel<2> : dtype == RS_BF16 ? head_kernel<1>
             : dtype == RS_BF16X3 ? head_kernel<RS_BF16X3> : dtype == RS_F16X3 ? head_kernel<RS_F16X3> : head_kernel<0>;
-    hipLaunchKernelGGL(fn, dim3(B), dim3(kHeadThreads), 0, st, d_y, cp, c, P_last, n_layers, d_len, d_fcw, d_fcb, d_probs,
-                       d_logits);
+    hipLaunchKernelGGL(fn, dim3(B), dim3(kHeadThreads), 0, st, d_y, cp, c, P_last, n_layers, d_len, plan.rbase,
+                       plan.nb_total, d_fcw, d_fcb, d_probs, d_logits);
     RS_HIP(hipGetLastError());
     return RS_OK;
 }

@@ -87,6 +87,10 @@ class Model:
                 raise ValueError("riser_amd supports two-class heads only")
             self._seq = SeqNet(*build_convnet_program(sd, cnn), device=self.device)
             self._h = None
+            if dtype not in ("f32w", "f32"):
+                raise ValueError(f"dtype {dtype!r}: configs with depth > 1 or kernels other than 3 run the generic fp32 "
+                                 "conv program only")
+            self.dtype = "f32"
             self._ws = Workspace(self.device)
             return
         conv_w, conv_b = [], []
@@ -156,7 +160,24 @@ class Model:
             return int(lmax)
         return nv.lib().rs_padded_length(self._h, int(lmax))
 
+    def block_samples(self) -> int:
+        """Block size U of the packed activation layout (rs_block_samples)."""
+        self._need_handle("block_samples")
+        return nv.lib().rs_block_samples(self._h)
+
+    def block_bases(self, lens_host) -> np.ndarray:
+        """First block of every read of a batch in the packed layout (+ the total as the last entry): read b's rows
+        in conv layer i's output start at row bases[b] * (U >> (i + 1))."""
+        U = self.block_samples()
+        nblk = np.asarray(lens_host, dtype=np.int64) // U + 1
+        return np.concatenate([[0], np.cumsum(nblk)]).astype(np.int64)
+
+    def _need_handle(self, what: str):
+        if self._h is None:
+            raise NotImplementedError(f"{what}: not available for generic conv programs (depth > 1 / kernels other than 3)")
+
     def layer_info(self):
+        self._need_handle("layer_info")
         out = []
         for i in range(self.n_layers):
             li = nv.LayerInfo()
@@ -166,10 +187,12 @@ class Model:
 
     def profile(self, on, coarse: bool = False):
         """HIP-event stage timing on the launch stream; coarse = only the conv stack's boundaries (4 events per call)."""
+        self._need_handle("profile")
         nv.check(nv.lib().rs_profile_enable(self._h, (2 if coarse else 1) if on else 0), "rs_profile_enable")
 
     def profile_read(self):
         """-> (stage_ms float32 [n_layers + 2], calls); see rs_profile_read."""
+        self._need_handle("profile_read")
         ms = np.zeros(self.n_layers + 2, dtype=np.float32)
         calls = C.c_int32(0)
         nv.check(nv.lib().rs_profile_read(self._h, ms.ctypes.data, C.byref(calls)), "rs_profile_read")
@@ -179,10 +202,9 @@ class Model:
         """Largest batch one library call accepts for reads of up to lmax samples: the conv kernels
         address every activation buffer through a 2 GiB buffer-resource window (32-bit offsets with
         hardware bounds checking).  Bigger batches are split transparently by the methods below."""
-        p0 = self.padded_length(lmax)
-        per_read = max((p0 >> (i + 1)) * (-(-c // 8) * 8) * 4 for i, c in enumerate(self.channels))
-        per_read = max(per_read, p0 * 4)
-        return max(1, (2 ** 31 - 2 ** 16) // per_read)
+        if self._seq is not None:
+            return 1 << 30
+        return max(1, nv.lib().rs_max_batch(self._h, int(lmax)))
 
     def _check_lengths(self, lens_host: np.ndarray):
         if lens_host.size == 0:
@@ -242,22 +264,26 @@ class Model:
                 if return_logits:
                     logits[s0:s1] = r[1]
             return (probs, logits) if return_logits else probs
+        lens_host = np.ascontiguousarray(lens_host, dtype=np.int32)
         if lens_dev is None:
-            lens_dev = torch.from_numpy(np.ascontiguousarray(lens_host, dtype=np.int32)).to(self.device)
+            lens_dev = torch.from_numpy(lens_host).to(self.device)
         L = nv.lib()
         need = L.rs_workspace_bytes(self._h, B, lmax)
         ws = self._ws.get(need)
         probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
         logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
-        nv.check(L.rs_forward(self._h, x.data_ptr(), ldx, lens_dev.data_ptr(), B, int(lens_host.min()), lmax, ws.data_ptr(),
+        nv.check(L.rs_forward(self._h, x.data_ptr(), ldx, lens_dev.data_ptr(), lens_host.ctypes.data, B,
+                              int(lens_host.min()), lmax, ws.data_ptr(),
                               ws.numel(), probs.data_ptr(), logits.data_ptr() if return_logits else None,
                               _stream_ptr(self.device)), "rs_forward")
         return (probs, logits) if return_logits else probs
 
     def classify_raw(self, sig_dev: torch.Tensor, off_dev: torch.Tensor, len_dev: torch.Tensor,
-                     lens_host: np.ndarray, out: torch.Tensor = None, return_logits: bool = False):
+                     lens_host: np.ndarray, out: torch.Tensor = None, return_logits: bool = False, packed: bool = True):
         """Fused normalise + forward on raw int16 reads already resident on the device:
-        read b = sig_dev[off[b] : off[b] + len[b]].  Returns fp32 [B, 2] on the device."""
+        read b = sig_dev[off[b] : off[b] + len[b]].  Returns fp32 [B, 2] on the device.
+        packed=False withholds the host's copy of the lengths from the library (every read then takes the blocks of the
+        longest one: the layout a caller without host lengths gets; bit-identical results)."""
         self._check_lengths(lens_host)
         B = int(lens_host.shape[0])
         lmax = int(lens_host.max())
@@ -274,17 +300,18 @@ class Model:
             for s0 in range(0, B, mb):
                 s1 = min(B, s0 + mb)
                 r = self.classify_raw(sig_dev, off_dev[s0:s1], len_dev[s0:s1], lens_host[s0:s1], out=probs[s0:s1],
-                                      return_logits=return_logits)
+                                      return_logits=return_logits, packed=packed)
                 if return_logits:
                     logits[s0:s1] = r[1]
             return (probs, logits) if return_logits else probs
         L = nv.lib()
+        lens_host = np.ascontiguousarray(lens_host, dtype=np.int32)
         need = L.rs_workspace_bytes(self._h, B, lmax)
         ws = self._ws.get(need)
         probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
         logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
-        nv.check(L.rs_classify(self._h, sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), B,
-                               int(lens_host.min()), lmax,
+        nv.check(L.rs_classify(self._h, sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(),
+                               lens_host.ctypes.data if packed else None, B, int(lens_host.min()), lmax,
                                ws.data_ptr(), ws.numel(), probs.data_ptr(),
                                logits.data_ptr() if return_logits else None, _stream_ptr(self.device)),
                  "rs_classify")
@@ -295,16 +322,18 @@ def _autotune(self, sig_dev: torch.Tensor, off_dev: torch.Tensor, len_dev: torch
     """Time every feasible tile shape of each tiled conv layer on this batch (rs_autotune) and keep the measured best
     for later batches of the same geometry; returns the number of layers whose choice changed.  Optional: call once per
     deployment batch size (e.g. before a run); results are bit-identical with or without it."""
+    self._need_handle("autotune")
     self._check_lengths(lens_host)
     B, lmax = int(lens_host.shape[0]), int(lens_host.max())
     if B > self.max_batch(lmax):
         raise ValueError("autotune: batch exceeds one library call (Model.max_batch)")
+    lens_host = np.ascontiguousarray(lens_host, dtype=np.int32)
     L = nv.lib()
     ws = self._ws.get(L.rs_workspace_bytes(self._h, B, lmax))
     probs = torch.empty((B, 2), dtype=torch.float32, device=self.device)
     changed = C.c_int32(0)
-    nv.check(L.rs_autotune(self._h, sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), B, int(lens_host.min()),
-                           lmax, ws.data_ptr(), ws.numel(), probs.data_ptr(), C.byref(changed), _stream_ptr(self.device)),
+    nv.check(L.rs_autotune(self._h, sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), lens_host.ctypes.data, B,
+                           int(lens_host.min()), lmax, ws.data_ptr(), ws.numel(), probs.data_ptr(), C.byref(changed), _stream_ptr(self.device)),
              "rs_autotune")
     return changed.value
 
@@ -322,6 +351,17 @@ def classify_raw_ensemble(models, sig_dev: torch.Tensor, off_dev: torch.Tensor, 
     m0 = models[0]
     m0._check_lengths(lens_host)
     B, lmax = int(lens_host.shape[0]), int(lens_host.max())
+    lens_host = np.ascontiguousarray(lens_host, dtype=np.int32)
+    if any(m._h is None for m in models):
+        # a generic conv program (depth > 1 / kernels other than 3) among the models: one classify_raw per model and
+        # the decision kernel on their probabilities - the same arithmetic, just not one library call
+        probs = out if out is not None else torch.empty((len(models), B, 2), dtype=torch.float32, device=m0.device)
+        for k, m in enumerate(models):
+            m.classify_raw(sig_dev, off_dev, len_dev, lens_host, out=probs[k])
+        if decision is not None:
+            nv.check(nv.lib().rs_decide(probs.data_ptr(), len(models), B, len_dev.data_ptr(), int(max_len), float(threshold),
+                                        int(mode), decision.data_ptr(), _stream_ptr(m0.device)), "rs_decide")
+        return probs
     mb = min(m.max_batch(lmax) for m in models)
     if B > mb:                                                         # split: reads are independent
         probs = out if out is not None else torch.empty((len(models), B, 2), dtype=torch.float32, device=m0.device)
@@ -337,8 +377,8 @@ def classify_raw_ensemble(models, sig_dev: torch.Tensor, off_dev: torch.Tensor, 
     ws = m0._ws.get(need)
     probs = out if out is not None else torch.empty((len(models), B, 2), dtype=torch.float32, device=m0.device)
     hs = (C.c_void_p * len(models))(*[m._h for m in models])
-    nv.check(L.rs_classify_ensemble(hs, len(models), sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), B,
-                                    int(lens_host.min()), lmax, ws.data_ptr(), ws.numel(), probs.data_ptr(),
+    nv.check(L.rs_classify_ensemble(hs, len(models), sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(),
+                                    lens_host.ctypes.data, B, int(lens_host.min()), lmax, ws.data_ptr(), ws.numel(), probs.data_ptr(),
                                     decision.data_ptr() if decision is not None else None, int(max_len),
                                     float(threshold), int(mode), _stream_ptr(m0.device)), "rs_classify_ensemble")
     return probs

@@ -37,7 +37,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.rs_version() >> 16 == 1
+    assert lib.rs_version() >> 16 == 2
     assert isinstance(lib.rs_last_error(), bytes)
 
 
@@ -50,7 +50,8 @@ def test_argument_validation_without_gpu(lib):
     assert lib.rs_workspace_bytes(None, 1, 4096) == 0
     assert lib.rs_padded_length(None, 4096) == 0
     assert lib.rs_decide(None, 0, 4, None, 1, 0.9, 0, None, None) == -1
-    assert lib.rs_forward(None, None, 0, None, 1, 4096, 4096, None, 0, None, None, None) == -1
+    assert lib.rs_forward(None, None, 0, None, None, 1, 4096, 4096, None, 0, None, None, None) == -1
+    assert lib.rs_max_batch(None, 4096) == 0 and lib.rs_block_samples(None) == 0
     assert lib.rs_model_destroy(None) == 0
 
 

@@ -1,0 +1,106 @@
+"""Packed block layout: a read occupies len / U + 1 blocks of U samples, so the conv stack's work follows
+every read's own length.  Lengths drawn uniformly from the live range against the oracle; packed == uniform pitch bit for
+bit in every arithmetic mode; batch composition and order never change a read's bits."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import riser_oracle as ro
+from oracle import torch_path
+from riser_amd import synth
+from riser_amd.model import Model, classify_raw_ensemble
+from riser_amd.preprocess import pack_reads
+
+pytestmark = pytest.mark.gpu
+SIG_SEED = 20260103
+_models = {}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def get_model(seed, dev, dtype="f32w"):
+    key = (seed, dtype)
+    if key not in _models:
+        _models[key] = Model(synth.make_state_dict(seed), synth.Config(), None, "t", dtype=dtype, device=dev)
+    return _models[key]
+
+
+def _reads(lens, first=3000):
+    return [synth.make_signals(SIG_SEED, 1, int(n), first_read=first + i)[0] for i, n in enumerate(lens)]
+
+
+def test_uniform_random_lengths_vs_oracle(dev):
+    """96 reads with lengths uniform in [4096, 16000] (any integer: riser/control.py:55-60) through the fused path, every
+    read against the oracle's torch-CPU path; labels at 0.9 identical."""
+    rng = np.random.default_rng(31)
+    lens = rng.integers(4096, 16001, size=96)
+    lens[:6] = (4096, 4097, 8191, 8192, 8193, 16000)              # block edges: len % U == 0 leaves a whole dead block
+    sigs = _reads(lens)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    sd = synth.make_state_dict(1)
+    got = get_model(1, dev).classify_raw(sig, off, ln, lh).cpu().numpy()
+    cpu = torch_path.TorchCpuModel(sd)
+    want = torch_path.classify_per_read(cpu, sigs)
+    assert np.abs(got - want).max() < 1e-4, np.abs(got - want).max()
+    assert np.array_equal(got[:, 1] > 0.9, want[:, 1] > 0.9)
+    # block bookkeeping the host mirrors: bases are the prefix sum of len // U + 1
+    m = get_model(1, dev)
+    U = m.block_samples()
+    assert U == 4096 and m.block_bases(lh)[-1] == int((lh // U + 1).sum())
+
+
+@pytest.mark.parametrize("dtype", ["f32w", "f32", "f16", "bf16", "bf16x3", "f16x3"])
+def test_packed_equals_uniform_pitch_bitwise(dev, dtype):
+    """the same batch with and without the host's copy of the lengths (packed blocks vs every read in the slot of the
+    longest): identical bits, in every mode, through classify_raw and the unfused rs_forward path"""
+    lens = np.array([16000, 4096, 8615, 12000, 8000, 4100, 16000, 9999, 12288, 8192, 5000, 15999, 7000], dtype=np.int32)
+    sigs = _reads(lens, 3200)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    m = get_model(2, dev, dtype)
+    packed = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+    uniform = m.classify_raw(sig, off, ln, lh, packed=False).cpu().numpy()
+    assert np.array_equal(packed, uniform), np.abs(packed - uniform).max()
+    # one read alone, the batch reversed, a sub-batch: same bits per read
+    for idx in ([2], list(range(len(lens)))[::-1], [4, 0, 7]):
+        s2, o2, l2, h2 = pack_reads([sigs[i] for i in idx], dev)
+        part = m.classify_raw(s2, o2, l2, h2).cpu().numpy()
+        assert np.array_equal(part, packed[idx]), (dtype, idx)
+    if dtype in ("f32w", "f32"):
+        # unfused route: conv0 kernel on per-read rows + the tiled kernels (fp32: same fmaf chains, same bits)
+        xs = [ro.mad_normalise(s) for s in sigs]
+        unf = m.classify_batch(xs).cpu().numpy()
+        assert np.array_equal(unf, packed), np.abs(unf - packed).max()
+
+
+def test_ensemble_on_packed_blocks(dev):
+    """rs_classify_ensemble shares one block table and one normalised copy between the models"""
+    lens = np.array([8615] * 20 + [4096, 12048, 6000], dtype=np.int32)
+    sigs = _reads(lens, 3400)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    models = [get_model(s, dev) for s in (1, 2, 3)]
+    dec = torch.empty(len(lens), dtype=torch.uint8, device=dev)
+    pe = classify_raw_ensemble(models, sig, off, ln, lh, decision=dec, max_len=8615, threshold=0.9).cpu().numpy()
+    for k, m in enumerate(models):
+        assert np.array_equal(pe[k], m.classify_raw(sig, off, ln, lh).cpu().numpy())
+    want = ro.classify_reads(synth.make_state_dict(2), sigs)
+    assert np.abs(pe[1] - want).max() < 1e-4
+
+
+def test_length_mismatch_is_contained(dev):
+    """host lengths that understate the device's (a caller bug) cost those reads their result - NaN - and nothing else:
+    the other reads keep their bits, nothing is written outside the workspace"""
+    lens = np.array([5000, 9000, 4500, 16000], dtype=np.int32)
+    sigs = _reads(lens, 3500)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    m = get_model(1, dev)
+    good = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+    lied = lh.copy()
+    lied[3] = 4096                                                # device says 16000 (4 blocks), host says 1 block
+    out = m.classify_raw(sig, off, ln, lied).cpu().numpy()
+    assert np.array_equal(out[:3], good[:3])
+    assert np.isnan(out[3]).all()
+    assert np.array_equal(m.classify_raw(sig, off, ln, lh).cpu().numpy(), good)

@@ -286,7 +286,7 @@ def test_too_short_and_bad_args(dev):
     ln = torch.tensor([4096], dtype=torch.int32, device=dev)
     out = torch.zeros((1, 2), device=dev)
     ws = torch.zeros(1024, dtype=torch.uint8, device=dev)
-    rc = L.rs_forward(m._h, x.data_ptr(), 4096, ln.data_ptr(), 1, 4096, 4096, ws.data_ptr(), ws.numel(), out.data_ptr(), None, None)
+    rc = L.rs_forward(m._h, x.data_ptr(), 4096, ln.data_ptr(), None, 1, 4096, 4096, ws.data_ptr(), ws.numel(), out.data_ptr(), None, None)
     assert rc == -5 and b"workspace" in L.rs_last_error()
     h = C.c_void_p()
     ch = (C.c_int32 * 2)(4, 4)

@@ -148,22 +148,25 @@ def test_layerwise_activations_vs_oracle(dev, dtype):
         x = ro.mad_normalise(s).astype(np.float32)[None, :]
         _, layers = ro.convnet_forward(sd, x, acc=np.float64, return_layers=True)
         want.append(layers)
-    P0 = m.padded_length(max(lens))
+    # packed block layout: read b owns the blocks bases[b] .. bases[b + 1] of U samples, U >> (i + 1) rows each
+    U, bases = m.block_samples(), m.block_bases(lens)
+    assert list(np.diff(bases)) == [n // U + 1 for n in lens]
     info = m.layer_info()
     for i in range(1, m.n_layers):
-        P_out, cp = P0 >> (i + 1), info[i]["cp_out"]
-        cap = torch.full((len(lens) * P_out, cp), float("nan"), dtype=torch.float32, device=dev)
+        P_out, cp = U >> (i + 1), info[i]["cp_out"]
+        cap = torch.full((int(bases[-1]) * P_out, cp), float("nan"), dtype=torch.float32, device=dev)
         nv.check(nv.lib().rs_debug_capture_layer(m._h, i, cap.data_ptr(), cap.numel() * 4), "capture")
         m.classify_raw(sig, off, ln, lh)
-        got = cap.cpu().numpy().reshape(len(lens), P_out, cp)
+        got_all = cap.cpu().numpy()
         for b, n in enumerate(lens):
+            got = got_all[bases[b] * P_out: bases[b + 1] * P_out]
             ref = want[b][i][0].T                                   # [L_out, C]
             L_out, C = ref.shape
             assert L_out == n >> (i + 1)
             scale = max(1.0, float(np.abs(ref).max()))
-            assert np.abs(got[b, :L_out, :C] - ref).max() < 2e-4 * scale, (i, b)
-            assert not got[b, L_out:, :].any(), (i, b)              # padding rows of the slot
-            assert not got[b, :, C:].any(), (i, b)                  # padding channels
+            assert np.abs(got[:L_out, :C] - ref).max() < 2e-4 * scale, (i, b)
+            assert not got[L_out:, :].any(), (i, b)                 # padding rows of the read's blocks
+            assert not got[:, C:].any(), (i, b)                     # padding channels
     nv.check(nv.lib().rs_debug_capture_layer(m._h, -1, None, 0), "capture off")
 
 
@@ -195,17 +198,20 @@ def test_winograd_f43_layers(dev, monkeypatch):
     sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=820 + i)[0] for i, n in enumerate(lens)]
     sig, off, ln, lh = pack_reads(sigs, dev)
     i = 8
-    P_out, cp = m.padded_length(16000) >> (i + 1), m.layer_info()[i]["cp_out"]
-    cap = torch.full((len(lens) * P_out, cp), float("nan"), dtype=torch.float32, device=dev)
+    U, bases = m.block_samples(), m.block_bases(lens)
+    assert U == 8192                                              # F(4,3) on the last layer doubles the block
+    P_out, cp = U >> (i + 1), m.layer_info()[i]["cp_out"]
+    cap = torch.full((int(bases[-1]) * P_out, cp), float("nan"), dtype=torch.float32, device=dev)
     nv.check(nv.lib().rs_debug_capture_layer(m._h, i, cap.data_ptr(), cap.numel() * 4), "capture")
     m.classify_raw(sig, off, ln, lh)
-    got = cap.cpu().numpy().reshape(len(lens), P_out, cp)
+    got_all = cap.cpu().numpy()
     for b, s in enumerate(sigs):
+        got = got_all[bases[b] * P_out: bases[b + 1] * P_out]
         x = ro.mad_normalise(s).astype(np.float32)[None, :]
         _, layers = ro.convnet_forward(sd, x, acc=np.float64, return_layers=True)
         refl = layers[i][0].T
         L_out, C = refl.shape
-        assert np.abs(got[b, :L_out, :C] - refl).max() < 2e-4 * max(1.0, float(np.abs(refl).max()))
-        assert not got[b, L_out:, :].any() and not got[b, :, C:].any()
+        assert np.abs(got[:L_out, :C] - refl).max() < 2e-4 * max(1.0, float(np.abs(refl).max()))
+        assert not got[L_out:, :].any() and not got[:, C:].any()
     m.close()
     base.close()
