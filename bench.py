@@ -365,6 +365,18 @@ def side_variants(args, device, wl, ref):
     variants["mixed_2s_3s_4s_f16"] = {"chunks_per_s": round(B / dtm, 1), "ms_per_step": round(dtm * 1e3, 4),
                                       "batch": B, "samples_per_step": int(mix_lens.sum())}
     mm.close()
+    # the live ReadUntil shape: ~357 assessable reads per 512-channel batch, capped at the RNA004 maximum of 8615 samples
+    # (riser/preprocess.py:36-37): 3 blocks of 4096 per read in the packed layout
+    lb, ll = 357, 8615
+    live_lens = np.full(lb, ll, dtype=np.int32)
+    live_off = torch.from_numpy(np.arange(lb, dtype=np.int64) * L).to(device)
+    live_len = torch.from_numpy(live_lens).to(device)
+    ml = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype="f32w", device=device)
+    pl = torch.empty((lb, 2), dtype=torch.float32, device=device)
+    dtl = timed(lambda: ml.classify_raw(sig, live_off, live_len, live_lens, out=pl))
+    variants["live_357x8615_f32"] = {"reads_per_s": round(lb / dtl, 1), "ms_per_step": round(dtl * 1e3, 4), "batch": lb,
+                                     "samples_per_read": ll}
+    ml.close()
     # the reference's secondary architecture (riser/nets/resnet.py; no shipped config or weights): a SquiggleNet-like
     # basic-block ResNet through the generic conv program (csrc/seqnet.hip: f32-input MFMA, weights resident in LDS)
     import types

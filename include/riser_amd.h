@@ -114,7 +114,7 @@ size_t rs_workspace_bytes(const rs_model* m, int B, int Lmax);
  * buffer-resource window (32-bit offsets, hardware bounds checking).  Reads are independent: split bigger batches. */
 int rs_max_batch(const rs_model* m, int Lmax);
 
-/* Block size U of the packed activation layout in samples: 2^n_layers (4096 for the shipped net; doubled when
+/* Block size U of the packed activation layout in samples: 2^max(n_layers, 12) (4096 for the shipped net; doubled when
  * RS_WINO4 puts the last layer on the F(4,3) lowering).  Read b of a batch starts at sample U * sum_{i<b}(len_i / U + 1)
  * of the normalised-signal region and at row (that >> (layer + 1)) of conv layer `layer`'s output buffer. */
 int rs_block_samples(const rs_model* m);

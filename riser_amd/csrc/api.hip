@@ -507,7 +507,9 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
     // every read's slot must start on a Winograd group boundary in every F(4,3) layer (P0 >> i divisible by 4):
     // then the grouping of a read's rows - and with it every rounding - is the same wherever the read sits in a
     // batch and whatever the batch's longest read is (results are bit-identical across batch compositions)
-    m->pad_shift = n_layers;
+    // ... and the packed layout's block is never smaller than 4096 samples (shallow nets: several rows of the last
+    // buffer per block), so a read spans a handful of blocks whatever the depth
+    m->pad_shift = std::max(n_layers, 12);
     for (int i = 1; i < n_layers; ++i)
         if (m->layers[i].wino_m == 4) m->pad_shift = std::max(m->pad_shift, i + 2);
     if (rc == RS_OK) rc = upload(&m->d_zero, std::vector<float>(64, 0.0f));

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kWaves * 64, RS_SF32_BLOCKS) void conv_stream_f32_k
 
     // (read, position, lengths) of the sub-tile, carried in scalars and advanced by 16 rows per step
     struct SubInfo {
-        int t0, b, len0, len1;          // position of pooled row 16 u in its read; raw lengths of reads b, b + 1
+        int t0, b, len0, len1, lenm;    // position of pooled row 16 u in its read; raw lengths of reads b, b + 1, b - 1
     };
     auto sub_info = [&](int u) {
         SubInfo si;
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(kWaves * 64, RS_SF32_BLOCKS) void conv_stream_f32_k
         si.t0 = g0 - si.b * a.P2;
         si.len0 = si.b < a.n_reads ? clen[si.b] : 0;
         si.len1 = si.b + 1 < a.n_reads ? clen[si.b + 1] : 0;
+        si.lenm = (si.b >= 1 && si.b - 1 < a.n_reads) ? clen[si.b - 1] : 0;
         return si;
     };
     auto advance = [&](SubInfo& si) {
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(kWaves * 64, RS_SF32_BLOCKS) void conv_stream_f32_k
         if (si.t0 >= a.P2) {
             si.t0 -= a.P2;
             ++si.b;
+            si.lenm = si.len0;
             si.len0 = si.len1;
             si.len1 = si.b + 1 < a.n_reads ? clen[si.b + 1] : 0;
         }
@@ -160,10 +162,17 @@ __global__ __launch_bounds__(kWaves * 64, RS_SF32_BLOCKS) void conv_stream_f32_k
         const f32x4 xa = __builtin_bit_cast(f32x4, raw[0]), xb = __builtin_bit_cast(f32x4, raw[1]),
                     xc = __builtin_bit_cast(f32x4, raw[2]);
         const float xs_[12] = {xa[0], xa[1], xa[2], xa[3], xb[0], xb[1], xb[2], xb[3], xc[0], xc[1], xc[2], xc[3]};
-        // input row 2t - 1 + k of the read (k = 0..3) is valid iff 0 <= 2t - 1 + k < L1
+        // input row 2t - 1 + k (k = 0..3) of the lane's slot is valid iff it is below the slot's valid rows L1.  Slots are
+        // BLOCKS of a read (common.hpp: BlockPlan): row -1 is the last row of the slot before, valid iff that slot is
+        // full (the same read continues into this one), and row P1 is row 0 of the slot behind
+        const int P1 = 2 * a.P2;
+        const int Lprev = (hi ? si.len0 : si.lenm) >> 1, Lnext = hi ? 0 : si.len1 >> 1;
         bool vk[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) vk[k] = fast || (2 * t - 1 + k >= 0 && 2 * t - 1 + k < L1);
+        for (int k = 0; k < 4; ++k) {
+            const int row = 2 * t - 1 + k;
+            vk[k] = fast || (row < 0 ? Lprev >= P1 : row >= P1 ? row - P1 < Lnext : row < L1);
+        }
 
         f32x4 acc[NT][4];
 #pragma unroll
