@@ -310,8 +310,11 @@ def side_variants(args, device, wl, ref):
             mv.autotune(sig, off, ln, lens)      # optional per-geometry tile tuning (fp32: the planner's picks stand)
         pv = torch.empty((B, 2), dtype=torch.float32, device=device)
         dtv = timed(lambda: mv.classify_raw(sig, off, ln, lens, out=pv))
-        variants["f32_direct" if dt == "f32" else dt] = {
-            "chunks_per_s": round(B / dtv, 1), "ms_per_step": round(dtv * 1e3, 4), "batch": B, **versus_ref(pv.cpu().numpy())}
+        entry = {"chunks_per_s": round(B / dtv, 1), "ms_per_step": round(dtv * 1e3, 4), "batch": B, **versus_ref(pv.cpu().numpy())}
+        if dt in ("f16", "bf16"):                # plain 16-bit: fast, outside the 1e-3 tolerance
+            variants.setdefault("approximate", {})[dt] = entry
+        else:
+            variants["f32_direct" if dt == "f32" else dt] = entry
         mv.close()
     # two batches in flight: the same 512-read call alternately on two HIP streams (per-stream workspaces).  The idle CUs
     # of one batch's tile rounds, prologues and launch boundaries run the other's work; throughput-oriented callers
@@ -347,10 +350,13 @@ def side_variants(args, device, wl, ref):
         dec = torch.empty(B, dtype=torch.uint8, device=device)
         dte = timed(lambda: classify_raw_ensemble(ens, sig, off, ln, lens, out=pe, decision=dec, max_len=L,
                                                   threshold=0.9, mode=nv.RS_ENRICH))
-        variants["ensemble3_" + dt] = {"reads_per_s": round(B / dte, 1), "model_forwards_per_s": round(3 * B / dte, 1),
-                                       "ms_per_step": round(dte * 1e3, 4), "batch": B,
-                                       "accepted": int((dec == 1).sum().item()),
-                                       "model0": versus_ref(pe[0].cpu().numpy())}
+        entry = {"reads_per_s": round(B / dte, 1), "model_forwards_per_s": round(3 * B / dte, 1),
+                 "ms_per_step": round(dte * 1e3, 4), "batch": B, "accepted": int((dec == 1).sum().item()),
+                 "model0": versus_ref(pe[0].cpu().numpy())}
+        if dt == "bf16x3":
+            variants["ensemble3_bf16x3"] = entry                   # BASELINE config 3 (the mode that meets 1e-3)
+        else:                                                      # plain bf16 misses the tolerance: not config 3
+            variants.setdefault("approximate", {})["ensemble3_bf16"] = entry
         for mk in ens:
             mk.close()
     # BASELINE config 5: progressive 2 s / 3 s / 4 s chunks in equal thirds of one batch, f16: per-read lengths
@@ -362,8 +368,13 @@ def side_variants(args, device, wl, ref):
     pm = torch.empty((B, 2), dtype=torch.float32, device=device)
     mm.autotune(sig, mix_off, mix_len, mix_lens)
     dtm = timed(lambda: mm.classify_raw(sig, mix_off, mix_len, mix_lens, out=pm))
-    variants["mixed_2s_3s_4s_f16"] = {"chunks_per_s": round(B / dtm, 1), "ms_per_step": round(dtm * 1e3, 4),
-                                      "batch": B, "samples_per_step": int(mix_lens.sum())}
+    variants.setdefault("approximate", {})["mixed_2s_3s_4s_f16"] = {
+        "chunks_per_s": round(B / dtm, 1), "ms_per_step": round(dtm * 1e3, 4), "batch": B, "samples_per_step": int(mix_lens.sum())}
+    mm.close()
+    mm = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype="f16x3", device=device)
+    dtm = timed(lambda: mm.classify_raw(sig, mix_off, mix_len, mix_lens, out=pm))
+    variants["mixed_2s_3s_4s_f16x3"] = {"chunks_per_s": round(B / dtm, 1), "ms_per_step": round(dtm * 1e3, 4), "batch": B,
+                                        "samples_per_step": int(mix_lens.sum())}
     mm.close()
     # the live ReadUntil shape: ~357 assessable reads per 512-channel batch, capped at the RNA004 maximum of 8615 samples
     # (riser/preprocess.py:36-37): 3 blocks of 4096 per read in the packed layout

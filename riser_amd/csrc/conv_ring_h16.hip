@@ -318,6 +318,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     // sub-stage's NDMA staging pieces of this wave, spread over the sub-stage's own passes.
     u32x4 keep_a[MT], keep_b[NT];
     auto deferred_pass = [&]() {
+#if defined(RS_X2_DROP) && RS_X2_DROP == 2     // measurement build: split precision without the x hi * w lo term
+        if constexpr (X3) return;
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -326,7 +329,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     auto substage = [&](auto TAP, int xb, bool have_prev, auto NDMA_, auto&& dma, auto&& between) {
         constexpr int tap = decltype(TAP)::value;
         constexpr int NDMA = decltype(NDMA_)::value;
+#if defined(RS_X2_DROP) && RS_X2_DROP == 1     // measurement build: split precision without the x lo * w hi term
+        constexpr int NM = MT * NT;
+#else
         constexpr int NM = (X3 ? 2 : 1) * MT * NT;                  // MFMAs of the passes executed here
+#endif
         constexpr int GAP = NM / (NDMA + 1) > 0 ? NM / (NDMA + 1) : 1;
         const unsigned ax0 = a_rd[tap][0] + (unsigned)(xb * XS), ax1 = a_rd[tap][1] + (unsigned)(xb * XS);
         u32x4 a0[MT], b0[NT], a1[MT], b1[NT];

@@ -281,9 +281,11 @@ def test_h16_streaming_layers_and_layer0_fold(dev, dtype):
 
 def test_config3_ensemble_split_precision_full_size(dev):
     """BASELINE config 3 at full size: the mRNA + mtRNA + globin stand-ins, 512 x 16000-sample chunks, one
-    rs_classify_ensemble call on the 16-bit MFMA in split precision (bf16x3).  Against the fp32 ensemble of the same
-    library on the same batch: every probability within 1e-3 and every accept / reject / try-again decision identical,
-    in both modes; and the single call equals three rs_classify calls + rs_decide bit for bit."""
+    rs_classify_ensemble call on the 16-bit MFMA in split precision (bf16x3).  Against the ORACLE on all 512 reads of all
+    three models: every probability within 1e-3, and every accept / reject / no-decision identical to the reference's
+    rule (riser/control.py:75-82, oracle decide()) applied to the oracle's probabilities, in both modes; the same against
+    the library's own fp32 ensemble; and the single call equals three rs_classify calls + rs_decide bit for bit."""
+    from conftest import oracle_bench_batch
     from riser_amd.model import Model, classify_raw_ensemble
     from riser_amd.preprocess import pack_reads
     B, L = 512, 16000
@@ -299,6 +301,13 @@ def test_config3_ensemble_split_precision_full_size(dev):
         p32 = classify_raw_ensemble(f32, sig, off, ln, lh, decision=dec32, max_len=L, threshold=0.9, mode=mode)
         assert float((p - p32).abs().max()) < 1e-3
         assert torch.equal(dec, dec32), int((dec != dec32).sum())
+        po = np.stack([oracle_bench_batch(k, "full") for k, _ in spec])                       # [3, 512, 2]
+        for probs in (p, p32):
+            assert np.abs(probs.cpu().numpy() - po).max() < 1e-3
+        want_dec = [ro.decide(list(po[:, b, 1]), list(po[:, b, 0]), 0.9, "enrich" if mode == nv.RS_ENRICH else "deplete", L, L)
+                    for b in range(B)]
+        got_dec = [nv.DECISION_NAMES[int(d)] for d in dec.cpu().numpy()]
+        assert got_dec == want_dec, sum(a != b for a, b in zip(got_dec, want_dec))
         assert torch.equal(p, torch.stack([m.classify_raw(sig, off, ln, lh) for m in x3]))
         counts = np.bincount(dec.cpu().numpy(), minlength=4)
         # a discriminating population: reads on both sides of the threshold (any model on-target: accepted when
@@ -406,9 +415,10 @@ def test_convnet_variants_against_reference(dev, golden_dir):
 
 def test_promethion_per_gpu_shape(dev):
     """BASELINE config 4, the per-GPU share: 18 000 x 16000-sample chunks resident in HBM, walked in sub-batches
-    (riser_amd.stream.classify_resident).  No oracle at this size, so: (a) a sample against the oracle, (b) bit
-    identity with direct library calls on arbitrary sub-ranges, (c) the population repeats 512 distinct signals, so
-    read i must give exactly the bits of read i mod 512 wherever it sits in whichever sub-batch."""
+    (riser_amd.stream.classify_resident): (a) the population repeats 512 distinct signals, so read i must give exactly
+    the bits of read i mod 512 wherever it sits in whichever sub-batch - and those 512 are ALL checked against the
+    oracle; (b) bit identity with direct library calls on arbitrary sub-ranges."""
+    from conftest import oracle_bench_batch
     from riser_amd.model import Model
     from riser_amd.stream import classify_resident
     sd = synth.make_state_dict(1)
@@ -423,10 +433,9 @@ def test_promethion_per_gpu_shape(dev):
     assert probs.shape == (1, N, 2) and np.isfinite(probs).all()
     p = probs[0]
     assert np.array_equal(p, p[idx % 512]), "a read's result depends on its position in the population"
-    pick = [0, 300, 511]
-    want = ro.classify_reads(sd, base[pick])
-    assert np.abs(p[pick] - want).max() < 1e-3
-    assert np.array_equal(p[pick, 1] > 0.9, want[:, 1] > 0.9)
+    oracle = oracle_bench_batch(1, "full")
+    assert np.abs(p[:512] - oracle).max() < 1e-4
+    assert np.array_equal(p[:512, 1] > 0.9, oracle[:, 1] > 0.9)
     lo, hi = 5000, 5100                                                # straddles no sub-batch boundary ...
     off = torch.arange(lo, hi, dtype=torch.int64, device=dev) * L
     ln = torch.full((hi - lo,), L, dtype=torch.int32, device=dev)

@@ -360,9 +360,10 @@ def test_split_precision_forward_vs_reference(dev, golden_dir, dtype):
 
 @pytest.mark.parametrize("dtype", ["bf16x3", "f16x3"])
 def test_split_precision_full_size_batch(dev, dtype):
-    """BASELINE config 3 / 5 shapes at full size: 512 x 16000 (and the mixed 2 s / 3 s / 4 s batch) in split precision
-    against the fp32 path of the same library run on the same batch (itself pinned to the reference above), plus the
-    size-independent properties: idempotence, sub-batch and read-order invariance, bit for bit."""
+    """BASELINE config 3 / 5 shapes at full size: 512 x 16000 (and the mixed 2 s / 3 s / 4 s batch) in split precision,
+    ALL 512 reads against the oracle (and against the library's own fp32 path), plus the size-independent properties:
+    idempotence, sub-batch and read-order invariance, bit for bit."""
+    from conftest import oracle_bench_batch
     from riser_amd.model import Model
     from riser_amd.preprocess import pack_reads
     B, L = 512, 16000
@@ -377,9 +378,11 @@ def test_split_precision_full_size_batch(dev, dtype):
             off = torch.from_numpy(np.arange(B, dtype=np.int64) * L).to(dev)
             ln = torch.from_numpy(lens).to(dev)
         got = m.classify_raw(sig, off, ln, lens).cpu().numpy()
+        oracle = oracle_bench_batch(1, name)
+        assert np.abs(got - oracle).max() < X3_TOL, (name, float(np.abs(got - oracle).max()))
+        assert np.array_equal(got[:, 1] > 0.9, oracle[:, 1] > 0.9), name
         want = ref.classify_raw(sig, off, ln, lens).cpu().numpy()
         assert np.abs(got - want).max() < X3_TOL, (name, float(np.abs(got - want).max()))
-        assert np.array_equal(got[:, 1] > 0.9, want[:, 1] > 0.9), name
         assert np.array_equal(got, m.classify_raw(sig, off, ln, lens).cpu().numpy())
         idx = torch.arange(100, 164, device=dev)
         part = m.classify_raw(sig, off[idx].contiguous(), ln[idx].contiguous(), lens[100:164]).cpu().numpy()
@@ -387,9 +390,6 @@ def test_split_precision_full_size_batch(dev, dtype):
         ridx = torch.arange(B - 1, -1, -1, device=dev)
         rev = m.classify_raw(sig, off[ridx].contiguous(), ln[ridx].contiguous(), lens[::-1].copy()).cpu().numpy()
         assert np.array_equal(rev[::-1], got)
-    pick = [0, 17, 255, 511]
-    oracle = ro.classify_reads(sd, [sigs[k][: lens[k]] for k in pick])
-    assert np.abs(got[pick] - oracle).max() < X3_TOL
     assert (got[:, 1] > 0.9).sum() > 10 and (got[:, 1] < 0.1).sum() > 10
     m.close()
 
@@ -504,10 +504,11 @@ def test_control_loop_golden(dev, proc, golden_dir, tmp_path):
 
 
 # ------------------------------------------------------------------------------------------
-# BASELINE-size properties (512 x 16000): no oracle at this size, so size-independent checks
+# BASELINE size (512 x 16000): every read against the oracle, and the size-independent properties
 # ------------------------------------------------------------------------------------------
 def test_full_size_batch_properties(dev):
     from riser_amd.preprocess import pack_reads
+    from conftest import oracle_bench_batch
     m = get_model(1, dev)
     B, L = 512, 16000
     sigs = synth.make_signals(SIG_SEED, B, L)
@@ -524,7 +525,11 @@ def test_full_size_batch_properties(dev):
     ridx = torch.arange(B - 1, -1, -1, device=dev)
     rev = m.classify_raw(sig, off[ridx].contiguous(), ln[ridx].contiguous(), lens[::-1].copy()).cpu().numpy()
     assert np.array_equal(rev[::-1], full)
-    # (d) a sample against the oracle
+    # (d) ALL 512 reads against the oracle (numpy normalise + torch-CPU conv stack), and four of them against the
+    # independent numpy restatement of the conv stack
+    oracle = oracle_bench_batch(1, "full")
+    assert np.abs(full - oracle).max() < PROB_TOL, float(np.abs(full - oracle).max())
+    assert np.array_equal(full[:, 1] > 0.9, oracle[:, 1] > 0.9)
     pick = [0, 17, 255, 511]
     want = ro.classify_reads(synth.make_state_dict(1), sigs[pick])
     assert np.abs(full[pick] - want).max() < PROB_TOL

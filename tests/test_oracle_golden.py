@@ -234,3 +234,20 @@ def test_winograd_f23_identity_matches_direct_block():
             want = ro.conv_block(x.astype(dt), w.astype(dt), b.astype(dt), acc=dt)
             assert got.shape == want.shape
             assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max())
+
+
+def test_batched_oracle_equals_per_read_oracle():
+    """oracle/torch_path.classify_batched (what the full-size GPU tests compare all 512 reads with) against the per-read
+    structure of riser/control.py:63-69 on mixed lengths: grouping by length changes nothing but torch's blocking."""
+    from oracle import torch_path
+    from riser_amd import synth
+    lens = [4096, 6024, 4096, 8615, 6024, 5000]
+    sigs = [synth.make_signals(20260103, 1, n, first_read=900 + i)[0] for i, n in enumerate(lens)]
+    cpu = torch_path.TorchCpuModel(synth.make_state_dict(2))
+    a = torch_path.classify_per_read(cpu, sigs)
+    b = torch_path.classify_batched(cpu, sigs, batch=2)
+    assert np.abs(a - b).max() < 2e-6
+    padded = np.zeros((len(lens), 9000), dtype=np.int16)
+    for i, s in enumerate(sigs):
+        padded[i, : len(s)] = s
+    assert np.array_equal(torch_path.classify_batched(cpu, padded, lens, batch=2), b)

@@ -10,11 +10,15 @@ B, L = int(os.environ.get("RS_B", 512)), int(os.environ.get("RS_L", 16000))
 sigs = synth.make_signals(20260103, B, L)
 dev = torch.device("cuda", 0)
 sig, off, ln, lens = pack_reads(list(sigs), dev)
-flops = []
-c_in, Li = 1, L
-for c in synth.CHANNELS:
-    flops.append(2.0 * c_in * c * 3 * Li * B)
-    c_in, Li = c, Li // 2
+if os.environ.get("RS_MIXED"):                       # 2 s / 3 s / 4 s thirds (BASELINE config 5)
+    lens = np.array([(L // 2, 3 * L // 4, L)[i % 3] for i in range(B)], dtype=np.int32)
+    ln = torch.from_numpy(lens).to(dev)
+flops = [0.0] * len(synth.CHANNELS)
+for n in lens:
+    c_in, Li = 1, int(n)
+    for i, c in enumerate(synth.CHANNELS):
+        flops[i] += 2.0 * c_in * c * 3 * Li
+        c_in, Li = c, Li // 2
 ref = None
 for dt in dts:
     m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dt)
