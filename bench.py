@@ -410,23 +410,35 @@ def side_variants(args, device, wl, ref):
 
 
 def control_loop_object(device, dtype):
-    """ReadUntil replay (riser_amd/replay.py): scripted 512-channel batches through the batched SequencerControl
-    with 1 and 3 models; what the 1 s decision window has to cover."""
+    """ReadUntil replay (riser_amd/replay.py): scripted AccumulatingCache traffic through the batched SequencerControl
+    with 1 and 3 models at 512 channels (MinION) and with 1 model at 18 000 channels (a PromethION-scale batch, the
+    per-GPU share of BASELINE config 4); what the 1 s decision window has to cover."""
     from riser_amd.model import Model
     from riser_amd.preprocess import Kit, SignalProcessor
     from riser_amd.replay import run_replay, scripted_batches
     proc = SignalProcessor(Kit.create_from_version("RNA004"), device=device)
-    batches = scripted_batches(43, 512)
+    batches = scripted_batches(210, 512)
     out = {"kit": "RNA004", "channels": 512, "dtype": dtype, "window_s": 1.0,
            "note": "host wall time per ReadUntil batch from get_read_batch() to the reject / finish calls "
-                   "(riser/control.py:31-106): upload, poly(A) scan, gating, normalise, one forward per model, decision, "
-                   "CSV rows; first 3 batches dropped as warm-up"}
+                   "(riser/control.py:31-106): upload of the new samples of every read, poly(A) scan, gating, normalise, one "
+                   "forward per model, decision, CSV rows; first 3 batches dropped as warm-up.  Traffic: every channel "
+                   "re-sends its read whole, 1600 samples longer per batch (AccumulatingCache, riser/client.py:29-31)"}
+    spec = list(zip((1, 2, 3), ("mRNA", "mtRNA", "globin")))
     for n_models in (1, 3):
-        models = [Model(synth.make_state_dict(s), synth.Config(), None, t, dtype=dtype, device=device)
-                  for s, t in list(zip((1, 2, 3), ("mRNA", "mtRNA", "globin")))[:n_models]]
+        models = [Model(synth.make_state_dict(s), synth.Config(), None, t, dtype=dtype, device=device) for s, t in spec[:n_models]]
         out[f"models_{n_models}"] = run_replay(models, proc, batches)
+        if n_models == 1:
+            # the same replay with every read re-uploaded whole each batch (no device-resident signals): what the
+            # signal store saves (SURVEY.md 8(f) N3, the part of it that pays)
+            out["models_1_full_reupload"] = run_replay(models, proc, batches, signal_cache=False)
         for m in models:
             m.close()
+    del batches
+    big = scripted_batches(14, 18000)
+    models = [Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dtype, device=device)]
+    out["promethion_18000_channels"] = run_replay(models, proc, big)
+    out["promethion_18000_channels_full_reupload"] = run_replay(models, proc, big, signal_cache=False)
+    models[0].close()
     return out
 
 

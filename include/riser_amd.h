@@ -226,6 +226,16 @@ int rs_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, i
 int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B,
                  int32_t* d_end, void* stream);
 
+/*
+ * Scatter n segments of raw samples between device buffers: segment k = d_src[d_src_off[k] .. + d_len[k]) is copied to
+ * d_dst[d_dst_off[k] ..) (offsets in samples).  The batched control loop keeps the raw signal of every read in flight
+ * resident on the device: an AccumulatingCache client (riser/client.py:29-31) re-sends a read's whole signal with every
+ * batch, and only the samples that are new since the last batch are uploaded (compacted, one transfer) and scattered
+ * behind the ones already there.
+ */
+int rs_copy_segments(const int16_t* d_src, int16_t* d_dst, const int64_t* d_src_off, const int64_t* d_dst_off,
+                     const int32_t* d_len, int n, void* stream);
+
 /* Introspection used by bench.py for roofline accounting: per conv layer i (0-based),
  * fills the padded GEMM shape the kernels execute.  Returns RS_ERR_ARG if out of range. */
 typedef struct rs_layer_info {

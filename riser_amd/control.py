@@ -6,13 +6,18 @@ order as the reference.  The difference is the shape of the work: the reference 
 (<= 512) reads of a ReadUntil batch one at a time - trim, normalise, one forward per model at
 batch 1, a device sync per probability (riser/control.py:31-93,152) - whereas this loop
 
-  1. uploads the raw int16 signals of the whole batch once,
+  1. keeps the raw int16 signal of every read in flight RESIDENT ON THE DEVICE, one row per channel: an
+     AccumulatingCache client (riser/client.py:29-31) re-sends a read's whole signal with every batch, and only the
+     samples that are new since the last batch cross PCIe (one compacted transfer + one scatter launch),
   2. finds the poly(A) ends of all un-cached reads in one kernel launch,
-  3. applies the reference's length gating on the host (pure index arithmetic: a trim is an
-     offset into the uploaded buffer, a truncation is a length),
+  3. applies the reference's length gating on the host as array arithmetic (a trim is an offset into the resident
+     signal, a truncation is a length),
   4. normalises every assessable read once and runs one batched forward per model,
   5. takes the ensemble decision on the device and copies probabilities + decisions back in
-     a single transfer.
+     a single synchronisation.
+
+Host work per batch is numpy over arrays of the batch's reads; the only per-read Python is what the client's own
+interface forces (one `get_raw_signal` call and one `read.id` per read) and the text of the CSV rows.
 
 The polyA cache only memoises a deterministic prefix property of a read, so its state
 never changes results; it is cleared at batch granularity once it holds >= 1000 entries
@@ -28,7 +33,6 @@ import torch
 
 from . import _native as nv
 from .model import classify_raw_ensemble
-from .preprocess import pack_reads
 
 _MODE = {"enrich": nv.RS_ENRICH, "deplete": nv.RS_DEPLETE}
 
@@ -65,14 +69,158 @@ class _MinuteTally:
         self.due = batch_start + 60
 
 
+class _Pinned:
+    """Grow-only pinned host scratch, handed out in aligned pieces and reset once per batch: the small index arrays of a
+    batch go to the device as asynchronous copies from here (a pageable source makes every copy a blocking one)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+        self.used = 0
+
+    def reset(self, need: int):
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = torch.empty(max(need, 1 << 16), dtype=torch.uint8).pin_memory()
+        self.used = 0
+
+    def to_device(self, arr: np.ndarray) -> torch.Tensor:
+        """arr (contiguous) -> device tensor of the same dtype, copied asynchronously on the current stream"""
+        nb = arr.nbytes
+        at = self.used
+        self.used = (at + nb + 63) & ~63
+        if self.used > self.buf.numel():                         # not reserved for: fall back to a blocking copy
+            return torch.from_numpy(arr).to(self.device)
+        host = self.buf[at: at + nb].view(torch.from_numpy(arr[:0]).dtype)
+        host.numpy()[:] = arr
+        return host.to(self.device, non_blocking=True)
+
+
+class _SignalStore:
+    """Raw int16 signals of a batch on the device -> per-read offsets into one device buffer.
+
+    resident=True: one row of `pitch` samples per channel holds the read currently in that pore; a read that was
+    already there (same id, not shorter) uploads only the samples behind what the row holds.  The client contract this
+    relies on is AccumulatingCache's: the same read id always carries the same signal prefix (riser/client.py:29-31).
+    Reads longer than a row are uploaded whole into a spill area behind the rows.
+    resident=False: every batch uploads every read whole (the round-2 behaviour; kept for the A/B in bench.py)."""
+
+    def __init__(self, device, resident: bool = True, pitch: int = 32768):
+        self.device, self.resident, self.pitch = device, resident, int(pitch)
+        self.rowmap = np.full(1024, -1, dtype=np.int64)          # channel -> row
+        self.n_rows = 0
+        self.row_hash = np.zeros(0, dtype=np.int64)              # hash(read id) of the read a row holds
+        self.row_have = np.zeros(0, dtype=np.int64)              # samples of it on the device
+        self.cap_rows = 0
+        self.spill_cap = 0
+        self.buf = None                                          # int16 [cap_rows * pitch + spill_cap]
+        self.stage = None                                        # pinned int16 staging of one batch's new samples
+        self.stage_dev = None
+        self.samples_uploaded = 0                                # statistics: what crossed PCIe / what a full re-upload
+        self.samples_presented = 0                               # of every batch would have carried
+
+    def _ensure(self, rows: int, spill: int):
+        if self.buf is not None and rows <= self.cap_rows and spill <= self.spill_cap:
+            return
+        new_rows = max(rows, self.cap_rows * 2 if rows > self.cap_rows else self.cap_rows, 512 if self.resident else 0)
+        new_spill = max(spill, self.spill_cap * 2 if spill > self.spill_cap else self.spill_cap, 1 << 20)
+        buf = torch.zeros(new_rows * self.pitch + new_spill, dtype=torch.int16, device=self.device)
+        if self.buf is not None and self.cap_rows:
+            buf[: self.cap_rows * self.pitch].copy_(self.buf[: self.cap_rows * self.pitch])
+        self.buf, self.cap_rows, self.spill_cap = buf, new_rows, new_spill
+
+    def _stage(self, n: int):
+        if self.stage is None or self.stage.numel() < n:
+            cap = max(n, 1 << 20, 0 if self.stage is None else self.stage.numel() * 2)
+            self.stage = torch.empty(cap, dtype=torch.int16).pin_memory()
+            self.stage_dev = torch.empty(cap, dtype=torch.int16, device=self.device)
+        return self.stage.numpy()
+
+    def update(self, channels: np.ndarray, ids, raws, lens: np.ndarray, pinned: _Pinned) -> np.ndarray:
+        """-> int64 [B]: offset of every read's first sample in self.buf"""
+        B = len(raws)
+        self.samples_presented += int(lens.sum())
+        # the staging buffers below are re-used: whatever the previous batch still has in flight must have landed
+        torch.cuda.current_stream(self.device).synchronize()
+        if not self.resident:
+            total = int(lens.sum())
+            offs = np.zeros(B, dtype=np.int64)
+            np.cumsum(lens[:-1], out=offs[1:])
+            self._ensure(0, total)
+            stage = self._stage(total)
+            np.concatenate(raws, out=stage[:total])
+            self.buf[:total].copy_(self.stage[:total], non_blocking=True)
+            self.samples_uploaded += total
+            return offs
+        # ---- rows: one per channel, assigned at first sight ---------------------------------------------------------
+        cmax = int(channels.max())
+        if cmax >= self.rowmap.shape[0]:
+            grown = np.full(max(cmax + 1, 2 * self.rowmap.shape[0]), -1, dtype=np.int64)
+            grown[: self.rowmap.shape[0]] = self.rowmap
+            self.rowmap = grown
+        rows = self.rowmap[channels]
+        fresh = np.flatnonzero(rows < 0)
+        if fresh.size:
+            uniq, first = np.unique(channels[fresh], return_index=True)     # a channel appears once per batch, but be safe
+            self.rowmap[uniq] = self.n_rows + np.arange(uniq.size)
+            self.n_rows += int(uniq.size)
+            self.row_hash = np.concatenate([self.row_hash, np.zeros(uniq.size, dtype=np.int64)])
+            self.row_have = np.concatenate([self.row_have, np.zeros(uniq.size, dtype=np.int64)])
+            rows = self.rowmap[channels]
+        hashes = np.fromiter(map(hash, ids), dtype=np.int64, count=B)
+        fits = lens <= self.pitch
+        if np.unique(rows).size != B:                               # two reads of one channel in one batch: nothing resident
+            fits = np.zeros(B, dtype=bool)
+        same = fits & (self.row_hash[rows] == hashes) & (self.row_have[rows] <= lens) & (self.row_have[rows] > 0)
+        start = np.where(same, self.row_have[rows], 0)
+        seg_len = lens - start
+        # reads longer than a row: whole, into the spill area, nothing remembered
+        spill_len = np.where(fits, 0, lens)
+        spill_off = np.zeros(B, dtype=np.int64)
+        np.cumsum(spill_len[:-1], out=spill_off[1:])
+        self._ensure(self.n_rows, int(spill_len.sum()))
+        spill_base = self.cap_rows * self.pitch
+        dst = np.where(fits, rows * self.pitch + start, spill_base + spill_off)
+        self.row_hash[rows[fits]] = hashes[fits]
+        self.row_have[rows[fits]] = lens[fits]
+        self.row_have[rows[~fits]] = 0
+        # ---- the new samples, compacted: one transfer, one scatter ------------------------------------------------
+        total = int(seg_len.sum())
+        self.samples_uploaded += total
+        if total:
+            src = np.zeros(B, dtype=np.int64)
+            np.cumsum(seg_len[:-1], out=src[1:])
+            stage = self._stage(total)
+            st = start.tolist()
+            np.concatenate([r[s:] for r, s in zip(raws, st)], out=stage[:total])
+            self.stage_dev[:total].copy_(self.stage[:total], non_blocking=True)
+            live = np.flatnonzero(seg_len > 0)
+            d_src = pinned.to_device(np.ascontiguousarray(src[live]))
+            d_dst = pinned.to_device(np.ascontiguousarray(dst[live]))
+            d_len = pinned.to_device(np.ascontiguousarray(seg_len[live].astype(np.int32)))
+            nv.check(nv.lib().rs_copy_segments(self.stage_dev.data_ptr(), self.buf.data_ptr(), d_src.data_ptr(),
+                                               d_dst.data_ptr(), d_len.data_ptr(), int(live.size),
+                                               torch.cuda.current_stream(self.device).cuda_stream), "rs_copy_segments")
+        return np.where(fits, rows * self.pitch, spill_base + spill_off)
+
+
 class SequencerControl:
-    def __init__(self, client, models, processor, logger, out_file):
+    def __init__(self, client, models, processor, logger, out_file, signal_cache: bool = True):
+        """signal_cache=False re-uploads every read whole with every batch (no device-resident signals)."""
         self.client, self.models, self.proc, self.logger = client, models, processor, logger
         self.out_filename = out_file
         # host wall time of the most recent assessed batches (seconds): bounded, a run lasts tens of hours
         self.batch_latencies = deque(maxlen=4096)
+        self._store = _SignalStore(processor.device, resident=signal_cache)
+        self._pinned = _Pinned(processor.device)
+        self._res_probs = self._res_dec = None
 
     # ------------------------------------------------------------------------------------
+    def reserve(self, reads: int):
+        """Allocate the models' workspaces for batches of up to `reads` assessable reads now, so that no batch of the run
+        pays for a device allocation (a growing workspace is a multi-GB hipMalloc + hipFree inside a 1 s window)."""
+        from .model import reserve_ensemble
+        reserve_ensemble(self.models, int(reads), self.proc.get_max_length())
+
     def assess_batch(self, entries, mode, threshold, polyA_cache):
         """entries: list of (channel, read).  Returns one record per ASSESSED read, in
         batch order: (channel, read, sig_length, [p_on per model], decision str)."""
@@ -80,66 +228,69 @@ class SequencerControl:
             return []
         proc = self.proc
         dev = proc.device
-        signals = [self.client.get_raw_signal(read) for _, read in entries]
-        sig, off, ln, lens = pack_reads(signals, dev)
-        offs_host = np.zeros(len(signals), dtype=np.int64)
-        if len(signals) > 1:
-            offs_host[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+        B = len(entries)
+        reads = [e[1] for e in entries]
+        channels = np.fromiter((e[0] for e in entries), dtype=np.int64, count=B)
+        ids = [r.id for r in reads]
+        get = self.client.get_raw_signal
+        raws = [get(r) for r in reads]
+        if raws[0].dtype != np.int16:
+            from .preprocess import _as_int16
+            raws = [_as_int16(s) for s in raws]
+        lens = np.fromiter((s.shape[0] for s in raws), dtype=np.int64, count=B)
+        self._pinned.reset(64 * B + (1 << 12))
+        offs = self._store.update(channels, ids, raws, lens, self._pinned)
+        sig = self._store.buf
 
         # -- poly(A) end for reads not in the cache: one launch -------------------------------
-        need = [i for i, (_, read) in enumerate(entries) if read.id not in polyA_cache]
-        ends = {}
-        if need:
-            idx = torch.from_numpy(np.asarray(need, dtype=np.int64)).to(dev)
-            found = proc.polyA_end_device(sig, off[idx].contiguous(), ln[idx].contiguous(), len(need)).cpu().numpy()
-            for i, e in zip(need, found):
-                ends[i] = int(e)
+        cget = polyA_cache.get
+        end = np.fromiter((cget(i, 0) for i in ids), dtype=np.int64, count=B)
+        need = np.flatnonzero(end == 0)
+        if need.size:
+            d_off = self._pinned.to_device(np.ascontiguousarray(offs[need]))
+            d_len = self._pinned.to_device(lens[need].astype(np.int32))
+            found = proc.polyA_end_device(sig, d_off, d_len, int(need.size)).cpu().numpy().astype(np.int64)
+            hit = np.flatnonzero(found > 0)
+            end[need[hit]] = found[hit]
+            for j in hit.tolist():
+                polyA_cache[ids[need[j]]] = int(found[j])
 
         # -- gating (riser/control.py:36-60) as offsets / lengths ------------------------------
         max_len, min_len = proc.get_max_length(), proc.get_min_length()
         fixed = proc.get_fixed_trim_length()
-        sel, a_off, a_len = [], [], []
-        for i, (_, read) in enumerate(entries):
-            n = int(lens[i])
-            if read.id in polyA_cache:
-                end = polyA_cache[read.id]
-            else:
-                end = ends[i] if ends[i] > 0 else None
-                if end:
-                    polyA_cache[read.id] = end
-            if not end:
-                if n > fixed + max_len:                              # should_trim_fixed_length
-                    start, length = fixed, min(n - fixed, max_len)
-                else:
-                    continue
-            else:
-                start, length = end + 1, n - (end + 1)
-                if length < min_len:
-                    continue
-                length = min(length, max_len)
-            sel.append(i)
-            a_off.append(int(offs_host[i]) + start)
-            a_len.append(length)
-        if not sel:
+        has = end > 0
+        start = np.where(has, end + 1, fixed)
+        length = lens - start
+        ok = np.where(has, length >= min_len, lens > fixed + max_len)       # :53-56 / should_trim_fixed_length :39-50
+        sel = np.flatnonzero(ok)
+        if sel.size == 0:
             return []
+        lens_a = np.minimum(length[sel], max_len).astype(np.int32)
 
         # -- normalise once, one batched forward per model, decision on the device -------------
-        B = len(sel)
-        lens_a = np.asarray(a_len, dtype=np.int32)
-        off_d = torch.from_numpy(np.asarray(a_off, dtype=np.int64)).to(dev)
-        len_d = torch.from_numpy(lens_a).to(dev)
-        # one library call: normalise once, one forward per model, decision on the device
-        dec = torch.empty(B, dtype=torch.uint8, device=dev)
-        probs = classify_raw_ensemble(self.models, sig, off_d, len_d, lens_a, decision=dec, max_len=max_len,
-                                      threshold=threshold, mode=_MODE[mode])
-        probs_h = probs.cpu().numpy()
-        dec_h = dec.cpu().numpy()
-        out = []
-        for j, i in enumerate(sel):
-            channel, read = entries[i]
-            out.append((channel, read, int(lens_a[j]), [probs_h[m, j, 1] for m in range(len(self.models))],
-                        nv.DECISION_NAMES[int(dec_h[j])]))
-        return out
+        n_sel, n_models = int(sel.size), len(self.models)
+        off_d = self._pinned.to_device(np.ascontiguousarray(offs[sel] + start[sel]))
+        len_d = self._pinned.to_device(lens_a)
+        if self._res_probs is None or self._res_probs.dev.shape[1] < n_sel or self._res_probs.dev.shape[0] != n_models:
+            cap = max(n_sel, 512)
+            self._res_probs = _Pair(torch.empty((n_models, cap, 2), dtype=torch.float32, device=dev),
+                                    torch.empty((n_models, cap, 2), dtype=torch.float32).pin_memory())
+            self._res_dec = _Pair(torch.empty(cap, dtype=torch.uint8, device=dev),
+                                  torch.empty(cap, dtype=torch.uint8).pin_memory())
+        probs_d = self._res_probs.dev.view(-1)[: n_models * n_sel * 2].view(n_models, n_sel, 2)
+        dec_d = self._res_dec.dev[:n_sel]
+        classify_raw_ensemble(self.models, sig, off_d, len_d, lens_a, out=probs_d, decision=dec_d, max_len=max_len,
+                              threshold=threshold, mode=_MODE[mode])
+        probs_p = self._res_probs.host.view(-1)[: n_models * n_sel * 2].view(n_models, n_sel, 2)
+        dec_p = self._res_dec.host[:n_sel]
+        probs_p.copy_(probs_d, non_blocking=True)
+        dec_p.copy_(dec_d, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        p_on = probs_p.numpy()[:, :, 1].T.astype(np.float64).tolist()          # [read][model]
+        dec_h = dec_p.numpy().tolist()
+        names = nv.DECISION_NAMES
+        return [(int(channels[i]), reads[i], n, p, names[d])
+                for i, n, p, d in zip(sel.tolist(), lens_a.tolist(), p_on, dec_h)]
 
     # ------------------------------------------------------------------------------------
     def target(self, mode, duration_h, threshold, unblock_duration=0.1):
@@ -168,12 +319,17 @@ class SequencerControl:
         t0 = time.monotonic()
         records = self.assess_batch(list(self.client.get_read_batch()), mode, threshold, cache)
         decided = {"reject": [], "accept": [], "no_decision": []}          # "try_again" reads stay with the client
-        targets = ";".join(m.target for m in self.models)
-        for channel, read, n_samples, p_on, decision in records:
-            if decision in decided:
-                decided[decision].append((channel, self._client_key(read)))
-            probs = ";".join(str(float(p)) for p in p_on)
-            sink.write(f"{t0:.0f},{read.id},{channel},{n_samples},{targets},{probs},{threshold},{mode},{decision}\n")
+        if records:
+            head = f"{t0:.0f},"
+            tail = "," + ";".join(m.target for m in self.models) + ","
+            tail2 = f",{threshold},{mode},"
+            key = self._client_key
+            lines = []
+            for channel, read, n_samples, p_on, decision in records:
+                if decision in decided:
+                    decided[decision].append((channel, key(read)))
+                lines.append(f"{head}{read.id},{channel},{n_samples}{tail}{';'.join(map(str, p_on))}{tail2}{decision}")
+            sink.write("\n".join(lines) + "\n")
         if len(cache) >= _CACHE_LIMIT:
             cache = {}
         self.client.reject_reads(decided["reject"], unblock_duration)
@@ -197,3 +353,10 @@ class SequencerControl:
         """What the ReadUntil client identifies a read by: minknow-api <= v5 has `.number`, >= v6 only `.id`
         (riser/control.py:137-143)."""
         return read.number if hasattr(read, "number") else read.id
+
+
+class _Pair:
+    """a device tensor and its pinned host twin"""
+
+    def __init__(self, dev, host):
+        self.dev, self.host = dev, host

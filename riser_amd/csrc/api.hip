@@ -909,6 +909,15 @@ int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
     return launch_polya(d_sig, d_off, d_len, B, d_end, static_cast<hipStream_t>(stream));
 }
 
+int rs_copy_segments(const int16_t* d_src, int16_t* d_dst, const int64_t* d_src_off, const int64_t* d_dst_off,
+                     const int32_t* d_len, int n, void* stream) {
+    if (n < 0 || (n > 0 && (!d_src || !d_dst || !d_src_off || !d_dst_off || !d_len))) {
+        set_error("rs_copy_segments: null argument");
+        return RS_ERR_ARG;
+    }
+    return launch_copy_segments(d_src, d_dst, d_src_off, d_dst_off, d_len, n, static_cast<hipStream_t>(stream));
+}
+
 int rs_debug_capture_layer(rs_model* m, int layer, void* d_dst, size_t bytes) {
     if (!m) {
         set_error("rs_debug_capture_layer: null model");

@@ -197,5 +197,7 @@ int launch_decide(const float* d_probs, int n_models, int B, const int32_t* d_le
 
 int launch_polya(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B,
                  int32_t* d_end, hipStream_t st);
+int launch_copy_segments(const int16_t* d_src, int16_t* d_dst, const int64_t* d_src_off, const int64_t* d_dst_off,
+                         const int32_t* d_len, int n, hipStream_t st);
 
 }  // namespace rs

@@ -118,7 +118,28 @@ __global__ __launch_bounds__(256) void polya_kernel(const int16_t* __restrict__ 
     if (tid == 0) out[b] = state[1] > 0 ? state[1] : -1;
 }
 
+// segment k: src[src_off[k] .. + len[k]) -> dst[dst_off[k] ..); one workgroup per segment, 2-byte elements (the segments
+// of a signal cache start at arbitrary sample positions)
+__global__ __launch_bounds__(256) void copy_segments_kernel(const int16_t* __restrict__ src, int16_t* __restrict__ dst,
+                                                            const int64_t* __restrict__ src_off,
+                                                            const int64_t* __restrict__ dst_off,
+                                                            const int32_t* __restrict__ len) {
+    const int k = blockIdx.x;
+    const int16_t* s = src + src_off[k];
+    int16_t* d = dst + dst_off[k];
+    const int n = len[k];
+    for (int i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+}
+
 }  // namespace
+
+int launch_copy_segments(const int16_t* d_src, int16_t* d_dst, const int64_t* d_src_off, const int64_t* d_dst_off,
+                         const int32_t* d_len, int n, hipStream_t st) {
+    if (n <= 0) return RS_OK;
+    hipLaunchKernelGGL(copy_segments_kernel, dim3(n), dim3(256), 0, st, d_src, d_dst, d_src_off, d_dst_off, d_len);
+    RS_HIP(hipGetLastError());
+    return RS_OK;
+}
 
 int launch_polya(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int32_t* d_end,
                  hipStream_t st) {

@@ -14,9 +14,14 @@ class FakeRead:
     """Shape of a ReadUntil read chunk: `.id`, `.raw_data` (bytes) and, for
     minknow-api <= 5, `.number` (riser/control.py:137-143)."""
 
-    def __init__(self, read_id: str, signal: np.ndarray, number=None):
+    def __init__(self, read_id: str, signal, number=None):
+        """signal: an int16 array (copied into bytes, as MinKNOW delivers them) or a bytes-like object that already
+        holds little-endian int16 samples (kept as is: the replay harness hands out memoryview slices of one buffer)"""
         self.id = read_id
-        self.raw_data = np.ascontiguousarray(signal, dtype=np.int16).tobytes()
+        if isinstance(signal, (bytes, bytearray, memoryview)):
+            self.raw_data = signal
+        else:
+            self.raw_data = np.ascontiguousarray(signal, dtype=np.int16).tobytes()
         if number is not None:
             self.number = number
 

@@ -206,6 +206,13 @@ class Model:
             return 1 << 30
         return max(1, nv.lib().rs_max_batch(self._h, int(lmax)))
 
+    def reserve(self, B: int, lmax: int):
+        """Allocate the workspace of the current stream for batches of up to B reads of up to lmax samples now (a
+        growing workspace is a device allocation inside some later call)."""
+        if self._h is not None:
+            B = max(1, min(int(B), self.max_batch(lmax)))
+            self._ws.get(nv.lib().rs_workspace_bytes(self._h, B, int(lmax)))
+
     def _check_lengths(self, lens_host: np.ndarray):
         if lens_host.size == 0:
             raise ValueError("empty batch")
@@ -339,6 +346,15 @@ def _autotune(self, sig_dev: torch.Tensor, off_dev: torch.Tensor, len_dev: torch
 
 
 Model.autotune = _autotune
+
+
+def reserve_ensemble(models, B: int, lmax: int):
+    """The workspace classify_raw_ensemble will ask for (it lives with models[0]), allocated ahead of the run."""
+    m0 = models[0]
+    if any(m._h is None for m in models):
+        return
+    B = max(1, min(int(B), min(m.max_batch(lmax) for m in models)))
+    m0._ws.get(max(nv.lib().rs_workspace_bytes(m._h, B, int(lmax)) for m in models))
 
 
 def classify_raw_ensemble(models, sig_dev: torch.Tensor, off_dev: torch.Tensor, len_dev: torch.Tensor,

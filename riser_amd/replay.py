@@ -24,33 +24,51 @@ from . import synth
 from .fake_client import FakeClient, FakeRead
 
 
-def scripted_batches(n_batches: int, channels: int = 512, seed: int = 4242, min_len: int = 5000,
+SAMPLES_PER_BATCH = 1600          # what a pore adds between two ReadUntil batches: 0.4 s at RNA004's 4 kHz
+VISITS = 5                         # batches a read stays in its pore before the next one takes the channel
+
+
+def scripted_batches(n_batches: int, channels: int = 512, seed: int = 4242, min_len: int = 7000,
                      max_len: int = 22000, pool_reads: int | None = None):
-    """-> list of n_batches lists of (channel, FakeRead)."""
+    """-> list of n_batches lists of (channel, FakeRead).
+
+    The traffic of an AccumulatingCache client (riser/client.py:29-31, `get_read_chunks(last=True)`): every channel
+    holds one read at a time and re-sends it WHOLE with every batch, SAMPLES_PER_BATCH samples longer than the batch
+    before, for VISITS batches; channels are staggered so every batch carries reads of every age.  Reads come from a
+    pool of synthetic raw reads (adapter + poly(A) plateau + RNA squiggle, synth.make_raw_read); a read's id is unique
+    to its (channel, turn), and its raw_data is a memoryview of the pool (no copies, so PromethION-scale batches of
+    18 000 channels stay cheap to script)."""
     rng = np.random.default_rng(7)
-    pool_reads = pool_reads or channels * 2
+    pool_reads = pool_reads or min(2 * channels, 1024)
     pool = []
     for rid in range(pool_reads):
         n = int(rng.integers(min_len, max_len))
-        pool.append(synth.make_raw_read(seed, rid, n, polya=(rid % 5 != 0)))
+        sig = synth.make_raw_read(seed, rid, n, polya=(rid % 5 != 0))
+        pool.append((memoryview(np.ascontiguousarray(sig, dtype=np.int16).tobytes()), n))
     batches = []
     for b in range(n_batches):
         reads = []
         for ch in range(channels):
-            rid = (b * 37 + ch) % len(pool)
-            reads.append((ch + 1, FakeRead(f"read-{b // 4}-{rid}", pool[rid])))
+            age = (b + ch) % VISITS                              # batches this read has been in the pore
+            turn = (b + ch) // VISITS
+            raw, n = pool[(turn * channels + ch) % pool_reads]
+            seen = min(n, n - (VISITS - 1 - age) * SAMPLES_PER_BATCH)
+            seen = max(seen, min(n, 2000))
+            reads.append((ch + 1, FakeRead(f"read-{turn}-{ch}", raw[: 2 * seen])))
         batches.append(reads)
     return batches
 
 
-def run_replay(models, processor, batches, mode: str = "enrich", threshold: float = 0.9, skip: int = 3) -> dict:
+def run_replay(models, processor, batches, mode: str = "enrich", threshold: float = 0.9, skip: int = 3,
+               signal_cache: bool = True) -> dict:
     """Drive SequencerControl.target over `batches`; returns counts and per-batch latency percentiles
-    (the first `skip` batches are warm-up: workspace allocation, first launches)."""
+    (the first `skip` batches are warm-up: first launches, the signal store's first fill)."""
     from .control import SequencerControl
     client = FakeClient(batches)
     with tempfile.TemporaryDirectory() as d:
         ctl = SequencerControl(client, models, processor, logging.getLogger("riser_amd.replay"),
-                               os.path.join(d, "out"))
+                               os.path.join(d, "out"), signal_cache=signal_cache)
+        ctl.reserve(max(len(b) for b in batches))
         ctl.start()
         t0 = time.perf_counter()
         ctl.target(mode, 1.0, threshold)
@@ -67,5 +85,8 @@ def run_replay(models, processor, batches, mode: str = "enrich", threshold: floa
             "assessed_per_batch": round(rows / max(len(batches), 1), 1),
             "wall_s": round(wall, 3), "assessed_per_s": round(rows / wall, 1),
             "p50_ms": round(float(np.percentile(lat, 50)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
-            "max_ms": round(float(lat.max()), 3),
+            "max_ms": round(float(lat.max()), 3), "latency_samples": int(lat.size),
+            "signal_cache": bool(signal_cache),
+            "pcie_samples_uploaded": int(ctl._store.samples_uploaded),
+            "pcie_samples_full_reupload": int(ctl._store.samples_presented),
             "rejected": sum(len(r) for r in client.rejected), "finished": sum(len(r) for r in client.finished)}

@@ -504,3 +504,63 @@ def test_other_channel_widths_all_modes(dev, channels):
         part = m.classify_raw(sig, off[idx].contiguous(), ln[idx].contiguous(), lh[[5, 0, 3]]).cpu().numpy()
         assert np.array_equal(part, got[[5, 0, 3]]), (dtype, channels)
         m.close()
+
+
+def test_control_loop_signal_store_and_scale(dev, tmp_path):
+    """the device-resident signal store (a re-seen read uploads only its new samples) changes nothing but the PCIe
+    bytes: the replay of AccumulatingCache traffic writes the same CSV, sends the same reject / finish lists with and
+    without it; a depth-2 ConvNet (generic conv program) runs through the same loop; and an 18 000-channel batch
+    (PromethION scale) goes through SequencerControl."""
+    from riser_amd import Kit, Model, SequencerControl, SignalProcessor
+    from riser_amd.replay import scripted_batches
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    models = [Model(synth.make_state_dict(s), synth.Config(), None, f"t{s}", device=dev) for s in (1, 2)]
+    batches = scripted_batches(7, 96)
+    # a read longer than a row of the store, a channel number beyond the first map, an id that changes mid-way
+    long_read = FakeRead("long", synth.make_raw_read(5, 5, 40000, True))
+    batches[2].append((3000, long_read))
+    batches[3].append((3000, long_read))
+    outs = []
+    for k, cache in enumerate((True, False)):
+        client = FakeClient(batches)
+        ctl = SequencerControl(client, models, proc, logging.getLogger("c"), str(tmp_path / f"s{k}"), signal_cache=cache)
+        ctl.reserve(128)
+        ctl.start(); ctl.target("enrich", 0.5, 0.9); ctl.finish()
+        rows = [ln.split(",", 1)[1] for ln in open(str(tmp_path / f"s{k}.csv")).read().strip().split("\n")[1:]]
+        outs.append((rows, client.rejected, client.finished, ctl._store.samples_uploaded, ctl._store.samples_presented))
+    assert outs[0][:3] == outs[1][:3] and len(outs[0][0]) > 200
+    assert outs[1][3] == outs[1][4] and outs[0][3] < 0.45 * outs[0][4]          # most samples never cross PCIe twice
+    # against the oracle's per-read loop (riser/control.py:31-97 restated): rows and lists
+    cpu_models = {s: torch_path.TorchCpuModel(synth.make_state_dict(s)) for s in (1, 2)}
+    want_rows, want_rej, want_fin = _oracle_loop(batches[:3], "RNA004", (1, 2), "enrich", 0.9, cpu_models)
+    got = [r.split(",") for r in outs[0][0][: len(want_rows)]]
+    for g, w in zip(got, want_rows):
+        assert (g[0], int(g[1]), int(g[2])) == w[:3]
+        assert np.allclose([float(v) for v in g[4].split(";")], w[4], atol=1e-3)
+    for m in models:
+        m.close()
+    # a generic conv program (depth 2) in the loop: classify_raw_ensemble falls back to one call per model + rs_decide
+    import json
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "convnet_variants.npz"))
+    vcfg = json.loads(str(g["depth2_k5373.cfg"]))
+    vsd = {k[len("depth2_k5373") + 4:]: g[k] for k in g.files if k.startswith("depth2_k5373.sd.")}
+    cfg = synth.Config(synth.CnnConfig(channels=vcfg["channels"], kernels=vcfg["kernels"], depth=vcfg["depth"]))
+    deep = Model(vsd, cfg, None, "deep", device=dev)
+    with pytest.raises(ValueError):
+        Model(vsd, cfg, None, "deep", dtype="f16", device=dev)            # the generic program is fp32 only
+    with pytest.raises(NotImplementedError):
+        deep.layer_info()
+    client = FakeClient(batches[:2])
+    ctl = SequencerControl(client, [deep], proc, logging.getLogger("c"), str(tmp_path / "deep"))
+    ctl.start(); ctl.target("deplete", 0.5, 0.9); ctl.finish()
+    assert open(str(tmp_path / "deep.csv")).read().count("\n") > 40
+    deep.close()
+    # PromethION scale: 18 000 channels in one ReadUntil batch
+    m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", device=dev)
+    big = scripted_batches(2, 18000)
+    client = FakeClient(big)
+    ctl = SequencerControl(client, [m], proc, logging.getLogger("c"), str(tmp_path / "big"))
+    ctl.start(); ctl.target("enrich", 0.5, 0.9); ctl.finish()
+    n_rows = open(str(tmp_path / "big.csv")).read().count("\n") - 1
+    assert n_rows > 10000 and len(client.finished) == 2
+    m.close()

@@ -19,13 +19,14 @@ def main():
     ap.add_argument("--dtype", default="f32w")
     ap.add_argument("--kit", default="RNA004")
     ap.add_argument("--mode", default="enrich")
+    ap.add_argument("--full-reupload", action="store_true", help="no device-resident signals: every read whole, every batch")
     args = ap.parse_args()
     from riser_amd import Model, SignalProcessor, Kit
     dev = torch.device("cuda", 0)
     models = [Model(synth.make_state_dict(s), synth.Config(), None, t, dtype=args.dtype, device=dev)
               for s, t in list(zip((1, 2, 3), ("mRNA", "mtRNA", "globin")))[: args.models]]
     proc = SignalProcessor(Kit.create_from_version(args.kit), device=dev)
-    res = run_replay(models, proc, scripted_batches(args.batches, args.channels), mode=args.mode)
+    res = run_replay(models, proc, scripted_batches(args.batches, args.channels), mode=args.mode, signal_cache=not args.full_reupload)
     res.update(channels=args.channels, models=args.models, dtype=args.dtype, kit=args.kit)
     print(json.dumps(res))
 
