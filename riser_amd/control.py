@@ -130,7 +130,7 @@ class _SignalStore:
 
     def _stage(self, n: int):
         if self.stage is None or self.stage.numel() < n:
-            cap = max(n, 1 << 20, 0 if self.stage is None else self.stage.numel() * 2)
+            cap = max(2 * n, 1 << 22)          # generous: pinning memory is a slow system call, growth must be rare
             self.stage = torch.empty(cap, dtype=torch.int16).pin_memory()
             self.stage_dev = torch.empty(cap, dtype=torch.int16, device=self.device)
         return self.stage.numpy()
@@ -213,6 +213,7 @@ class SequencerControl:
         self._store = _SignalStore(processor.device, resident=signal_cache)
         self._pinned = _Pinned(processor.device)
         self._res_probs = self._res_dec = None
+        self._channels_seen = 0
 
     # ------------------------------------------------------------------------------------
     def reserve(self, reads: int):
@@ -229,6 +230,7 @@ class SequencerControl:
         proc = self.proc
         dev = proc.device
         B = len(entries)
+        self._channels_seen = max(self._channels_seen, B)
         reads = [e[1] for e in entries]
         channels = np.fromiter((e[0] for e in entries), dtype=np.int64, count=B)
         ids = [r.id for r in reads]
@@ -330,7 +332,9 @@ class SequencerControl:
                     decided[decision].append((channel, key(read)))
                 lines.append(f"{head}{read.id},{channel},{n_samples}{tail}{';'.join(map(str, p_on))}{tail2}{decision}")
             sink.write("\n".join(lines) + "\n")
-        if len(cache) >= _CACHE_LIMIT:
+        # riser/control.py:96-97 drops the cache at 1000 entries, two flow cells' worth of reads at 512 channels; the same
+        # proportion at any channel count (the cache never changes a result, only how often a read is re-scanned)
+        if len(cache) >= max(_CACHE_LIMIT, 2 * self._channels_seen):
             cache = {}
         self.client.reject_reads(decided["reject"], unblock_duration)
         self.client.finish_processing_reads(decided["reject"] + decided["accept"] + decided["no_decision"])

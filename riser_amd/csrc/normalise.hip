@@ -15,6 +15,18 @@
 #include "common.hpp"
 
 #include <atomic>
+#include <stdio.h>
+
+// Diagnostic build only (-DRS_K1_STAMPS, tools/k1_stamps.py): s_memtime at the phase boundaries of workgroup 0
+#ifdef RS_K1_STAMPS
+__device__ unsigned long long g_k1_stamps[16];
+#define RS_K1_STAMP(k)                                                                   \
+    do {                                                                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_k1_stamps[k] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define RS_K1_STAMP(k) do { } while (0)
+#endif
 
 namespace rs {
 namespace {
@@ -76,6 +88,8 @@ __device__ void block_select2(KeyFn key, int n, int R, int k_lo, int k_hi, unsig
     // level for tens of samples, so with lanes on CONSECUTIVE samples most lanes of an instruction hit the same bin and
     // the LDS atomic unit serialises them.
     const int chunk = ((n + kThreads - 1) / kThreads) | 1;
+    // (reading four keys ahead of their four atomics was measured: +40 % on the pass - the LDS atomic unit, at ~3 lane
+    // atomics per clock on this data, is what bounds the two selects: 10-12 k of the kernel's 58 k cycles each)
     for (int k = 0, i = tid * chunk; k < chunk; ++k, ++i)
         if (i < n) atomicAdd(&hist[key(i) >> shift], 1u);
     __syncthreads();
@@ -178,6 +192,7 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
     float* __restrict__ out32, int64_t ld32, int32_t pad_to, double* __restrict__ out64, int64_t ld64,
     double* __restrict__ stats, int lmax, int zero_prefix, const BlockPlan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    RS_K1_STAMP(0);
     // rs_classify lays the fp32 rows out behind 16 zero bytes: the conv kernel that folds layer 0
     // into its staging reads x[-1] of the first read from there
     if (zero_prefix && out32 && blockIdx.x == 0 && threadIdx.x < 4) out32[(int)threadIdx.x - 4] = 0.0f;
@@ -194,37 +209,12 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
     int16_t* sx = sx0 + (int)((reinterpret_cast<uintptr_t>(src) >> 1) & 7);
     float* o32 = out32 ? out32 + (int64_t)b * ld32 : nullptr;
     double* o64 = out64 ? out64 + (int64_t)b * ld64 : nullptr;
-    if (pl.rbase) {
-        // packed block layout: this read's fp32 row starts at its first block, is zero-filled to the end of its last
-        // one, and the workgroup writes the read's entries of the block table the conv stack runs on
-        int base = b * pl.uniform_nblk;
-        if (pl.uniform_nblk <= 0) {
-            int s = 0;
-            for (int i = tid; i < b; i += kThreads) s += (min(len[i], lmax) >> pl.shift) + 1;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-            if (lane == 0) sc->red_a[w] = s;
-            __syncthreads();
-            base = 0;
-#pragma unroll
-            for (int i = 0; i < kWaves; ++i) base += sc->red_a[i];
-            __syncthreads();
-        }
-        const int nblk = plan_nblk(n, pl);
-        if (tid == 0) {
-            pl.rbase[b] = base;
-            if (b == (int)gridDim.x - 1) pl.rbase[b + 1] = base + nblk;
-        }
-        // device lengths that disagree with the host's copy (which sized the workspace): never write outside it
-        if (base + nblk > pl.nb_total) return;
-        if (tid < nblk) {
-            pl.blen[base + tid] = max(0, min(n - (tid << pl.shift), 1 << pl.shift));
-            pl.bread[base + tid] = b;
-        }
-        o32 = out32 + ((int64_t)base << pl.shift);
-        pad_to = nblk << pl.shift;
-    }
-
+    // packed block layout: the read's first block is the number of blocks of the reads before it.  The length loads are
+    // issued here and reduced together with min / max below, so their latency hides behind the staging of the read.
+    int nblk_before = 0;
+    if (pl.rbase && pl.uniform_nblk <= 0)
+        for (int i = tid; i < b; i += kThreads) nblk_before += (min(len[i], lmax) >> pl.shift) + 1;
+    RS_K1_STAMP(1);
     // ---- stage the read into LDS, min / max on the way ------------------------------------
     // 16-byte loads over the 16-byte-aligned body of the read (the LDS copy is shifted by the same
     // phase, so aligned global chunks are aligned LDS chunks), element loads for the ragged ends
@@ -262,33 +252,58 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
     for (int d = 32; d >= 1; d >>= 1) {
         mn = min(mn, __shfl_xor(mn, d, 64));
         mx = max(mx, __shfl_xor(mx, d, 64));
+        nblk_before += __shfl_xor(nblk_before, d, 64);
     }
     if (lane == 0) {
         sc->red_a[w] = mn;
         sc->red_b[w] = mx;
+        sc->wave_tot[w] = nblk_before;
     }
     __syncthreads();
     mn = sc->red_a[0];
     mx = sc->red_b[0];
+    nblk_before = sc->wave_tot[0];
 #pragma unroll
     for (int i = 1; i < kWaves; ++i) {
         mn = min(mn, sc->red_a[i]);
         mx = max(mx, sc->red_b[i]);
+        nblk_before += sc->wave_tot[i];
     }
     __syncthreads();
+    if (pl.rbase) {
+        // this read's fp32 row starts at its first block, is zero-filled to the end of its last one, and the workgroup
+        // writes the read's entries of the block table the conv stack runs on
+        const int base = pl.uniform_nblk > 0 ? b * pl.uniform_nblk : nblk_before;
+        const int nblk = plan_nblk(n, pl);
+        if (tid == 0) {
+            pl.rbase[b] = base;
+            if (b == (int)gridDim.x - 1) pl.rbase[b + 1] = base + nblk;
+        }
+        // device lengths that disagree with the host's copy (which sized the workspace): never write outside it
+        if (base + nblk > pl.nb_total) return;
+        if (tid < nblk) {
+            pl.blen[base + tid] = max(0, min(n - (tid << pl.shift), 1 << pl.shift));
+            pl.bread[base + tid] = b;
+        }
+        o32 = out32 + ((int64_t)base << pl.shift);
+        pad_to = nblk << pl.shift;
+    }
 
+    RS_K1_STAMP(2);
     // ---- median: the two middle order statistics -------------------------------------------
     const int k_lo = (n - 1) >> 1, k_hi = n >> 1;
     int m_lo, m_hi;
     block_select2([&](int i) { return (int)sx[i] - mn; }, n, mx - mn, k_lo, k_hi, hist, sc, tid, m_lo, m_hi);
     const int sum2 = m_lo + m_hi + 2 * mn;                       // 2 * median, exact
 
+    RS_K1_STAMP(3);
     // ---- MAD: middle order statistics of |2x - 2 med| (integers < 2^17) --------------------
     const int rd = max(abs(2 * mn - sum2), abs(2 * mx - sum2));
     int d_lo, d_hi;
     block_select2([&](int i) { return abs(2 * (int)sx[i] - sum2); }, n, rd, k_lo, k_hi, hist, sc, tid, d_lo, d_hi);
     const int mad4 = d_lo + d_hi;                                // 4 * mad, exact
 
+    RS_K1_STAMP(4);
     if (stats && tid == 0) {
         stats[2 * b + 0] = (double)sum2 * 0.5;
         stats[2 * b + 1] = (double)mad4 * 0.25;
@@ -327,10 +342,12 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
         // to fp32 - into the histogram's LDS, and the per-sample work becomes a look-up.
         float* lut = reinterpret_cast<float*>(hist);
         const bool use_lut = o32 && !o64 && dthr <= kBins / 2;
+        RS_K1_STAMP(5);
         if (use_lut) {
             for (int k = tid; k < 2 * dthr; k += kThreads) lut[k] = (float)(((double)(k - dthr) * 0.5) / denom);
             __syncthreads();
         }
+        RS_K1_STAMP(6);
         for (int i = tid; i < n; i += kThreads) {
             const int t = dev2(i);
             if (abs(t) < dthr) {
@@ -359,8 +376,10 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
             } while (j < n && abs(dev2(j)) >= dthr);
         }
     }
+    RS_K1_STAMP(7);
     if (o32)
         for (int i = n + tid; i < pad_to; i += kThreads) o32[i] = 0.0f;
+    RS_K1_STAMP(8);
 }
 
 }  // namespace
@@ -394,6 +413,16 @@ int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* 
     hipLaunchKernelGGL(normalise_kernel, dim3(B), dim3(kThreads), lds, st, d_sig, d_off, d_len, d_out32, ld32,
                        pad_to, d_out64, ld64, d_stats, Lmax, zero_prefix, plan ? *plan : BlockPlan{});
     RS_HIP(hipGetLastError());
+#ifdef RS_K1_STAMPS
+    {
+        RS_HIP(hipStreamSynchronize(st));
+        unsigned long long h[16];
+        RS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_k1_stamps), sizeof(h)));
+        fprintf(stderr, "[k1-stamps] B %d Lmax %d cycles: plan %llu | stage+minmax %llu | median %llu | mad %llu | thr %llu | lut %llu | "
+                "normalise+smooth %llu | pad %llu | total %llu\n", B, Lmax, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3],
+                h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[8] - h[0]);
+    }
+#endif
     return RS_OK;
 }
 

@@ -12,6 +12,7 @@ Used by tools/replay_bench.py and by bench.py's `control_loop` object.
 """
 from __future__ import annotations
 
+import gc
 import logging
 import os
 import tempfile
@@ -70,10 +71,17 @@ def run_replay(models, processor, batches, mode: str = "enrich", threshold: floa
                                os.path.join(d, "out"), signal_cache=signal_cache)
         ctl.reserve(max(len(b) for b in batches))
         ctl.start()
-        t0 = time.perf_counter()
-        ctl.target(mode, 1.0, threshold)
-        torch.cuda.synchronize(processor.device)
-        wall = time.perf_counter() - t0
+        # the scripted batches are hundreds of thousands of long-lived Python objects that a live run never holds (its
+        # reads are transient): keep the cyclic collector from walking them in the middle of a timed batch
+        gc.collect()
+        gc.freeze()
+        try:
+            t0 = time.perf_counter()
+            ctl.target(mode, 1.0, threshold)
+            torch.cuda.synchronize(processor.device)
+            wall = time.perf_counter() - t0
+        finally:
+            gc.unfreeze()
         ctl.finish()
         with open(os.path.join(d, "out.csv")) as f:
             rows = sum(1 for _ in f) - 1
@@ -86,6 +94,7 @@ def run_replay(models, processor, batches, mode: str = "enrich", threshold: floa
             "wall_s": round(wall, 3), "assessed_per_s": round(rows / wall, 1),
             "p50_ms": round(float(np.percentile(lat, 50)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
             "max_ms": round(float(lat.max()), 3), "latency_samples": int(lat.size),
+            "first_ms": [round(float(v) * 1e3, 2) for v in list(ctl.batch_latencies)[:8]],
             "signal_cache": bool(signal_cache),
             "pcie_samples_uploaded": int(ctl._store.samples_uploaded),
             "pcie_samples_full_reupload": int(ctl._store.samples_presented),
