@@ -391,20 +391,27 @@ def side_variants(args, device, wl, ref):
     # the reference's secondary architecture (riser/nets/resnet.py; no shipped config or weights): a SquiggleNet-like
     # basic-block ResNet through the generic conv program (csrc/seqnet.hip: f32-input MFMA, weights resident in LDS)
     import types
-    from riser_amd.resnet import ResNetModel, build_program, program_flops
+    from riser_amd.resnet import ResNetModel, build_program, program_flops, program_traffic_bytes
     rcfg = synth.RESNET_BENCH_CFG
     rsd = synth.make_resnet_state_dict(7)
     rm = ResNetModel(rsd, types.SimpleNamespace(resnet=types.SimpleNamespace(**rcfg)), None, "x", device=device)
     xr = torch.from_numpy(np.stack([np.clip((s.astype(np.float32) - 500.0) / 60.0, -3.5, 3.5)
                                     for s in wl.sample_sigs[:64]])).to(device).repeat(B // 64, 1).contiguous()
     dtr = timed(lambda: rm._net.forward(xr))
-    fl = program_flops(build_program(rsd, types.SimpleNamespace(**rcfg))[0], L) * xr.shape[0]
+    rprog = build_program(rsd, types.SimpleNamespace(**rcfg))[0]
+    fl = program_flops(rprog, L) * xr.shape[0]
+    by = program_traffic_bytes(rprog, L, fused=True) * xr.shape[0]
+    by_unfused = program_traffic_bytes(rprog, L, fused=False) * xr.shape[0]
     variants["resnet_basic_f32"] = {"chunks_per_s": round(xr.shape[0] / dtr, 1), "ms_per_step": round(dtr * 1e3, 4),
                                     "batch": int(xr.shape[0]), "config": rcfg,
                                     "conv_tflops": round(fl / dtr / 1e12, 2),
                                     "roofline_frac_f32_mfma": round(fl / dtr / 1e12 / PEAK_F32_MFMA_TF, 4),
-                                    "note": "un-padded conv FLOPs / step time over the 157.3 TF f32 MFMA peak; at these widths "
-                                            "(20-67 channels, fp32 rows) the program is HBM-bound: ~3.8 GB of activations per step"}
+                                    "hbm_gb_per_step": round(by / 1e9, 3), "hbm_gb_per_step_unfused": round(by_unfused / 1e9, 3),
+                                    "hbm_tb_per_s": round(by / dtr / 1e12, 3), "roofline_frac_hbm": round(by / dtr / 8e12, 4),
+                                    "note": "one launch per residual block (conv-BN-ReLU, conv-BN, 1x1 shortcut, add, ReLU) and one for "
+                                            "the stem (conv-BN-ReLU-MaxPool): x in, y out per launch (hbm_gb_per_step, algorithmic); "
+                                            "conv_tflops = un-padded conv FLOPs / step time over the 157.3 TF f32 MFMA peak (channel "
+                                            "widths of 20-67 pad to 32-80 columns of the 16-wide MFMA tile)"}
     rm.close()
     return variants
 

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 namespace rs {
@@ -228,6 +229,361 @@ __global__ __launch_bounds__(256) void seq_conv_mfma_lds_kernel(const float* __r
     }
 }
 
+// ---- fused residual block and fused stem (riser/nets/resnet.py:39-43,54-57,79-84) ------------------------------------
+// The launch-per-conv program above moves every intermediate through HBM: a basic block reads its input three times
+// (conv, shortcut, residual), writes and re-reads the intermediate.  The two kernels below are what rs_seqnet_create
+// substitutes when it recognises the patterns build_program emits:
+//
+//   STEM   conv1d(1 -> C; k, stride, pad) + BN + ReLU -> MaxPool1d(2, 2, padding 1): the GEMM rows of a tile start at an
+//          odd conv position, so a pooling pair is two accumulator registers of one lane and the un-pooled activations
+//          never exist in memory.
+//   BLOCK  y = relu( conv3(relu(conv3(x; stride) + b1)) + b2 + shortcut(x) ), shortcut = x or conv1(x; stride) + b:
+//          a workgroup owns R - 2 output positions of one read; phase 1 computes the R rows of the intermediate they
+//          need (one halo row each side) into LDS, phase 2 runs the second conv with its im2col rows read from that LDS
+//          tile (a row of the tile is a run of the next conv's K index, exactly as in global memory) and the 1x1 shortcut
+//          conv as extra K chunks of the same GEMM read from x; both weight matrices stay in LDS for the whole launch.
+//          x is read once (plus the halo), y written once.
+// Same MFMA orientation and K order as seq_conv_mfma_lds_kernel (so the intermediate has the bits the unfused program
+// computes); fp32 throughout.
+
+template <int NT>
+__global__ __launch_bounds__(256) void seq_stem_pool_kernel(const float* __restrict__ x, unsigned x_bytes,
+                                                            const float* __restrict__ wq, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int B, int L, int T_conv, int TP,
+                                                            int c_out, int K, int stride, int pad, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    constexpr int NP = 16 * NT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int K16 = (K + 15) & ~15;
+    for (int i = threadIdx.x; i < K16 / 4 * NP; i += 256)
+        reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(wq)[i];
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+    // GEMM row g = b * 2 TP + j holds conv position j - 1 of read b: rows (2p, 2p + 1) are the window of pooled row p
+    const int rpr = 2 * TP;
+    const int rows = B * rpr;
+    float bcol[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bcol[j] = 16 * j + r < c_out ? bias[16 * j + r] : 0.0f;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row0 = tile * 128 + wave * 32;
+        // (read, row in it) of a GEMM row: one division per tile, then a step or two (integer division per lane and row
+        // cost more VALU time than the tile's MFMAs)
+        const int tb0 = __builtin_amdgcn_readfirstlane((tile * 128) / rpr);
+        auto locate = [&](int g, int& b, int& j) {
+            b = tb0;
+            j = g - tb0 * rpr;
+            while (j >= rpr) {
+                j -= rpr;
+                ++b;
+            }
+        };
+        int off0[2], base[2];
+        bool ok[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int g = row0 + 16 * m + r;
+            int b, j;
+            locate(g, b, j);
+            const int tc = j - 1;
+            ok[m] = g < rows && tc >= 0 && tc < T_conv;
+            off0[m] = tc * stride - pad;
+            base[m] = b * L;
+        }
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto load_a = [&](int k0, f32x4 (&av)[2]) {
+            const int kidx = k0 + 4 * kq;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int o = off0[m] + kidx;
+                // (elements at K index >= K meet zero weights: inside the read they need no mask)
+                if (ok[m] && o >= 0 && o + 3 < L) {
+                    av[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(base[m] + o) * 4u, 0, 0));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        av[m][i] = (ok[m] && kidx + i < K && o + i >= 0 && o + i < L) ? x[(int64_t)base[m] + o + i] : 0.0f;
+                }
+            }
+        };
+        f32x4 av[2], avn[2];
+        load_a(0, av);
+        for (int k0 = 0; k0 < K16; k0 += 16) {
+            f32x4 bv[NT];
+            if (k0 + 16 < K16) load_a(k0 + 16, avn);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(wl + ((k0 / 4 + kq) * NP + 16 * j + r) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][i], bv[j][i], acc[m][j], 0, 0, 0);
+            av[0] = avn[0];
+            av[1] = avn[1];
+        }
+        // lane (column r, row group kq) holds GEMM rows 4 kq + e: (e = 0, 1) and (2, 3) are pooling windows
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const int g = row0 + 16 * m + 4 * kq + e;              // even
+                if (g >= rows) continue;
+                int b, j0;
+                locate(g, b, j0);
+                const int ta = j0 - 1, tb = j0;                        // the window's conv positions (MaxPool pads with -inf)
+                const bool va = ta >= 0 && ta < T_conv, vb = tb < T_conv;
+                float* yr = y + ((int64_t)b * TP + (j0 >> 1)) * c_out;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = 16 * j + r;
+                    if (col >= c_out) continue;
+                    float v = -INFINITY;
+                    if (va) v = fmaxf(v, acc[m][j][e] + bcol[j]);
+                    if (vb) v = fmaxf(v, acc[m][j][e + 1] + bcol[j]);
+                    yr[col] = fmaxf(v, 0.0f);                          // relu(max) == max(relu)
+                }
+            }
+    }
+}
+
+struct BlockArgs {
+    const float* x;           // [B][T_in][c_in]
+    unsigned x_bytes;
+    float* y;                 // [B][T_out][c_out]
+    const float* w1q;         // [K1_16 / 4][NPs][4], K index = tap * c_in + c
+    const float* b1;          // [16 NT]
+    const float* w2q;         // [K2_16 / 4][NPs][4], K index = tap * Cp + c for the 3x3 part, K2a16 + c for the 1x1 shortcut
+    const float* b2;          // [16 NT] (the shortcut conv's bias included)
+    int NPs;                  // column pitch of the weight matrices: c_out rounded up to 4 (the columns behind it are zeros
+                              // that a lane takes from a register, not from LDS)
+    int B, T_in, T_out, c_in, c_out, Cp, stride;
+    int K1, K2a, Ksc;         // 3 c_in; 3 Cp; c_in if the shortcut is a conv, else 0 (identity: c_in == c_out, stride 1)
+    int tiles_per_read, n_tiles;
+};
+
+template <int NT, int MTW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const BlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int NP = a.NPs;
+    constexpr int R = 16 * MTW * WAVES;            // rows of the intermediate tile (WAVES waves x MTW x 16)
+    constexpr int kThr = 64 * WAVES;
+    constexpr int TO = R - 2;                      // output positions per tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int K1_16 = (a.K1 + 15) & ~15, K2a16 = (a.K2a + 15) & ~15, Ksc16 = (a.Ksc + 15) & ~15;
+    float* wl1 = lds;
+    float* wl2 = wl1 + K1_16 * NP;
+    float* tl = wl2 + (K2a16 + Ksc16) * NP;        // [(R + 4)][Cp]: row j = intermediate position to0 - 1 + j; 4 zero rows behind
+    for (int i = threadIdx.x; i < K1_16 / 4 * NP; i += kThr)
+        reinterpret_cast<f32x4*>(wl1)[i] = reinterpret_cast<const f32x4*>(a.w1q)[i];
+    for (int i = threadIdx.x; i < (K2a16 + Ksc16) / 4 * NP; i += kThr)
+        reinterpret_cast<f32x4*>(wl2)[i] = reinterpret_cast<const f32x4*>(a.w2q)[i];
+    for (int i = threadIdx.x; i < (R + 4) * a.Cp; i += kThr) tl[i] = 0.0f;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const int lim = a.T_in * a.c_in;
+    float b1c[NT], b2c[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        b1c[j] = a.b1[16 * j + r];
+        b2c[j] = a.b2[16 * j + r];
+    }
+    // EDGE = false: a tile whose every intermediate row, output and x access lies inside its read (all but the first
+    // and the last tiles of a read): no per-row masks, no bounds tests in front of the loads - in fp32 every such VALU
+    // instruction is issue time next to the MFMAs, not hidden behind them
+    auto do_tile = [&](int tile, auto EDGE_) {
+        constexpr bool EDGE = decltype(EDGE_)::value;
+        const int b = tile / a.tiles_per_read;
+        const int to0 = (tile - b * a.tiles_per_read) * TO;
+        const int64_t xbase = (int64_t)b * lim;
+        // ---- phase 1: the intermediate rows j = 0 .. R-1 (positions to0 - 1 + j) = relu(conv3(x; stride) + b1) -> LDS ----
+        {
+            int off0[MTW];
+            bool ok[MTW];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int p = to0 - 1 + (wave * MTW + m) * 16 + r;
+                ok[m] = !EDGE || (p >= 0 && p < a.T_out);
+                off0[m] = (p * a.stride - 1) * a.c_in;
+            }
+            f32x4 acc[MTW][NT];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            auto load_a = [&](int k0, f32x4 (&av)[MTW]) {
+                const int kidx = k0 + 4 * kq;
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const int o = off0[m] + kidx;
+                    // (elements at K index >= K1 meet zero weights: inside the read they need no mask)
+                    if (!EDGE || (ok[m] && o >= 0 && o + 3 < lim)) {
+                        av[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)((xbase + o) * 4), 0, 0));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            av[m][i] = (ok[m] && kidx + i < a.K1 && o + i >= 0 && o + i < lim) ? a.x[xbase + o + i] : 0.0f;
+                    }
+                }
+            };
+            f32x4 av[MTW], avn[MTW];
+            load_a(0, av);
+            for (int k0 = 0; k0 < K1_16; k0 += 16) {
+                f32x4 bv[NT];
+                if (k0 + 16 < K1_16) load_a(k0 + 16, avn);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bv[j] = 16 * j + r < NP ? *reinterpret_cast<const f32x4*>(wl1 + ((k0 / 4 + kq) * NP + 16 * j + r) * 4)
+                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][i], bv[j][i], acc[m][j], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) av[m] = avn[m];
+            }
+            // rows outside [0, T_out) are the second conv's zero padding; channels >= c_out of a row stay zero
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int jrow = (wave * MTW + m) * 16 + 4 * kq + e;
+                    const int p = to0 - 1 + jrow;
+                    const bool okp = !EDGE || (p >= 0 && p < a.T_out);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int col = 16 * j + r;
+                        if (col < a.c_out) tl[jrow * a.Cp + col] = okp ? fmaxf(acc[m][j][e] + b1c[j], 0.0f) : 0.0f;
+                    }
+                }
+        }
+        __syncthreads();
+        // ---- phase 2: output rows i = 0 .. TO-1 (positions to0 + i): conv3 over LDS rows i .. i+2 (+ the 1x1 shortcut) ----
+        {
+            f32x4 acc[MTW][NT];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* trow[MTW];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) trow[m] = tl + ((wave * MTW + m) * 16 + r) * a.Cp + 4 * kq;
+            // identity shortcut: the residual values of this lane's outputs, requested before the K loop that hides them
+            float resv[MTW][4][NT];
+            if (!a.Ksc) {
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = (wave * MTW + m) * 16 + 4 * kq + e;
+                        const int pos = to0 + i;
+                        const bool okr = i < TO && (!EDGE || pos < a.T_out);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const int col = 16 * j + r;
+                            resv[m][e][j] = (okr && col < a.c_out) ? a.x[xbase + (int64_t)pos * a.c_in + col] : 0.0f;
+                        }
+                    }
+            }
+            for (int k0 = 0; k0 < K2a16; k0 += 16) {
+                f32x4 bv[NT], av[MTW];
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) av[m] = *reinterpret_cast<const f32x4*>(trow[m] + k0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bv[j] = 16 * j + r < NP ? *reinterpret_cast<const f32x4*>(wl2 + ((k0 / 4 + kq) * NP + 16 * j + r) * 4)
+                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][i], bv[j][i], acc[m][j], 0, 0, 0);
+            }
+            if (a.Ksc) {                                             // 1x1 shortcut conv: x[(to0 + i) * stride][0 .. c_in)
+                int off0[MTW];
+                bool ok[MTW];
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const int i = (wave * MTW + m) * 16 + r;
+                    ok[m] = i < TO && (!EDGE || to0 + i < a.T_out);
+                    off0[m] = (to0 + i) * a.stride * a.c_in;
+                }
+                auto load_sc = [&](int k0, f32x4 (&av)[MTW]) {
+                    const int kidx = k0 + 4 * kq;
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) {
+                        const int o = off0[m] + kidx;
+                        if (ok[m] && (!EDGE || o + 3 < lim)) {
+                            av[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)((xbase + o) * 4), 0, 0));
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) av[m][i] = (ok[m] && kidx + i < a.Ksc && o + i < lim) ? a.x[xbase + o + i] : 0.0f;
+                        }
+                    }
+                };
+                f32x4 av[MTW], avn[MTW];
+                load_sc(0, av);
+                for (int k0 = 0; k0 < Ksc16; k0 += 16) {
+                    f32x4 bv[NT];
+                    if (k0 + 16 < Ksc16) load_sc(k0 + 16, avn);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        bv[j] = 16 * j + r < NP ? *reinterpret_cast<const f32x4*>(wl2 + (((K2a16 + k0) / 4 + kq) * NP + 16 * j + r) * 4)
+                                                : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                            for (int j = 0; j < NT; ++j)
+                                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][i], bv[j][i], acc[m][j], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) av[m] = avn[m];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = (wave * MTW + m) * 16 + 4 * kq + e;
+                    const int pos = to0 + i;
+                    if (i >= TO || (EDGE && pos >= a.T_out)) continue;
+                    const int64_t orow = ((int64_t)b * a.T_out + pos) * a.c_out;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int col = 16 * j + r;
+                        if (col >= a.c_out) continue;
+                        float v = acc[m][j][e] + b2c[j];
+                        if (!a.Ksc) v += resv[m][e][j];                  // identity shortcut
+                        a.y[orow + col] = fmaxf(v, 0.0f);
+                    }
+                }
+        }
+        __syncthreads();                                             // the next tile's phase 1 overwrites the LDS tile
+    };
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int tt = tile % a.tiles_per_read;
+        const int to0 = tt * TO;
+        const bool interior = to0 >= 2 && to0 + TO <= a.T_out && (to0 + R - 2) * a.stride + 6 <= a.T_in;
+        if (interior)
+            do_tile(tile, std::false_type{});
+        else
+            do_tile(tile, std::true_type{});
+    }
+}
+
 __global__ __launch_bounds__(256) void seq_maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
                                                           int T_in, int T_out, int c, int pad) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -255,8 +611,19 @@ __global__ __launch_bounds__(256) void seq_head_kernel(const float* __restrict__
     for (int c0 = 0; c0 < c; c0 += 64) {
         const int ch = c0 + lane;
         float s = 0.f;
-        if (ch < c)
-            for (int t = wave; t < T; t += 4) s += x[((int64_t)b * T + t) * c + ch];
+        if (ch < c) {
+            // eight rows in flight per lane (the loop is a chain of dependent-looking loads otherwise: T / 4 round trips)
+            const float* col = x + (int64_t)b * T * c + ch;
+            int t = wave;
+            for (; t + 28 < T; t += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(t + 4 * u) * c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; t < T; t += 4) s += col[(int64_t)t * c];
+        }
         part[wave][lane] = s;
         __syncthreads();
         if (wave == 0 && ch < c) {
@@ -292,6 +659,17 @@ struct OpDev {
     float* d_b = nullptr;     // [cq*4]
     float* d_wq = nullptr;    // MFMA packing [K16 / 4][Npad][4] (K = k * c_in in im2col order), or null if too large for LDS
     int nt = 0;               // Npad / 16
+    // fusion (rs_seqnet_create, fuse_program): this op starts a fused launch that also covers the next `fuse_skip` ops
+    int fuse = 0;             // 0 none, 1 stem conv + max-pool, 2 residual basic block
+    int fuse_skip = 0;
+    int f_src = -1, f_dst = -1;
+    int f_cin = 0, f_cout = 0, f_cp = 0, f_stride = 1, f_ksc = 0, f_mtw = 1, f_waves = 4;
+    int f_nt = 0, f_nps = 0;
+    float* d_f_w1 = nullptr;  // block: first conv [K1_16 / 4][Npad][4]
+    float* d_f_w2 = nullptr;  // block: second conv (+ shortcut conv) [K2_16 / 4][Npad][4]
+    float* d_f_b1 = nullptr;  // [Npad]
+    float* d_f_b2 = nullptr;  // [Npad]
+    size_t f_lds = 0;
 };
 
 }  // namespace
@@ -300,6 +678,8 @@ struct OpDev {
 using namespace rs;
 
 struct rs_seqnet {
+    bool fuse = true;              // RS_SEQ_NOFUSE=1 (read at create): one launch per op, as the program is written
+    std::vector<std::vector<float>> keep_w;   // host copies of the conv weights until fusion has packed them
     int device = 0;
     int n_buffers = 0;
     int c_last = 0;
@@ -347,6 +727,123 @@ bool propagate(const rs_seqnet* m, int L, std::vector<int>& T, std::vector<int>&
     return true;
 }
 
+// is buffer `buf` dead after op index `after` (never read again before it is rewritten)?
+bool dead_after(const std::vector<OpDev>& ops, size_t after, int buf) {
+    for (size_t k = after + 1; k < ops.size(); ++k) {
+        if (ops[k].src == buf || ops[k].add == buf) return false;
+        if (ops[k].dst == buf) return true;
+    }
+    return true;
+}
+
+template <class T>
+hipError_t upload_vec(float** d, const std::vector<T>& h) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(d), std::max<size_t>(h.size(), 1) * sizeof(T));
+    if (e == hipSuccess) e = hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+// Recognise what riser_amd/resnet.py:build_program emits for the reference's stem (resnet.py:79-84) and BasicBlock
+// (resnet.py:50-57 + shortcut :21-24,45-47) and mark the first op of each pattern as a fused launch.  hw[k] = host copy
+// of op k's [c_out][c_in][k] weights (conv ops), hb[k] its bias.
+hipError_t fuse_program(rs_seqnet* m, const std::vector<const float*>& hw, const std::vector<const float*>& hb) {
+    std::vector<OpDev>& ops = m->ops;
+    const size_t lds_cap = 160 * 1024;
+    for (size_t k = 0; k < ops.size(); ++k) {
+        OpDev& o = ops[k];
+        if (o.kind != 0) continue;
+        // ---- stem: conv(1 -> C) + ReLU, then MaxPool1d(2, 2, padding 1) of it -------------------------------------------
+        if (o.c_in == 1 && o.relu && o.add < 0 && o.d_wq && k + 1 < ops.size() && ops[k + 1].kind == 1 && ops[k + 1].pad == 1 &&
+            ops[k + 1].src == o.dst && dead_after(ops, k + 1, o.dst)) {
+            o.fuse = 1;
+            o.fuse_skip = 1;
+            o.f_src = o.src;
+            o.f_dst = ops[k + 1].dst;
+            continue;
+        }
+        // ---- basic block: [1x1 shortcut conv]  conv3(stride) + ReLU  conv3 + residual + ReLU -----------------------------
+        size_t k1 = k, ksc = (size_t)-1;
+        if (o.k == 1 && o.pad == 0 && !o.relu && o.add < 0 && k + 2 < ops.size()) {
+            ksc = k;
+            k1 = k + 1;
+        }
+        if (k1 + 1 >= ops.size()) continue;
+        const OpDev& c1 = ops[k1];
+        const OpDev& c2 = ops[k1 + 1];
+        const int X = ksc != (size_t)-1 ? ops[ksc].src : c1.src;
+        const int res = ksc != (size_t)-1 ? ops[ksc].dst : X;
+        const bool shape_ok = c1.kind == 0 && c2.kind == 0 && c1.k == 3 && c1.pad == 1 && c1.relu && c1.add < 0 && c1.src == X &&
+                              c2.k == 3 && c2.pad == 1 && c2.stride == 1 && c2.relu && c2.src == c1.dst && c2.add == res &&
+                              c2.c_in == c1.c_out && c2.c_out == c1.c_out && c2.dst != X && c1.dst != X &&
+                              (ksc != (size_t)-1 ? (ops[ksc].stride == c1.stride && ops[ksc].c_in == c1.c_in && ops[ksc].c_out == c1.c_out)
+                                                 : (c1.stride == 1 && c1.c_in == c1.c_out));
+        if (!shape_ok) continue;
+        if (!dead_after(ops, k1 + 1, c1.dst) || (ksc != (size_t)-1 && !dead_after(ops, k1 + 1, res))) continue;
+        const int c_in = c1.c_in, c_out = c1.c_out, nt = (c_out + 15) / 16, NP = (c_out + 3) & ~3;
+        if (nt > 5) continue;
+        int Cp = (c_out + 3) & ~3;
+        if (((Cp / 4) & 1) == 0) Cp += 4;                      // row pitch = 4 (mod 8) floats: conflict-free ds_read_b128 over 16 rows
+        const int K1 = 3 * c_in, K1_16 = (K1 + 15) & ~15, K2a = 3 * Cp, K2a16 = (K2a + 15) & ~15;
+        const int Ksc = ksc != (size_t)-1 ? c_in : 0, Ksc16 = (Ksc + 15) & ~15;
+        const size_t w_floats = (size_t)(K1_16 + K2a16 + Ksc16) * NP;
+        // 126 outputs per tile (two 16-row tiles per wave: half the halo, half the weight reads per MFMA) unless the 62-output
+        // tile is what lets a second workgroup share the CU
+        auto lds_of = [&](int mtw_) { return (w_floats + (size_t)(64 * mtw_ + 4) * Cp) * 4; };
+        int mtw = 2, waves = 4;
+        if (lds_of(2) > lds_cap || (lds_cap / lds_of(2) < 2 && lds_cap / lds_of(1) >= 2)) mtw = 1;
+        // a block so wide that one workgroup owns the CU's LDS runs eight waves (two per SIMD) on the same 128-row tile:
+        // with one wave per SIMD every LDS / global round trip idles the matrix pipe
+        if (lds_cap / lds_of(mtw) < 2 && mtw == 2) {
+            mtw = 1;
+            waves = 8;
+        }
+        const size_t lds = (w_floats + (size_t)(16 * mtw * waves + 4) * Cp) * 4;
+        if (lds > lds_cap) continue;
+        // pack: conv 1 as the unfused kernel does; conv 2 over the LDS tile's K index tap * Cp + c, the shortcut behind it
+        std::vector<float> w1q((size_t)K1_16 * NP, 0.0f), w2q((size_t)(K2a16 + Ksc16) * NP, 0.0f), b1(16 * nt, 0.0f), b2(16 * nt, 0.0f);
+        for (int co = 0; co < c_out; ++co) {
+            b1[co] = hb[k1][co];
+            b2[co] = hb[k1 + 1][co] + (ksc != (size_t)-1 ? hb[ksc][co] : 0.0f);
+            for (int ci = 0; ci < c_in; ++ci)
+                for (int kk = 0; kk < 3; ++kk) {
+                    const int kidx = kk * c_in + ci;
+                    w1q[((size_t)(kidx / 4) * NP + co) * 4 + kidx % 4] = hw[k1][((size_t)co * c_in + ci) * 3 + kk];
+                }
+            for (int ci = 0; ci < c_out; ++ci)
+                for (int kk = 0; kk < 3; ++kk) {
+                    const int kidx = kk * Cp + ci;
+                    w2q[((size_t)(kidx / 4) * NP + co) * 4 + kidx % 4] = hw[k1 + 1][((size_t)co * c_out + ci) * 3 + kk];
+                }
+            if (ksc != (size_t)-1)
+                for (int ci = 0; ci < c_in; ++ci) {
+                    const int kidx = K2a16 + ci;
+                    w2q[((size_t)(kidx / 4) * NP + co) * 4 + kidx % 4] = hw[ksc][(size_t)co * c_in + ci];
+                }
+        }
+        hipError_t e = upload_vec(&o.d_f_w1, w1q);
+        if (e == hipSuccess) e = upload_vec(&o.d_f_w2, w2q);
+        if (e == hipSuccess) e = upload_vec(&o.d_f_b1, b1);
+        if (e == hipSuccess) e = upload_vec(&o.d_f_b2, b2);
+        if (e != hipSuccess) return e;
+        o.fuse = 2;
+        o.fuse_skip = (int)(k1 + 1 - k);
+        o.f_src = X;
+        o.f_dst = c2.dst;
+        o.f_cin = c_in;
+        o.f_cout = c_out;
+        o.f_cp = Cp;
+        o.f_nps = NP;
+        o.f_stride = c1.stride;
+        o.f_ksc = Ksc;
+        o.f_mtw = mtw;
+        o.f_waves = waves;
+        o.f_nt = nt;
+        o.f_lds = lds;
+        k = k1 + 1;
+    }
+    return hipSuccess;
+}
+
 size_t buffer_bytes(const rs_seqnet* m, int B, int L) {
     std::vector<int> T, C;
     size_t elems = 0;
@@ -373,6 +870,8 @@ int rs_seqnet_create(const rs_seq_op* ops, int n_ops, int n_buffers, const float
     m->n_buffers = n_buffers;
     m->c_last = c_last;
     m->scalar_conv = getenv("RS_SEQ_SCALAR") != nullptr;
+    m->fuse = getenv("RS_SEQ_NOFUSE") == nullptr && !m->scalar_conv;
+    std::vector<const float*> hw, hb;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) m->num_cu = cus;
@@ -418,12 +917,23 @@ int rs_seqnet_create(const rs_seq_op* ops, int n_ops, int n_buffers, const float
                 o.nt = nt;
             }
             m->ops.push_back(o);
+            hw.push_back(s.w);
+            hb.push_back(s.b);
             if (e != hipSuccess) {
                 rs_seqnet_destroy(m);
                 return hip_fail(e, "rs_seqnet_create upload");
             }
         } else {
             m->ops.push_back(o);
+            hw.push_back(nullptr);
+            hb.push_back(nullptr);
+        }
+    }
+    if (m->fuse) {
+        const hipError_t fe = fuse_program(m, hw, hb);
+        if (fe != hipSuccess) {
+            rs_seqnet_destroy(m);
+            return hip_fail(fe, "rs_seqnet_create fused packing");
         }
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_fcw), (size_t)2 * c_last * 4);
@@ -445,6 +955,10 @@ int rs_seqnet_destroy(rs_seqnet* m) {
         if (o.d_w) (void)hipFree(o.d_w);
         if (o.d_b) (void)hipFree(o.d_b);
         if (o.d_wq) (void)hipFree(o.d_wq);
+        if (o.d_f_w1) (void)hipFree(o.d_f_w1);
+        if (o.d_f_w2) (void)hipFree(o.d_f_w2);
+        if (o.d_f_b1) (void)hipFree(o.d_f_b1);
+        if (o.d_f_b2) (void)hipFree(o.d_f_b2);
     }
     if (m->d_fcw) (void)hipFree(m->d_fcw);
     if (m->d_fcb) (void)hipFree(m->d_fcb);
@@ -484,6 +998,70 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
     for (size_t k = 0; k < m->ops.size(); ++k) {
         const OpDev& o = m->ops[k];
         const OpShape& sh = shp[k];
+        if (o.fuse == 1 && (int64_t)B * 2 * shp[k + 1].t_out < 0x7fffffffLL && (int64_t)B * sh.t_in * 4 < 0x7fffffffLL) {
+            // stem conv + ReLU + MaxPool(2, 2, pad 1) in one launch: GEMM rows = 2 * pooled rows
+            const OpShape& ps = shp[k + 1];
+            const int rows = B * 2 * ps.t_out;
+            const int n_tiles = (rows + 127) / 128;
+            const int K = o.k * o.c_in, K16 = (K + 15) & ~15;
+            const size_t lds = (size_t)K16 * o.nt * 16 * 4;
+            auto fn = o.nt == 1 ? seq_stem_pool_kernel<1> : o.nt == 2 ? seq_stem_pool_kernel<2> : o.nt == 3 ? seq_stem_pool_kernel<3>
+                    : o.nt == 4 ? seq_stem_pool_kernel<4> : seq_stem_pool_kernel<5>;
+            RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
+            const int grid = std::min(n_tiles, m->num_cu * per_cu);
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, buf(o.f_src), (unsigned)((int64_t)B * sh.t_in * 4), o.d_wq, o.d_b,
+                               buf(o.f_dst), B, sh.t_in, sh.t_out, ps.t_out, o.c_out, K, o.stride, o.pad, n_tiles);
+            RS_HIP(hipGetLastError());
+            last = o.f_dst;
+            k += o.fuse_skip;
+            continue;
+        }
+        if (o.fuse == 2 && (int64_t)B * shp[k + o.fuse_skip].t_in * o.f_cout * 4 < 0x7fffffffLL) {
+            // residual basic block in one launch (shapes of its first 3x3 conv: ops[k + fuse_skip - 1])
+            const OpShape& s1 = shp[k + o.fuse_skip - 1];
+            const int64_t xb = (int64_t)B * s1.t_in * o.f_cin * 4;
+            if (xb < 0x7fffffffLL) {
+                BlockArgs a;
+                a.x = buf(o.f_src);
+                a.x_bytes = (unsigned)xb;
+                a.y = buf(o.f_dst);
+                a.w1q = o.d_f_w1;
+                a.b1 = o.d_f_b1;
+                a.w2q = o.d_f_w2;
+                a.b2 = o.d_f_b2;
+                a.B = B;
+                a.T_in = s1.t_in;
+                a.T_out = s1.t_out;
+                a.c_in = o.f_cin;
+                a.c_out = o.f_cout;
+                a.Cp = o.f_cp;
+                a.NPs = o.f_nps;
+                a.stride = o.f_stride;
+                a.K1 = 3 * o.f_cin;
+                a.K2a = 3 * o.f_cp;
+                a.Ksc = o.f_ksc;
+                const int TO = 16 * o.f_mtw * o.f_waves - 2;
+                a.tiles_per_read = (s1.t_out + TO - 1) / TO;
+                a.n_tiles = B * a.tiles_per_read;
+                using Fn = void (*)(const BlockArgs);
+                static const Fn table[5][3] = {   // [NT - 1][4 waves x 1 | 4 waves x 2 | 8 waves x 1 row tiles per wave]
+                    {seq_basic_block_kernel<1, 1, 4>, seq_basic_block_kernel<1, 2, 4>, seq_basic_block_kernel<1, 1, 8>},
+                    {seq_basic_block_kernel<2, 1, 4>, seq_basic_block_kernel<2, 2, 4>, seq_basic_block_kernel<2, 1, 8>},
+                    {seq_basic_block_kernel<3, 1, 4>, seq_basic_block_kernel<3, 2, 4>, seq_basic_block_kernel<3, 1, 8>},
+                    {seq_basic_block_kernel<4, 1, 4>, seq_basic_block_kernel<4, 2, 4>, seq_basic_block_kernel<4, 1, 8>},
+                    {seq_basic_block_kernel<5, 1, 4>, seq_basic_block_kernel<5, 2, 4>, seq_basic_block_kernel<5, 1, 8>}};
+                Fn fn = table[o.f_nt - 1][o.f_waves == 8 ? 2 : o.f_mtw - 1];
+                RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(o.f_lds, 1)));
+                const int grid = std::min(a.n_tiles, m->num_cu * per_cu);
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * o.f_waves), o.f_lds, st, a);
+                RS_HIP(hipGetLastError());
+                last = o.f_dst;
+                k += o.fuse_skip;
+                continue;
+            }
+        }
         if (o.kind == 0 && m->scalar_conv) {
             const int cq = (o.c_out + 3) / 4;
             const int64_t total = (int64_t)B * sh.t_out * cq;

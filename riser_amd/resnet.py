@@ -93,6 +93,43 @@ def program_flops(prog, L: int) -> float:
     return fl
 
 
+def program_traffic_bytes(prog, L: int, fused: bool = True) -> float:
+    """fp32 bytes one chunk of L samples moves through HBM under the launch structure rs_seqnet_create builds: every
+    launch reads its input(s) once and writes its output once.  fused=True: the stem conv + max-pool and every basic
+    residual block (optional 1x1 shortcut conv, conv3, conv3 + residual) are one launch each (csrc/seqnet.hip:
+    fuse_program); fused=False: one launch per op."""
+    T, C = {0: L}, {0: 1}
+    shapes = []
+    for o in prog:
+        if o["kind"] == 0:
+            co, ci, k = o["w"].shape
+            t_out = (T[o["src"]] + 2 * o["pad"] - k) // o["stride"] + 1
+            c_out = co
+        else:
+            t_out = T[o["src"]] // 2 + (1 if o.get("pad", 1) else 0)
+            c_out = C[o["src"]]
+        shapes.append((T[o["src"]] * C[o["src"]], t_out * c_out))
+        T[o["dst"]], C[o["dst"]] = t_out, c_out
+    total, k = 0.0, 0
+    while k < len(prog):
+        o = prog[k]
+        if fused and o["kind"] == 0 and o["w"].shape[1] == 1 and k + 1 < len(prog) and prog[k + 1]["kind"] == 1:
+            total += shapes[k][0] + shapes[k + 1][1]                       # stem: signal in, pooled rows out
+            k += 2
+            continue
+        if fused and o["kind"] == 0:
+            sc = o["w"].shape[2] == 1 and not o["relu"]
+            k1 = k + 1 if sc else k
+            if (k1 + 1 < len(prog) and prog[k1]["kind"] == 0 and prog[k1 + 1]["kind"] == 0 and prog[k1]["w"].shape[2] == 3
+                    and prog[k1 + 1]["w"].shape[2] == 3 and prog[k1 + 1]["add"] == (o["dst"] if sc else prog[k1]["src"])):
+                total += shapes[k1][0] + shapes[k1 + 1][1]                   # block: x in, y out
+                k = k1 + 2
+                continue
+        total += shapes[k][0] + shapes[k][1] + (shapes[k][1] if o.get("add", -1) >= 0 else 0)
+        k += 1
+    return 4.0 * total
+
+
 class SeqNet:
     """A conv / max-pool program on the device (rs_seqnet_*): uniform-length batches [B, L] -> probabilities."""
 

@@ -52,3 +52,35 @@ def test_resnet_gpu_vs_reference(golden_dir, name):
         with pytest.raises(ValueError):
             m.classify_batch(np.zeros((1, 4), dtype=np.float32))
     m.close()
+
+
+@pytest.mark.gpu
+def test_resnet_fused_blocks_equal_the_op_by_op_program():
+    """rs_seqnet_create fuses the stem (conv + BN + ReLU + MaxPool) and every basic residual block (two 3x3 convs, the 1x1
+    shortcut, add, ReLU) into one launch each; RS_SEQ_NOFUSE=1 runs the program one op per launch.  Same logits to fp32
+    round-off on the bench architecture (stride-2 stages, identity and conv shortcuts, ragged last tiles) at several
+    lengths, and against the oracle."""
+    import torch
+    from riser_amd.resnet import ResNetModel
+    dev = torch.device("cuda", 0)
+    cfg = dict(synth.RESNET_BENCH_CFG)
+    sd = synth.make_resnet_state_dict(7)
+    config = types.SimpleNamespace(resnet=types.SimpleNamespace(**cfg))
+    fused = ResNetModel(sd, config, None, "x", device=dev)
+    os.environ["RS_SEQ_NOFUSE"] = "1"
+    try:
+        plain = ResNetModel(sd, config, None, "x", device=dev)
+    finally:
+        del os.environ["RS_SEQ_NOFUSE"]
+    for L in (3000, 4097, 6024, 16000):
+        x = _inputs(L)
+        pf, lf = fused.classify_batch(x, return_logits=True)
+        pp, lp = plain.classify_batch(x, return_logits=True)
+        assert np.abs(lf.cpu().numpy() - lp.cpu().numpy()).max() < 2e-5, L
+        want = rr.resnet_forward(sd, cfg, x)
+        assert np.abs(lf.cpu().numpy() - want).max() < 1e-4, L
+    # a batch that is not a multiple of anything, single read
+    x = _inputs(5000)[:1]
+    assert np.abs(fused.classify_batch(x).cpu().numpy() - plain.classify_batch(x).cpu().numpy()).max() < 1e-5
+    fused.close()
+    plain.close()
