@@ -291,6 +291,10 @@ __global__ __launch_bounds__(256) void seq_stem_pool_kernel(const float* __restr
             off0[m] = tc * stride - pad;
             base[m] = b * L;
         }
+        // a wave whose 32 rows and all their samples lie inside one read takes the loads without bounds tests
+        const int jw = row0 - tb0 * rpr;                        // first row of the wave in read tb0 (or beyond: then not interior)
+        const bool interior = row0 + 32 <= rows && jw >= 1 && jw + 32 <= rpr - 2 && (jw - 1) * stride - pad >= 0 &&
+                              (jw + 31) * stride - pad + K16 + 3 < L;
         f32x4 acc[2][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) void seq_stem_pool_kernel(const float* __restr
             for (int m = 0; m < 2; ++m) {
                 const int o = off0[m] + kidx;
                 // (elements at K index >= K meet zero weights: inside the read they need no mask)
-                if (ok[m] && o >= 0 && o + 3 < L) {
+                if (interior || (ok[m] && o >= 0 && o + 3 < L)) {
                     av[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(base[m] + o) * 4u, 0, 0));
                 } else {
 #pragma unroll
@@ -663,13 +667,13 @@ struct OpDev {
     int fuse = 0;             // 0 none, 1 stem conv + max-pool, 2 residual basic block
     int fuse_skip = 0;
     int f_src = -1, f_dst = -1;
-    int f_cin = 0, f_cout = 0, f_cp = 0, f_stride = 1, f_ksc = 0, f_mtw = 1, f_waves = 4;
+    int f_cin = 0, f_cout = 0, f_cp = 0, f_stride = 1, f_ksc = 0;
     int f_nt = 0, f_nps = 0;
     float* d_f_w1 = nullptr;  // block: first conv [K1_16 / 4][Npad][4]
     float* d_f_w2 = nullptr;  // block: second conv (+ shortcut conv) [K2_16 / 4][Npad][4]
     float* d_f_b1 = nullptr;  // [Npad]
     float* d_f_b2 = nullptr;  // [Npad]
-    size_t f_lds = 0;
+    size_t f_wfloats = 0;     // floats of both weight matrices in LDS
 };
 
 }  // namespace
@@ -779,8 +783,12 @@ hipError_t fuse_program(rs_seqnet* m, const std::vector<const float*>& hw, const
                                                  : (c1.stride == 1 && c1.c_in == c1.c_out));
         if (!shape_ok) continue;
         if (!dead_after(ops, k1 + 1, c1.dst) || (ksc != (size_t)-1 && !dead_after(ops, k1 + 1, res))) continue;
-        const int c_in = c1.c_in, c_out = c1.c_out, nt = (c_out + 15) / 16, NP = (c_out + 3) & ~3;
+        const int c_in = c1.c_in, c_out = c1.c_out, nt = (c_out + 15) / 16;
         if (nt > 5) continue;
+        // column pitch of the weight matrices in LDS: the compact one (c_out rounded to 4) only where the full 16 * nt would
+        // cost the block its second workgroup per CU - it costs a select per weight fragment
+        int NP = 16 * nt;
+        if ((size_t)(((3 * c_in + 15) & ~15) + ((3 * (c_out + 7) + 15) & ~15) + ((c_in + 15) & ~15)) * NP * 4 > 60 * 1024) NP = (c_out + 3) & ~3;
         int Cp = (c_out + 3) & ~3;
         if (((Cp / 4) & 1) == 0) Cp += 4;                      // row pitch = 4 (mod 8) floats: conflict-free ds_read_b128 over 16 rows
         const int K1 = 3 * c_in, K1_16 = (K1 + 15) & ~15, K2a = 3 * Cp, K2a16 = (K2a + 15) & ~15;
@@ -788,17 +796,7 @@ hipError_t fuse_program(rs_seqnet* m, const std::vector<const float*>& hw, const
         const size_t w_floats = (size_t)(K1_16 + K2a16 + Ksc16) * NP;
         // 126 outputs per tile (two 16-row tiles per wave: half the halo, half the weight reads per MFMA) unless the 62-output
         // tile is what lets a second workgroup share the CU
-        auto lds_of = [&](int mtw_) { return (w_floats + (size_t)(64 * mtw_ + 4) * Cp) * 4; };
-        int mtw = 2, waves = 4;
-        if (lds_of(2) > lds_cap || (lds_cap / lds_of(2) < 2 && lds_cap / lds_of(1) >= 2)) mtw = 1;
-        // a block so wide that one workgroup owns the CU's LDS runs eight waves (two per SIMD) on the same 128-row tile:
-        // with one wave per SIMD every LDS / global round trip idles the matrix pipe
-        if (lds_cap / lds_of(mtw) < 2 && mtw == 2) {
-            mtw = 1;
-            waves = 8;
-        }
-        const size_t lds = (w_floats + (size_t)(16 * mtw * waves + 4) * Cp) * 4;
-        if (lds > lds_cap) continue;
+        if ((w_floats + (size_t)(64 + 4) * Cp) * 4 > lds_cap) continue;       // not even the smallest tile fits
         // pack: conv 1 as the unfused kernel does; conv 2 over the LDS tile's K index tap * Cp + c, the shortcut behind it
         std::vector<float> w1q((size_t)K1_16 * NP, 0.0f), w2q((size_t)(K2a16 + Ksc16) * NP, 0.0f), b1(16 * nt, 0.0f), b2(16 * nt, 0.0f);
         for (int co = 0; co < c_out; ++co) {
@@ -835,10 +833,8 @@ hipError_t fuse_program(rs_seqnet* m, const std::vector<const float*>& hw, const
         o.f_nps = NP;
         o.f_stride = c1.stride;
         o.f_ksc = Ksc;
-        o.f_mtw = mtw;
-        o.f_waves = waves;
         o.f_nt = nt;
-        o.f_lds = lds;
+        o.f_wfloats = w_floats;
         k = k1 + 1;
     }
     return hipSuccess;
@@ -1041,7 +1037,25 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                 a.K1 = 3 * o.f_cin;
                 a.K2a = 3 * o.f_cp;
                 a.Ksc = o.f_ksc;
-                const int TO = 16 * o.f_mtw * o.f_waves - 2;
+                // tile = (row tiles per wave, waves): rows R = 16 * mtw * waves of the intermediate, R - 2 outputs.  More rows
+                // per wave = fewer halo rows, weight-fragment reads and set-up instructions per MFMA; candidates must fit the
+                // LDS next to the weights, should leave room for a second workgroup on the CU, and must not waste more than
+                // ~6 % of their rows behind the end of the read; a block so wide that one workgroup owns the CU's LDS runs
+                // eight waves (two per SIMD: with one, every LDS / global round trip idles the matrix pipe)
+                const size_t lds_cap = 160 * 1024;
+                auto lds_of = [&](int rows) { return (o.f_wfloats + (size_t)(rows + 4) * o.f_cp) * 4; };
+                auto waste = [&](int rows) {
+                    const int to = rows - 2, n = (s1.t_out + to - 1) / to;
+                    return (double)(n * to - s1.t_out) / (double)(n * to);
+                };
+                int mtw = 1, waves = 4;
+                if (lds_cap / lds_of(64) < 2) {
+                    if (lds_of(128) <= lds_cap) waves = 8;
+                } else {
+                    if (lds_cap / lds_of(128) >= 2 && waste(128) < 0.06) mtw = 2;
+                }
+                const size_t f_lds = lds_of(16 * mtw * waves);
+                const int TO = 16 * mtw * waves - 2;
                 a.tiles_per_read = (s1.t_out + TO - 1) / TO;
                 a.n_tiles = B * a.tiles_per_read;
                 using Fn = void (*)(const BlockArgs);
@@ -1051,11 +1065,12 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                     {seq_basic_block_kernel<3, 1, 4>, seq_basic_block_kernel<3, 2, 4>, seq_basic_block_kernel<3, 1, 8>},
                     {seq_basic_block_kernel<4, 1, 4>, seq_basic_block_kernel<4, 2, 4>, seq_basic_block_kernel<4, 1, 8>},
                     {seq_basic_block_kernel<5, 1, 4>, seq_basic_block_kernel<5, 2, 4>, seq_basic_block_kernel<5, 1, 8>}};
-                Fn fn = table[o.f_nt - 1][o.f_waves == 8 ? 2 : o.f_mtw - 1];
+                // (256-row tiles - four row tiles per wave - were measured on the 20-channel stage: 168 against 165 us)
+                Fn fn = table[o.f_nt - 1][waves == 8 ? 2 : mtw - 1];
                 RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(o.f_lds, 1)));
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, lds_cap / f_lds));
                 const int grid = std::min(a.n_tiles, m->num_cu * per_cu);
-                hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * o.f_waves), o.f_lds, st, a);
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), f_lds, st, a);
                 RS_HIP(hipGetLastError());
                 last = o.f_dst;
                 k += o.fuse_skip;

@@ -29,6 +29,8 @@ class Workspace:
     different HIP streams (two batches in flight: stream.classify_resident) never share activations.  Keyed by the
     stream that is current when the call is made; a library call only ever touches the workspace it is handed."""
 
+    MAX_STREAMS = 8          # workspaces kept alive: a caller cycling through more streams than this re-allocates
+
     def __init__(self, device):
         self.device = device
         self._bufs = {}
@@ -38,6 +40,8 @@ class Workspace:
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             self._bufs[key] = None
+            if len(self._bufs) > self.MAX_STREAMS:           # drop the workspace of the stream used longest ago
+                del self._bufs[next(k for k in self._bufs if k != key)]
             with torch.cuda.stream(torch.cuda.current_stream(self.device)):
                 buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._bufs[key] = buf

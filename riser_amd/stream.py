@@ -71,6 +71,18 @@ class StreamClassifier:
         return out.numpy()
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev, n: int):
+    """n side streams per device, created once: every stream that classifies owns a workspace in each model
+    (model.Workspace is keyed by stream), so fresh streams per call would pin a new multi-GB workspace per call."""
+    key = (dev.index, int(n))
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _SIDE_STREAMS[key]
+
+
 def classify_resident(models, sig_dev: torch.Tensor, n_reads: int, read_len: int, lengths: np.ndarray | None = None,
                       sub_batch: int = 1024, out: torch.Tensor | None = None, streams: int = 1) -> torch.Tensor:
     """Classify a population that is ALREADY resident in HBM: int16 [n_reads * read_len] (row i valid for
@@ -96,7 +108,7 @@ def classify_resident(models, sig_dev: torch.Tensor, n_reads: int, read_len: int
                 model.classify_raw(sig_dev, off_all[lo:hi], len_all[lo:hi], lengths[lo:hi], out=out[m, lo:hi])
         return out
     caller = torch.cuda.current_stream(dev)
-    side = [torch.cuda.Stream(device=dev) for _ in range(streams)]
+    side = _side_streams(dev, streams)
     for st in side:
         st.wait_stream(caller)                                   # inputs (and `out`) were produced on the caller's stream
     for k, lo in enumerate(range(0, n_reads, sub_batch)):
