@@ -49,6 +49,7 @@ Hooks Hooks::from_env() {
     text("RS_H16_PANEL", h.h16_panel, sizeof(h.h16_panel));
     text("RS_FORCE_SHAPE_RING", h.force_ring, sizeof(h.force_ring));
     if (const char* e = getenv("RS_H16_RING")) h.h16_ring = atoi(e) != 0;
+    if (const char* e = getenv("RS_H16_WRES")) h.h16_wres = atoi(e) != 0;
     return h;
 }
 
@@ -692,8 +693,10 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         const bool stream16 = (is16 || x3) && i <= 2 && conv_stream_h16_ok(L, P_in);
         // split precision runs the LDS-DMA ring kernel on every layer, plain 16-bit on its tiled layers with RS_H16_RING
         const bool ring = !stream16 && (x3 || (is16 && m->hooks.h16_ring && L.d_w2));
-        const int kind = (stream32 || stream16) ? 0 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)
-                                                            : m->dtype == RS_F32 ? 3 : 4;
+        // ... and narrow layers whose whole weight tensor fits LDS next to two activation slabs on the weights-resident kernel
+        const bool wres = ring && conv_wres_h16_ok(L, x3);
+        const int kind = (stream32 || stream16 || wres) ? 0 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)
+                                                                    : m->dtype == RS_F32 ? 3 : 4;
         m->last_ring[i] = ring;
         auto launch_layer = [&]() -> int {
             int rc;
@@ -718,7 +721,10 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                                             f0 ? d_x : nullptr, m->d_w0, m->channels[0], x3);
                 m->last_bm[i] = 16;
                 m->last_bn[i] = round_up(L.c_out, 16);
-            } else if (ring)
+            } else if (wres)
+                rc = launch_conv_wres_h16(L, buf[cur], buf[cur ^ 1], d_blen, NB, P_in, i, m->num_cu, f16, x3, check_dead, st,
+                                          &m->last_bm[i], &m->last_bn[i]);
+            else if (ring)
                 rc = launch_conv_ring_h16(L, buf[cur], buf[cur ^ 1], d_blen, NB, P_in, i, m->num_cu, f16, x3, check_dead, st,
                                           &m->last_bm[i], &m->last_bn[i]);
             else

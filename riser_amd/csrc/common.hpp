@@ -67,6 +67,7 @@ struct Hooks {
     char force_ring[256] = "";       // RS_FORCE_SHAPE_RING
     char h16_panel[128] = "";        // RS_H16_PANEL: "64" or "layer:64;..."
     bool h16_ring = true;            // RS_H16_RING=0: plain 16-bit tiled layers on conv_h16.hip instead of the LDS-DMA ring kernel
+    bool h16_wres = true;            // RS_H16_WRES=0: narrow 16-bit layers on the ring kernel instead of the weights-resident one
     static Hooks from_env();
 };
 const Hooks& default_hooks();
@@ -171,6 +172,12 @@ int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, co
                            const float* fuse_w0, int fuse_c0, bool x3 = false);
 // LDS-DMA ring kernel (conv_ring_h16.hip): plain 16-bit and split-precision (x3) modes
 int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
+                         int layer_index, int num_cu, bool f16, bool x3, int check_dead, hipStream_t st, int* bm_out,
+                         int* bn_out);
+// weights-resident kernel for the narrow tiled 16-bit layers (conv_wres_h16.hip): all output channels in one tile, the
+// layer's whole weight tensor in LDS; bit-identical to the ring kernel
+bool conv_wres_h16_ok(const ConvLayerDev& L, bool x3);
+int launch_conv_wres_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
                          int layer_index, int num_cu, bool f16, bool x3, int check_dead, hipStream_t st, int* bm_out,
                          int* bn_out);
 int conv_ring_max_bn();

@@ -104,3 +104,26 @@ def test_length_mismatch_is_contained(dev):
     assert np.array_equal(out[:3], good[:3])
     assert np.isnan(out[3]).all()
     assert np.array_equal(m.classify_raw(sig, off, ln, lh).cpu().numpy(), good)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "f16x3", "bf16x3"])
+def test_weights_resident_kernel_equals_ring_kernel_bitwise(dev, dtype):
+    """conv_wres_h16.hip (the narrow tiled 16-bit layers with the layer's whole weight tensor resident in LDS: layer 3 of
+    the shipped net in every 16-bit mode, layer 4 in the plain ones) issues the same MFMA sequence per accumulator as the
+    LDS-DMA ring kernel: RS_H16_WRES=0 (ring kernel everywhere) gives identical bits, on a mixed-length batch and on the
+    full 512 x 16000 one."""
+    from conftest import hooked_model
+    sd = synth.make_state_dict(1)
+    m = get_model(1, dev, dtype)
+    ring = hooked_model({"RS_H16_WRES": "0"}, sd, dtype, dev)
+    lens = np.array([16000, 4096, 8615, 12000, 8000, 4100, 9999, 12288, 8192, 5000, 15999], dtype=np.int32)
+    sig, off, ln, lh = pack_reads(_reads(lens, 3600), dev)
+    a, b = m.classify_raw(sig, off, ln, lh).cpu().numpy(), ring.classify_raw(sig, off, ln, lh).cpu().numpy()
+    assert np.array_equal(a, b), np.abs(a - b).max()
+    sigs = synth.make_signals(SIG_SEED, 512, 16000)
+    sig, off, ln, lh = pack_reads(list(sigs), dev)
+    a, b = m.classify_raw(sig, off, ln, lh).cpu().numpy(), ring.classify_raw(sig, off, ln, lh).cpu().numpy()
+    assert np.array_equal(a, b), np.abs(a - b).max()
+    info = m.layer_info()
+    assert info[3]["bn"] == 80 and info[3]["bm"] == 256          # layer 3 ran the weights-resident tile
+    ring.close()
