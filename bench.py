@@ -440,6 +440,13 @@ def control_loop_object(device, dtype):
             out["models_1_full_reupload"] = run_replay(models, proc, batches, signal_cache=False)
         for m in models:
             m.close()
+    # the same loop with the models in split precision (bf16x3: within 1e-3 of the reference, labels identical - the mode of
+    # BASELINE config 3): the device share of a batch halves
+    for n_models in (1, 3):
+        models = [Model(synth.make_state_dict(s), synth.Config(), None, t, dtype="bf16x3", device=device) for s, t in spec[:n_models]]
+        out[f"models_{n_models}_bf16x3"] = run_replay(models, proc, batches)
+        for m in models:
+            m.close()
     del batches
     big = scripted_batches(14, 18000)
     models = [Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dtype, device=device)]

@@ -152,6 +152,8 @@ class _SignalStore:
             self.samples_uploaded += total
             return offs
         # ---- rows: one per channel, assigned at first sight ---------------------------------------------------------
+        if int(channels.min()) < 0:
+            raise ValueError("negative channel number")
         cmax = int(channels.max())
         if cmax >= self.rowmap.shape[0]:
             grown = np.full(max(cmax + 1, 2 * self.rowmap.shape[0]), -1, dtype=np.int64)

@@ -113,11 +113,11 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
 
 // ---- head ---------------------------------------------------------------------------------
 // AdaptiveAvgPool1d(1) -> Flatten -> Linear(C, 2) (riser/nets/cnn.py:28-33) -> softmax
-// (riser/model.py:27).  One 256-thread workgroup per read: threads stride over channels (coalesced
+// (riser/model.py:27).  One 1024-thread workgroup per read: threads stride over channels (coalesced
 // 4-byte loads, all rows of a channel in flight together), the mean is over the len >> n_layers
 // valid rows of the read's slot in the last activation buffer; wave shuffles + one LDS hop reduce
 // the two dot products.  The summation order depends only on the channel count, never on the batch.
-constexpr int kHeadThreads = 256;
+constexpr int kHeadThreads = 1024;     // 1702 channels: two per thread, every load of a read in flight at once
 constexpr int kHeadRowsUnroll = 4;
 
 template <int DT>

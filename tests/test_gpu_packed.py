@@ -127,3 +127,43 @@ def test_weights_resident_kernel_equals_ring_kernel_bitwise(dev, dtype):
     info = m.layer_info()
     assert info[3]["bn"] == 80 and info[3]["bm"] == 256          # layer 3 ran the weights-resident tile
     ring.close()
+
+
+def test_edge_lengths_and_oversized_batches(dev):
+    """the longest read the normalise kernel stages (65536 samples = 17 blocks), the shortest the net accepts (4096), a
+    batch larger than one library call may address (Model.max_batch: split transparently) - all against the oracle or
+    against the same reads classified alone"""
+    sd = synth.make_state_dict(3)
+    m = get_model(3, dev)
+    cpu = torch_path.TorchCpuModel(sd)
+    lens = np.array([65536, 4096, 65535, 32768, 4097], dtype=np.int32)
+    sigs = _reads(lens, 3700)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    got = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+    want = torch_path.classify_per_read(cpu, sigs)
+    assert np.abs(got - want).max() < 1e-4, np.abs(got - want).max()
+    assert np.array_equal(got, m.classify_raw(sig, off, ln, lh, packed=False).cpu().numpy())
+    # 16-bit split precision on the same reads (the 17-block read crosses every tile boundary of every layer)
+    got3 = get_model(3, dev, "f16x3").classify_raw(sig, off, ln, lh).cpu().numpy()
+    assert np.abs(got3 - want).max() < 1e-3
+    # more reads than one call addresses: 64 distinct 16000-sample signals repeated
+    L = 16000
+    n = m.max_batch(L) + 300
+    base = synth.make_signals(SIG_SEED, 64, L, first_read=5000)
+    idx = np.arange(n) % 64
+    big = torch.from_numpy(np.ascontiguousarray(base[idx].reshape(-1))).to(dev)
+    offs = torch.arange(n, dtype=torch.int64, device=dev) * L
+    lens_h = np.full(n, L, dtype=np.int32)
+    lens_h[::7] = 9000                                             # mixed lengths inside the oversized batch
+    lens_d = torch.from_numpy(lens_h).to(dev)
+    p = m.classify_raw(big, offs, lens_d, lens_h).cpu().numpy()
+    first = {}
+    for i in range(n):                                             # a read's bits depend on (signal, length) only
+        key = (int(idx[i]), int(lens_h[i]))
+        if key in first:
+            assert np.array_equal(p[i], p[first[key]]), (i, key)
+        else:
+            first[key] = i
+    pick = [0, 7, 63, n - 1]
+    want = torch_path.classify_batched(cpu, [base[idx[i]] for i in pick], [int(lens_h[i]) for i in pick])
+    assert np.abs(p[pick] - want).max() < 1e-4
