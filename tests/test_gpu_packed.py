@@ -167,3 +167,31 @@ def test_edge_lengths_and_oversized_batches(dev):
     pick = [0, 7, 63, n - 1]
     want = torch_path.classify_batched(cpu, [base[idx[i]] for i in pick], [int(lens_h[i]) for i in pick])
     assert np.abs(p[pick] - want).max() < 1e-4
+
+
+def test_forward_path_block_plan_beyond_one_scan_chunk(dev):
+    """rs_forward (signals that arrive normalised) builds the block table with plan_kernel, a single workgroup scanning
+    1024 reads per pass: 1500 short reads exercise the carry between passes; every read must match its solo result bit for
+    bit, with and without the host's lengths"""
+    m = get_model(2, dev)
+    base = [ro.mad_normalise(s).astype(np.float32) for s in _reads([4096, 4100, 5000, 8192, 4097], 3900)]
+    n = 1500
+    lens = np.array([len(base[i % 5]) for i in range(n)], dtype=np.int32)
+    x = np.zeros((n, int(lens.max())), dtype=np.float32)
+    for i in range(n):
+        x[i, : lens[i]] = base[i % 5]
+    xd = torch.from_numpy(x).to(dev)
+    got = m.forward_batch(xd, lens).cpu().numpy()
+    solo = np.stack([m.classify(b).cpu().numpy() for b in base])
+    assert np.array_equal(got, solo[np.arange(n) % 5])
+    # the uniform-pitch form of the same call (no host lengths)
+    import ctypes as C
+    from riser_amd import _native as nv
+    L = nv.lib()
+    ld = torch.from_numpy(lens).to(dev)
+    ws = torch.empty(L.rs_workspace_bytes(m._h, n, int(lens.max())), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    nv.check(L.rs_forward(m._h, xd.data_ptr(), x.shape[1], ld.data_ptr(), None, n, int(lens.min()), int(lens.max()),
+                          ws.data_ptr(), ws.numel(), out.data_ptr(), None, None), "rs_forward")
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), got)
