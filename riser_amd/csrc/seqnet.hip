@@ -588,6 +588,195 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
     }
 }
 
+// BOTTLENECK block (riser/nets/resnet.py:60-70): y = relu( conv1(relu(conv3(relu(conv1(x) + b1); stride) + b2)) + b3 +
+// shortcut(x) ) in one launch, three GEMM phases with two LDS tiles between them:
+//   A  t1 = relu(conv1x1(x) + b1) for the RA = 128 input positions (to0 * stride - 1 ..) the tile's 3x3 conv reads (zero
+//      rows outside the read: the 3x3 conv's padding), A operand = rows of x;
+//   B  t2 = relu(conv3(t1; stride) + b2) for the tile's R2 = (RA - 3) / stride + 1 outputs (126 / 63): the im2col row of
+//      output i is the run of three t1 rows from row i * stride of the LDS tile;
+//   C  y = relu(conv1x1(t2) + b3 + shortcut): rows of the t2 tile, the 1x1 shortcut conv as extra K chunks read from x
+//      (or the identity residual).
+// All three weight matrices stay in LDS; x is read once (plus one halo row each side), y written once.
+struct BneckArgs {
+    const float* x;
+    unsigned x_bytes;
+    float* y;
+    const float *w1q, *b1, *w2q, *b2, *w3q, *b3;   // [K16 / 4][NP][4] packings, biases padded to 16 NT
+    int NPm, NPo;             // column pitches of the mid / out weight matrices
+    int B, T_in, T_out, c_in, c_mid, c_out, Cmp, stride;
+    int Ksc;                  // c_in if the shortcut is a conv, else 0
+    int R2, tiles_per_read, n_tiles;
+};
+
+template <int NTM, int NTO>
+__global__ __launch_bounds__(256) void seq_bottleneck_block_kernel(const BneckArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int RA = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int K1_16 = (a.c_in + 15) & ~15, K2_16 = (3 * a.Cmp + 15) & ~15, K3_16 = (a.Cmp + 15) & ~15, Ksc16 = (a.Ksc + 15) & ~15;
+    float* wl1 = lds;
+    float* wl2 = wl1 + K1_16 * a.NPm;
+    float* wl3 = wl2 + K2_16 * a.NPm;
+    float* t1 = wl3 + (K3_16 + Ksc16) * a.NPo;     // [RA + 4][Cmp]
+    float* t2 = t1 + (RA + 4) * a.Cmp;             // [RA + 4][Cmp]
+    for (int i = threadIdx.x; i < K1_16 / 4 * a.NPm; i += 256) reinterpret_cast<f32x4*>(wl1)[i] = reinterpret_cast<const f32x4*>(a.w1q)[i];
+    for (int i = threadIdx.x; i < K2_16 / 4 * a.NPm; i += 256) reinterpret_cast<f32x4*>(wl2)[i] = reinterpret_cast<const f32x4*>(a.w2q)[i];
+    for (int i = threadIdx.x; i < (K3_16 + Ksc16) / 4 * a.NPo; i += 256)
+        reinterpret_cast<f32x4*>(wl3)[i] = reinterpret_cast<const f32x4*>(a.w3q)[i];
+    for (int i = threadIdx.x; i < 2 * (RA + 4) * a.Cmp; i += 256) t1[i] = 0.0f;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const int lim = a.T_in * a.c_in;
+    float b1c[NTM], b2c[NTM], b3c[NTO];
+#pragma unroll
+    for (int j = 0; j < NTM; ++j) {
+        b1c[j] = a.b1[16 * j + r];
+        b2c[j] = a.b2[16 * j + r];
+    }
+#pragma unroll
+    for (int j = 0; j < NTO; ++j) b3c[j] = a.b3[16 * j + r];
+    const int n_mt = (a.R2 + 15) / 16;             // 16-row tiles of phases B and C (8 or 4)
+    auto wfrag = [&](const float* wl, int NP, int k0, int j) -> f32x4 {
+        return 16 * j + r < NP ? *reinterpret_cast<const f32x4*>(wl + ((k0 / 4 + kq) * NP + 16 * j + r) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    // a lane's four consecutive x values at element o of the read (zero outside it), K index kidx .. kidx + 3 of Klim
+    auto xload = [&](int64_t xbase, bool ok, int o, int kidx, int Klim) -> f32x4 {
+        if (ok && o >= 0 && o + 3 < lim)
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)((xbase + o) * 4), 0, 0));
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (ok && kidx + i < Klim && o + i >= 0 && o + i < lim) ? a.x[xbase + o + i] : 0.0f;
+        return v;
+    };
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int b = tile / a.tiles_per_read;
+        const int to0 = (tile - b * a.tiles_per_read) * a.R2;
+        const int64_t xbase = (int64_t)b * lim;
+        // ---- phase A: t1 rows j = 0 .. RA-1 <-> input positions q0 + j ------------------------------------------------
+        {
+            const int q0 = to0 * a.stride - 1;
+            f32x4 acc[2][NTM];
+            int off0[2];
+            bool ok[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int q = q0 + (wave * 2 + m) * 16 + r;
+                ok[m] = q >= 0 && q < a.T_in;
+                off0[m] = q * a.c_in;
+#pragma unroll
+                for (int j = 0; j < NTM; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            for (int k0 = 0; k0 < K1_16; k0 += 16) {
+                f32x4 av[2], bv[NTM];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) av[m] = xload(xbase, ok[m], off0[m] + k0 + 4 * kq, k0 + 4 * kq, a.c_in);
+#pragma unroll
+                for (int j = 0; j < NTM; ++j) bv[j] = wfrag(wl1, a.NPm, k0, j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int j = 0; j < NTM; ++j)
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][i], bv[j][i], acc[m][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int jrow = (wave * 2 + m) * 16 + 4 * kq + e;
+                    const int q = q0 + jrow;
+                    const bool okq = q >= 0 && q < a.T_in;
+#pragma unroll
+                    for (int j = 0; j < NTM; ++j) {
+                        const int col = 16 * j + r;
+                        if (col < a.c_mid) t1[jrow * a.Cmp + col] = okq ? fmaxf(acc[m][j][e] + b1c[j], 0.0f) : 0.0f;
+                    }
+                }
+        }
+        __syncthreads();
+        // ---- phase B: t2 row i <-> output position to0 + i: conv3 over t1 rows i * stride .. + 2 -----------------------
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int mt = wave + 4 * m;
+            if (mt >= n_mt) break;
+            f32x4 acc[NTM];
+#pragma unroll
+            for (int j = 0; j < NTM; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* trow = t1 + ((mt * 16 + r) * a.stride) * a.Cmp + 4 * kq;
+            for (int k0 = 0; k0 < K2_16; k0 += 16) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(trow + k0);
+#pragma unroll
+                for (int j = 0; j < NTM; ++j) {
+                    const f32x4 bv = wfrag(wl2, a.NPm, k0, j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc[j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = mt * 16 + 4 * kq + e;
+#pragma unroll
+                for (int j = 0; j < NTM; ++j) {
+                    const int col = 16 * j + r;
+                    if (col < a.c_mid) t2[i * a.Cmp + col] = fmaxf(acc[j][e] + b2c[j], 0.0f);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase C: y row i = conv1x1(t2 row i) + b3 + shortcut -> ReLU ------------------------------------------------
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int mt = wave + 4 * m;
+            if (mt >= n_mt) break;
+            f32x4 acc[NTO];
+#pragma unroll
+            for (int j = 0; j < NTO; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* trow = t2 + (mt * 16 + r) * a.Cmp + 4 * kq;
+            for (int k0 = 0; k0 < K3_16; k0 += 16) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(trow + k0);
+#pragma unroll
+                for (int j = 0; j < NTO; ++j) {
+                    const f32x4 bv = wfrag(wl3, a.NPo, k0, j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc[j], 0, 0, 0);
+                }
+            }
+            if (a.Ksc) {
+                const int i_r = mt * 16 + r;
+                const bool okr = i_r < a.R2 && to0 + i_r < a.T_out;
+                const int off0 = (to0 + i_r) * a.stride * a.c_in;
+                for (int k0 = 0; k0 < Ksc16; k0 += 16) {
+                    const f32x4 av = xload(xbase, okr, off0 + k0 + 4 * kq, k0 + 4 * kq, a.Ksc);
+#pragma unroll
+                    for (int j = 0; j < NTO; ++j) {
+                        const f32x4 bv = wfrag(wl3, a.NPo, K3_16 + k0, j);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc[j], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = mt * 16 + 4 * kq + e;
+                const int pos = to0 + i;
+                if (i >= a.R2 || pos >= a.T_out) continue;
+                const int64_t orow = ((int64_t)b * a.T_out + pos) * a.c_out;
+#pragma unroll
+                for (int j = 0; j < NTO; ++j) {
+                    const int col = 16 * j + r;
+                    if (col >= a.c_out) continue;
+                    float v = acc[j][e] + b3c[j];
+                    if (!a.Ksc) v += a.x[xbase + (int64_t)pos * a.c_in + col];    // identity shortcut
+                    a.y[orow + col] = fmaxf(v, 0.0f);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void seq_maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
                                                           int T_in, int T_out, int c, int pad) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -673,7 +862,11 @@ struct OpDev {
     float* d_f_w2 = nullptr;  // block: second conv (+ shortcut conv) [K2_16 / 4][Npad][4]
     float* d_f_b1 = nullptr;  // [Npad]
     float* d_f_b2 = nullptr;  // [Npad]
-    size_t f_wfloats = 0;     // floats of both weight matrices in LDS
+    size_t f_wfloats = 0;     // floats of the weight matrices in LDS
+    // bottleneck block (fuse == 3): third conv (+ shortcut), mid width
+    float* d_f_w3 = nullptr;
+    float* d_f_b3 = nullptr;
+    int f_cmid = 0, f_ntm = 0, f_npm = 0;
 };
 
 }  // namespace
@@ -781,7 +974,78 @@ hipError_t fuse_program(rs_seqnet* m, const std::vector<const float*>& hw, const
                               c2.c_in == c1.c_out && c2.c_out == c1.c_out && c2.dst != X && c1.dst != X &&
                               (ksc != (size_t)-1 ? (ops[ksc].stride == c1.stride && ops[ksc].c_in == c1.c_in && ops[ksc].c_out == c1.c_out)
                                                  : (c1.stride == 1 && c1.c_in == c1.c_out));
-        if (!shape_ok) continue;
+        if (!shape_ok) {
+            // ---- bottleneck block: [1x1 shortcut conv]  conv1 + ReLU  conv3(stride) + ReLU  conv1 + residual + ReLU -------
+            if (k1 + 2 >= ops.size()) continue;
+            const OpDev& d1 = ops[k1];
+            const OpDev& d2 = ops[k1 + 1];
+            const OpDev& d3 = ops[k1 + 2];
+            const bool bn_ok = d1.kind == 0 && d2.kind == 0 && d3.kind == 0 && d1.k == 1 && d1.pad == 0 && d1.stride == 1 && d1.relu &&
+                               d1.add < 0 && d1.src == X && d2.k == 3 && d2.pad == 1 && d2.relu && d2.add < 0 && d2.src == d1.dst &&
+                               d2.c_in == d1.c_out && d2.c_out == d1.c_out && d3.k == 1 && d3.pad == 0 && d3.stride == 1 && d3.relu &&
+                               d3.src == d2.dst && d3.add == res && d3.c_in == d2.c_out && d3.dst != X && d1.dst != X && d2.dst != X &&
+                               (ksc != (size_t)-1 ? (ops[ksc].stride == d2.stride && ops[ksc].c_in == d1.c_in && ops[ksc].c_out == d3.c_out)
+                                                  : (d2.stride == 1 && d1.c_in == d3.c_out));
+            if (!bn_ok || (d2.stride != 1 && d2.stride != 2)) continue;
+            if (!dead_after(ops, k1 + 2, d1.dst) || !dead_after(ops, k1 + 2, d2.dst) ||
+                (ksc != (size_t)-1 && !dead_after(ops, k1 + 2, res)))
+                continue;
+            const int c_in = d1.c_in, c_mid = d1.c_out, c_out = d3.c_out;
+            const int ntm = (c_mid + 15) / 16, nto = (c_out + 15) / 16;
+            if (ntm > 2 || nto > 5) continue;
+            int Cmp = (c_mid + 3) & ~3;
+            if (((Cmp / 4) & 1) == 0) Cmp += 4;
+            const int NPm = (c_mid + 3) & ~3, NPo = (c_out + 3) & ~3;
+            const int K1_16 = (c_in + 15) & ~15, K2_16 = (3 * Cmp + 15) & ~15, K3_16 = (Cmp + 15) & ~15;
+            const int Ksc = ksc != (size_t)-1 ? c_in : 0, Ksc16 = (Ksc + 15) & ~15;
+            const size_t w_floats = (size_t)(K1_16 + K2_16) * NPm + (size_t)(K3_16 + Ksc16) * NPo;
+            if ((w_floats + (size_t)2 * (128 + 4) * Cmp) * 4 > lds_cap) continue;
+            std::vector<float> w1q((size_t)K1_16 * NPm, 0.0f), w2q((size_t)K2_16 * NPm, 0.0f), w3q((size_t)(K3_16 + Ksc16) * NPo, 0.0f);
+            std::vector<float> b1(16 * ntm, 0.0f), b2(16 * ntm, 0.0f), b3(16 * nto, 0.0f);
+            for (int co = 0; co < c_mid; ++co) {
+                b1[co] = hb[k1][co];
+                b2[co] = hb[k1 + 1][co];
+                for (int ci = 0; ci < c_in; ++ci) w1q[((size_t)(ci / 4) * NPm + co) * 4 + ci % 4] = hw[k1][(size_t)co * c_in + ci];
+                for (int ci = 0; ci < c_mid; ++ci)
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const int kidx = kk * Cmp + ci;
+                        w2q[((size_t)(kidx / 4) * NPm + co) * 4 + kidx % 4] = hw[k1 + 1][((size_t)co * c_mid + ci) * 3 + kk];
+                    }
+            }
+            for (int co = 0; co < c_out; ++co) {
+                b3[co] = hb[k1 + 2][co] + (ksc != (size_t)-1 ? hb[ksc][co] : 0.0f);
+                for (int ci = 0; ci < c_mid; ++ci) w3q[((size_t)(ci / 4) * NPo + co) * 4 + ci % 4] = hw[k1 + 2][(size_t)co * c_mid + ci];
+                if (ksc != (size_t)-1)
+                    for (int ci = 0; ci < c_in; ++ci) {
+                        const int kidx = K3_16 + ci;
+                        w3q[((size_t)(kidx / 4) * NPo + co) * 4 + kidx % 4] = hw[ksc][(size_t)co * c_in + ci];
+                    }
+            }
+            hipError_t e = upload_vec(&o.d_f_w1, w1q);
+            if (e == hipSuccess) e = upload_vec(&o.d_f_w2, w2q);
+            if (e == hipSuccess) e = upload_vec(&o.d_f_w3, w3q);
+            if (e == hipSuccess) e = upload_vec(&o.d_f_b1, b1);
+            if (e == hipSuccess) e = upload_vec(&o.d_f_b2, b2);
+            if (e == hipSuccess) e = upload_vec(&o.d_f_b3, b3);
+            if (e != hipSuccess) return e;
+            o.fuse = 3;
+            o.fuse_skip = (int)(k1 + 2 - k);
+            o.f_src = X;
+            o.f_dst = d3.dst;
+            o.f_cin = c_in;
+            o.f_cmid = c_mid;
+            o.f_cout = c_out;
+            o.f_cp = Cmp;
+            o.f_npm = NPm;
+            o.f_nps = NPo;
+            o.f_stride = d2.stride;
+            o.f_ksc = Ksc;
+            o.f_ntm = ntm;
+            o.f_nt = nto;
+            o.f_wfloats = w_floats;
+            k = k1 + 2;
+            continue;
+        }
         if (!dead_after(ops, k1 + 1, c1.dst) || (ksc != (size_t)-1 && !dead_after(ops, k1 + 1, res))) continue;
         const int c_in = c1.c_in, c_out = c1.c_out, nt = (c_out + 15) / 16;
         if (nt > 5) continue;
@@ -951,6 +1215,8 @@ int rs_seqnet_destroy(rs_seqnet* m) {
         if (o.d_w) (void)hipFree(o.d_w);
         if (o.d_b) (void)hipFree(o.d_b);
         if (o.d_wq) (void)hipFree(o.d_wq);
+        if (o.d_f_w3) (void)hipFree(o.d_f_w3);
+        if (o.d_f_b3) (void)hipFree(o.d_f_b3);
         if (o.d_f_w1) (void)hipFree(o.d_f_w1);
         if (o.d_f_w2) (void)hipFree(o.d_f_w2);
         if (o.d_f_b1) (void)hipFree(o.d_f_b1);
@@ -1071,6 +1337,49 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                 const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, lds_cap / f_lds));
                 const int grid = std::min(a.n_tiles, m->num_cu * per_cu);
                 hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), f_lds, st, a);
+                RS_HIP(hipGetLastError());
+                last = o.f_dst;
+                k += o.fuse_skip;
+                continue;
+            }
+        }
+        if (o.fuse == 3) {
+            // residual bottleneck block in one launch; shapes: conv 1 = ops[k + skip - 2], conv 2 (the strided one) = [k + skip - 1]
+            const OpShape& s1 = shp[k + o.fuse_skip - 2];
+            const OpShape& s2 = shp[k + o.fuse_skip - 1];
+            const int64_t xb = (int64_t)B * s1.t_in * o.f_cin * 4;
+            if (xb < 0x7fffffffLL && (int64_t)B * s2.t_out * o.f_cout * 4 < 0x7fffffffLL) {
+                BneckArgs a;
+                a.x = buf(o.f_src);
+                a.x_bytes = (unsigned)xb;
+                a.y = buf(o.f_dst);
+                a.w1q = o.d_f_w1; a.b1 = o.d_f_b1; a.w2q = o.d_f_w2; a.b2 = o.d_f_b2; a.w3q = o.d_f_w3; a.b3 = o.d_f_b3;
+                a.NPm = o.f_npm;
+                a.NPo = o.f_nps;
+                a.B = B;
+                a.T_in = s1.t_in;
+                a.T_out = s2.t_out;
+                a.c_in = o.f_cin;
+                a.c_mid = o.f_cmid;
+                a.c_out = o.f_cout;
+                a.Cmp = o.f_cp;
+                a.stride = o.f_stride;
+                a.Ksc = o.f_ksc;
+                a.R2 = (128 - 3) / o.f_stride + 1;
+                a.tiles_per_read = (s2.t_out + a.R2 - 1) / a.R2;
+                a.n_tiles = B * a.tiles_per_read;
+                using Fn = void (*)(const BneckArgs);
+                static const Fn table[2][5] = {
+                    {seq_bottleneck_block_kernel<1, 1>, seq_bottleneck_block_kernel<1, 2>, seq_bottleneck_block_kernel<1, 3>,
+                     seq_bottleneck_block_kernel<1, 4>, seq_bottleneck_block_kernel<1, 5>},
+                    {seq_bottleneck_block_kernel<2, 1>, seq_bottleneck_block_kernel<2, 2>, seq_bottleneck_block_kernel<2, 3>,
+                     seq_bottleneck_block_kernel<2, 4>, seq_bottleneck_block_kernel<2, 5>}};
+                Fn fn = table[o.f_ntm - 1][o.f_nt - 1];
+                const size_t f_lds = (o.f_wfloats + (size_t)2 * (128 + 4) * o.f_cp) * 4;
+                RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / f_lds));
+                const int grid = std::min(a.n_tiles, m->num_cu * per_cu);
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(256), f_lds, st, a);
                 RS_HIP(hipGetLastError());
                 last = o.f_dst;
                 k += o.fuse_skip;

@@ -95,9 +95,9 @@ def program_flops(prog, L: int) -> float:
 
 def program_traffic_bytes(prog, L: int, fused: bool = True) -> float:
     """fp32 bytes one chunk of L samples moves through HBM under the launch structure rs_seqnet_create builds: every
-    launch reads its input(s) once and writes its output once.  fused=True: the stem conv + max-pool and every basic
-    residual block (optional 1x1 shortcut conv, conv3, conv3 + residual) are one launch each (csrc/seqnet.hip:
-    fuse_program); fused=False: one launch per op."""
+    launch reads its input(s) once and writes its output once.  fused=True: the stem conv + max-pool and every residual
+    block (optional 1x1 shortcut conv; conv3, conv3 + residual - or conv1, conv3, conv1 + residual) are one launch each
+    (csrc/seqnet.hip: fuse_program); fused=False: one launch per op."""
     T, C = {0: L}, {0: 1}
     shapes = []
     for o in prog:
@@ -122,8 +122,14 @@ def program_traffic_bytes(prog, L: int, fused: bool = True) -> float:
             k1 = k + 1 if sc else k
             if (k1 + 1 < len(prog) and prog[k1]["kind"] == 0 and prog[k1 + 1]["kind"] == 0 and prog[k1]["w"].shape[2] == 3
                     and prog[k1 + 1]["w"].shape[2] == 3 and prog[k1 + 1]["add"] == (o["dst"] if sc else prog[k1]["src"])):
-                total += shapes[k1][0] + shapes[k1 + 1][1]                   # block: x in, y out
+                total += shapes[k1][0] + shapes[k1 + 1][1]                   # basic block: x in, y out
                 k = k1 + 2
+                continue
+            if (k1 + 2 < len(prog) and all(prog[k1 + d]["kind"] == 0 for d in range(3)) and prog[k1]["w"].shape[2] == 1
+                    and prog[k1 + 1]["w"].shape[2] == 3 and prog[k1 + 2]["w"].shape[2] == 1
+                    and prog[k1 + 2]["add"] == (o["dst"] if sc else prog[k1]["src"])):
+                total += shapes[k1][0] + shapes[k1 + 2][1]                   # bottleneck block: x in, y out
+                k = k1 + 3
                 continue
         total += shapes[k][0] + shapes[k][1] + (shapes[k][1] if o.get("add", -1) >= 0 else 0)
         k += 1

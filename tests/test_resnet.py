@@ -54,17 +54,21 @@ def test_resnet_gpu_vs_reference(golden_dir, name):
     m.close()
 
 
+BOTTLENECK_WIDE_CFG = dict(channels=[32, 48, 68], kernel=19, padding=5, stride=3, block="bottleneck", n_layers=3,
+                           blocks=[2, 2, 1], n_classes=2)
+
+
 @pytest.mark.gpu
-def test_resnet_fused_blocks_equal_the_op_by_op_program():
-    """rs_seqnet_create fuses the stem (conv + BN + ReLU + MaxPool) and every basic residual block (two 3x3 convs, the 1x1
-    shortcut, add, ReLU) into one launch each; RS_SEQ_NOFUSE=1 runs the program one op per launch.  Same logits to fp32
-    round-off on the bench architecture (stride-2 stages, identity and conv shortcuts, ragged last tiles) at several
-    lengths, and against the oracle."""
+@pytest.mark.parametrize("cfg", [dict(synth.RESNET_BENCH_CFG), BOTTLENECK_WIDE_CFG], ids=["basic", "bottleneck"])
+def test_resnet_fused_blocks_equal_the_op_by_op_program(cfg):
+    """rs_seqnet_create fuses the stem (conv + BN + ReLU + MaxPool) and every residual block - basic (two 3x3 convs) and
+    bottleneck (1x1, strided 3x3, 1x1), with the 1x1 shortcut, add and ReLU - into one launch each; RS_SEQ_NOFUSE=1 runs
+    the program one op per launch.  Same logits to fp32 round-off (stride-2 stages, identity and conv shortcuts, ragged
+    last tiles) at several lengths, and against the oracle."""
     import torch
     from riser_amd.resnet import ResNetModel
     dev = torch.device("cuda", 0)
-    cfg = dict(synth.RESNET_BENCH_CFG)
-    sd = synth.make_resnet_state_dict(7)
+    sd = synth.make_resnet_state_dict(7, cfg)
     config = types.SimpleNamespace(resnet=types.SimpleNamespace(**cfg))
     fused = ResNetModel(sd, config, None, "x", device=dev)
     os.environ["RS_SEQ_NOFUSE"] = "1"
