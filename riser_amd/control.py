@@ -216,6 +216,7 @@ class SequencerControl:
         self._pinned = _Pinned(processor.device)
         self._res_probs = self._res_dec = None
         self._channels_seen = 0
+        self._reserved_for = 0
 
     # ------------------------------------------------------------------------------------
     def reserve(self, reads: int):
@@ -223,6 +224,7 @@ class SequencerControl:
         pays for a device allocation (a growing workspace is a multi-GB hipMalloc + hipFree inside a 1 s window)."""
         from .model import reserve_ensemble
         reserve_ensemble(self.models, int(reads), self.proc.get_max_length())
+        self._reserved_for = max(self._reserved_for, int(reads))
 
     def assess_batch(self, entries, mode, threshold, polyA_cache):
         """entries: list of (channel, read).  Returns one record per ASSESSED read, in
@@ -233,6 +235,8 @@ class SequencerControl:
         dev = proc.device
         B = len(entries)
         self._channels_seen = max(self._channels_seen, B)
+        if B > self._reserved_for:                 # first batch (a flow cell's channel count), or a larger one than ever seen
+            self.reserve(max(512, B))
         reads = [e[1] for e in entries]
         channels = np.fromiter((e[0] for e in entries), dtype=np.int64, count=B)
         ids = [r.id for r in reads]
