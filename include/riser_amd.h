@@ -25,8 +25,9 @@
  *     With it the conv stack lays the batch out in packed blocks (each read occupies len / U + 1 blocks of
  *     U = rs_block_samples() samples, work proportional to every read's own length) - the host needs the block count to
  *     size the launches; without it every read takes the blocks of an Lmax-sample read.  Results are bit-identical
- *     either way.  It must mirror d_len: a device length that disagrees can only cost that read its result (NaN
- *     probabilities), never a write outside the workspace.
+ *     either way.  It must mirror d_len: a device length that disagrees can only cost that read and the reads BEHIND it in
+ *     the batch their results (a read whose blocks no longer fit the table the host sized is dropped: NaN probabilities),
+ *     never a read in front of it, and never an access outside the workspace or the length array.
  *   - reads shorter than 2^n_layers samples (4096 for the shipped 12-layer net,
  *     riser/preprocess.py:8) cannot be classified: RS_ERR_LENGTH, matching the
  *     RuntimeError torch raises in max_pool1d for the reference.
@@ -40,6 +41,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#define RS_API __attribute__((visibility("default")))
 
 typedef enum rs_status {
     RS_OK = 0,
@@ -78,13 +81,13 @@ typedef enum rs_mode { RS_ENRICH = 0, RS_DEPLETE = 1 } rs_mode;
 typedef struct rs_model rs_model;
 
 /* Message of the last failing call on this thread ("" if none). */
-const char* rs_last_error(void);
+RS_API const char* rs_last_error(void);
 
 /* ABI version of this header: (major << 16) | minor. */
-int rs_version(void);
+RS_API int rs_version(void);
 
 /* Number of HIP devices visible (0 if none / no driver).  Does not select a device. */
-int rs_device_count(void);
+RS_API int rs_device_count(void);
 
 /*
  * Build a model on `device` from a reference-format ConvNet state dict.
@@ -99,25 +102,25 @@ int rs_device_count(void);
  *   n_classes           must be 2 (riser/control.py:69 unpacks exactly two probabilities)
  * Host pointers need only live for the duration of the call.
  */
-int rs_model_create(int n_layers, const int32_t* channels, int n_classes,
+RS_API int rs_model_create(int n_layers, const int32_t* channels, int n_classes,
                     const float* const* conv_w, const float* const* conv_b,
                     const float* fc_w, const float* fc_b,
                     int dtype /* rs_dtype */, int device, rs_model** out);
 
-int rs_model_destroy(rs_model* m);
+RS_API int rs_model_destroy(rs_model* m);
 
 /* Bytes of device workspace rs_forward / rs_classify need for a batch of B reads of at
  * most Lmax samples (0 on bad arguments): the block table, the normalised signals and two activation buffers. */
-size_t rs_workspace_bytes(const rs_model* m, int B, int Lmax);
+RS_API size_t rs_workspace_bytes(const rs_model* m, int B, int Lmax);
 
 /* Largest B one call accepts for reads of up to Lmax samples: every activation buffer is addressed through a 2 GiB
  * buffer-resource window (32-bit offsets, hardware bounds checking).  Reads are independent: split bigger batches. */
-int rs_max_batch(const rs_model* m, int Lmax);
+RS_API int rs_max_batch(const rs_model* m, int Lmax);
 
 /* Block size U of the packed activation layout in samples: 2^max(n_layers, 12) (4096 for the shipped net; doubled when
  * RS_WINO4 puts the last layer on the F(4,3) lowering).  Read b of a batch starts at sample U * sum_{i<b}(len_i / U + 1)
  * of the normalised-signal region and at row (that >> (layer + 1)) of conv layer `layer`'s output buffer. */
-int rs_block_samples(const rs_model* m);
+RS_API int rs_block_samples(const rs_model* m);
 
 /*
  * MAD normalisation + outlier smoothing of B reads.
@@ -132,7 +135,7 @@ int rs_block_samples(const rs_model* m);
  * Lmax is the host-known maximum of d_len (sizes the LDS staging buffer); every read
  * must have 1 <= len <= Lmax <= 65536.
  */
-int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
+RS_API int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
                  float* d_out32, int64_t ld32, int32_t pad_to,
                  double* d_out64, int64_t ld64, double* d_stats, void* stream);
 
@@ -145,7 +148,7 @@ int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
  * Every read must have 1 <= len; read b is d_sig[d_off[b] .. d_off[b] + d_len[b]) in elements.  d_stats: fp64 [B, 2]
  * = (median, mad) or NULL.  Off the live path: an exact radix select per read, not tuned.
  */
-int rs_normalise_float(const void* d_sig, int elem_bytes, const int64_t* d_off, const int32_t* d_len, int B,
+RS_API int rs_normalise_float(const void* d_sig, int elem_bytes, const int64_t* d_off, const int32_t* d_len, int B,
                        void* d_out, int64_t ld, double* d_stats, void* stream);
 
 /*
@@ -160,18 +163,18 @@ int rs_normalise_float(const void* d_sig, int elem_bytes, const int64_t* d_off, 
  *             tiles that fall entirely into the padding behind a read are skipped; when Lmin says no such tile
  *             can exist the per-tile test is not even compiled into the walk.
  */
-int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, const int32_t* h_len, int B, int Lmin,
+RS_API int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len, const int32_t* h_len, int B, int Lmin,
                int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, float* d_logits, void* stream);
 
 /* Samples a read of Lmax samples occupies in the packed layout: (Lmax / U + 1) * U, U = rs_block_samples(). */
-int rs_padded_length(const rs_model* m, int Lmax);
+RS_API int rs_padded_length(const rs_model* m, int Lmax);
 
 /*
  * Fused path: raw int16 reads -> normalise -> forward -> probabilities.
  * Equivalent to the pair of calls at riser/control.py:63 and :69 for every read of the
  * batch; the normalised signals live in the workspace.
  */
-int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, const int32_t* h_len,
+RS_API int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, const int32_t* h_len,
                 int B, int Lmin, int Lmax, void* d_ws, size_t ws_bytes,
                 float* d_probs, float* d_logits, void* stream);
 
@@ -185,7 +188,7 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
  * d_probs receives the batch's probabilities as rs_classify would produce them; *n_changed (optional) the number
  * of layers whose choice changed.  Costs a few hundred launches: call once per deployment batch size, not per batch.
  */
-int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, const int32_t* h_len, int B,
+RS_API int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, const int32_t* h_len, int B,
                 int Lmin, int Lmax, void* d_ws, size_t ws_bytes, float* d_probs, int32_t* n_changed, void* stream);
 
 /*
@@ -196,9 +199,15 @@ int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
  * device (see rs_decide for `max_len`, `threshold`, `mode`).
  *   d_probs     fp32 [n_models, B, 2]
  *   d_decision  uint8 [B] or NULL
- * The workspace is shared by the models: rs_workspace_bytes(models[0], B, Lmax).
+ * The workspace is shared by the models (block table and normalised signals once).  With
+ * rs_ensemble_workspace_bytes(models, n_models, B, Lmax) bytes every model has its own pair of activation buffers and the
+ * forwards run CONCURRENTLY (model 0 on `stream`, the others on library-owned side streams forked behind the normalise
+ * launch and joined in front of the decision; everything the call enqueues is ordered on `stream` as before).  With less,
+ * but at least the MAXIMUM of rs_workspace_bytes(models[k], B, Lmax) over the models, they run back to back on `stream`;
+ * below that the call is refused with RS_ERR_WORKSPACE.  The probabilities are the same bits either way.
  */
-int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d_sig, const int64_t* d_off,
+RS_API size_t rs_ensemble_workspace_bytes(rs_model* const* models, int n_models, int B, int Lmax);
+RS_API int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d_sig, const int64_t* d_off,
                          const int32_t* d_len, const int32_t* h_len, int B, int Lmin, int Lmax, void* d_ws,
                          size_t ws_bytes, float* d_probs, uint8_t* d_decision, int max_len, float threshold, int mode,
                          void* stream);
@@ -210,7 +219,7 @@ int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d
  *   d_out     uint8 [B], rs_decision values
  * Comparisons are strict `>` in fp32, as torch does for `tensor > python_float`.
  */
-int rs_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len,
+RS_API int rs_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len,
               float threshold, int mode /* rs_mode */, uint8_t* d_out, void* stream);
 
 /*
@@ -223,7 +232,7 @@ int rs_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, i
  * Reads may have any length (the whole signal is scanned, as the reference does; the scan stops at the first end
  * found, which nothing later in the signal can change).
  */
-int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B,
+RS_API int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B,
                  int32_t* d_end, void* stream);
 
 /*
@@ -233,7 +242,7 @@ int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
  * batch, and only the samples that are new since the last batch are uploaded (compacted, one transfer) and scattered
  * behind the ones already there.
  */
-int rs_copy_segments(const int16_t* d_src, int16_t* d_dst, const int64_t* d_src_off, const int64_t* d_dst_off,
+RS_API int rs_copy_segments(const int16_t* d_src, int16_t* d_dst, const int64_t* d_src_off, const int64_t* d_dst_off,
                      const int32_t* d_len, int n, void* stream);
 
 /* Introspection used by bench.py for roofline accounting: per conv layer i (0-based),
@@ -246,7 +255,7 @@ typedef struct rs_layer_info {
     int32_t bm, bn, kc;         /* workgroup tile (rows x couts) and channel chunk of the last launch (0 if never run) */
     int32_t gemm_row_div;       /* conv rows per GEMM row: 1 direct lowering, 2 Winograd F(2,3), 4 Winograd F(4,3) */
 } rs_layer_info;
-int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out);
+RS_API int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out);
 
 /*
  * Sequential conv programs: the secondary ResNet architecture (riser/nets/resnet.py:7-131; not
@@ -264,11 +273,11 @@ typedef struct rs_seq_op {
     const float* b;         /* HOST fp32 [c_out] */
 } rs_seq_op;
 typedef struct rs_seqnet rs_seqnet;
-int rs_seqnet_create(const rs_seq_op* ops, int n_ops, int n_buffers, const float* fc_w /* [2, c_last] */,
+RS_API int rs_seqnet_create(const rs_seq_op* ops, int n_ops, int n_buffers, const float* fc_w /* [2, c_last] */,
                      const float* fc_b, int c_last, int device, rs_seqnet** out);
-int rs_seqnet_destroy(rs_seqnet* m);
-size_t rs_seqnet_workspace_bytes(const rs_seqnet* m, int B, int L);
-int rs_seqnet_forward(rs_seqnet* m, const float* d_x /* fp32 [B, L] */, int B, int L, void* d_ws, size_t ws_bytes,
+RS_API int rs_seqnet_destroy(rs_seqnet* m);
+RS_API size_t rs_seqnet_workspace_bytes(const rs_seqnet* m, int B, int L);
+RS_API int rs_seqnet_forward(rs_seqnet* m, const float* d_x /* fp32 [B, L] */, int B, int L, void* d_ws, size_t ws_bytes,
                       float* d_probs, float* d_logits, void* stream);
 
 /*
@@ -277,7 +286,7 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x /* fp32 [B, L] */, int B, i
  * rs_block_samples - fp32 or 16-bit) into d_dst
  * (at most `bytes`).  d_dst = NULL switches it off.  Used by the layer-wise parity tests.
  */
-int rs_debug_capture_layer(rs_model* m, int layer, void* d_dst, size_t bytes);
+RS_API int rs_debug_capture_layer(rs_model* m, int layer, void* d_dst, size_t bytes);
 
 /*
  * Stage timing with HIP events on the launch stream (used by bench.py's roofline leg).
@@ -292,8 +301,8 @@ int rs_debug_capture_layer(rs_model* m, int layer, void* d_dst, size_t bytes);
  * at the call's start, after normalise + layer 0 (their time lands in stage 1), after the LAST conv layer (the
  * whole conv stack, layers 1 .. n-1, lands in stage n_layers) and after the head: what bench.py's timed region uses.
  */
-int rs_profile_enable(rs_model* m, int on);
-int rs_profile_read(rs_model* m, float* stage_ms, int32_t* calls);
+RS_API int rs_profile_enable(rs_model* m, int on);
+RS_API int rs_profile_read(rs_model* m, float* stage_ms, int32_t* calls);
 
 #ifdef __cplusplus
 }

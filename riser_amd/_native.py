@@ -21,7 +21,7 @@ DECISION_NAMES = ("try_again", "accept", "reject", "no_decision")
 SYMBOLS = (
     "rs_last_error", "rs_version", "rs_device_count", "rs_model_create", "rs_model_destroy",
     "rs_workspace_bytes", "rs_max_batch", "rs_block_samples", "rs_normalise", "rs_normalise_float", "rs_forward", "rs_padded_length", "rs_classify",
-    "rs_classify_ensemble", "rs_autotune", "rs_decide", "rs_polya_end", "rs_copy_segments", "rs_model_layer_info", "rs_profile_enable", "rs_profile_read",
+    "rs_classify_ensemble", "rs_ensemble_workspace_bytes", "rs_autotune", "rs_decide", "rs_polya_end", "rs_copy_segments", "rs_model_layer_info", "rs_profile_enable", "rs_profile_read",
     "rs_debug_capture_layer",
     "rs_seqnet_create", "rs_seqnet_destroy", "rs_seqnet_workspace_bytes", "rs_seqnet_forward",
 )
@@ -87,6 +87,8 @@ def lib():
     L.rs_classify_ensemble.restype = i32
     L.rs_classify_ensemble.argtypes = [C.POINTER(vp), i32, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp, vp, i32, C.c_float,
                                        i32, vp]
+    L.rs_ensemble_workspace_bytes.restype = sz
+    L.rs_ensemble_workspace_bytes.argtypes = [C.POINTER(vp), i32, i32, i32]
     L.rs_decide.restype = i32
     L.rs_decide.argtypes = [vp, i32, i32, vp, i32, C.c_float, i32, vp, vp]
     L.rs_polya_end.restype = i32

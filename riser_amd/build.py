@@ -23,7 +23,7 @@ ARCH = "gfx950"
 SOURCES = ["api.hip", "normalise.hip", "normalise_float.hip", "pointwise.hip", "conv_f32.hip", "conv_wino.hip", "conv_wino4.hip", "conv_stream_f32.hip", "conv_h16.hip", "conv_ring_h16.hip", "conv_wres_h16.hip", "conv_stream_h16.hip", "polya.hip", "seqnet.hip"]
 # -ffp-contract=off: the normalise kernel must reproduce numpy's separately rounded fp64
 # operations; the conv kernels use explicit fmaf / MFMA so they lose nothing.
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 
 
@@ -75,8 +75,31 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), lib_name: 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB])
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden",
+             "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), *objs, "-o", LIB])
+    if not lib_name:
+        build_hostpack(force, run)
     return LIB
+
+
+HOSTPACK = os.path.join(HERE, "_hostpack.so")
+
+
+def build_hostpack(force: bool = False, run=None) -> str:
+    """riser_amd/_hostpack.so: the per-read host loops of the control loop (csrc/hostpack.c, CPython C API, gcc; no GPU
+    code).  Optional at run time: control.py falls back to the Python loops when it is missing."""
+    import sysconfig
+    src = os.path.join(CSRC, "hostpack.c")
+    if force or _stale(HOSTPACK, [src]):
+        cc = shutil.which("gcc") or shutil.which("cc")
+        if not cc:
+            raise RuntimeError("gcc not found (riser_amd/_hostpack.so)")
+        cmd = [cc, "-O2", "-shared", "-fPIC", "-Wall", "-pthread", "-I" + sysconfig.get_paths()["include"], src, "-o", HOSTPACK]
+        if run:
+            run(cmd)
+        else:
+            subprocess.run(cmd, check=True)
+    return HOSTPACK
 
 
 if __name__ == "__main__":

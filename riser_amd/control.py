@@ -6,22 +6,28 @@ order as the reference.  The difference is the shape of the work: the reference 
 (<= 512) reads of a ReadUntil batch one at a time - trim, normalise, one forward per model at
 batch 1, a device sync per probability (riser/control.py:31-93,152) - whereas this loop
 
-  1. keeps the raw int16 signal of every read in flight RESIDENT ON THE DEVICE, one row per channel: an
-     AccumulatingCache client (riser/client.py:29-31) re-sends a read's whole signal with every batch, and only the
-     samples that are new since the last batch cross PCIe (one compacted transfer + one scatter launch),
+  1. stages the raw int16 signals of the batch in pinned host memory and uploads them in one transfer.  A client that
+     re-sends a read's WHOLE signal with every batch (an accumulating client) gets a device-resident signal store: one
+     row per channel, and only the samples behind what the row already holds cross PCIe - after the overlap with the
+     held samples has been verified (see _SignalStore); a client that delivers disjoint chunks under one read id (what
+     `get_read_chunks(last=True)` of riser/client.py:44 does between two pops) is detected and uploaded whole,
   2. finds the poly(A) ends of all un-cached reads in one kernel launch,
-  3. applies the reference's length gating on the host as array arithmetic (a trim is an offset into the resident
+  3. applies the reference's length gating on the host as array arithmetic (a trim is an offset into the staged
      signal, a truncation is a length),
   4. normalises every assessable read once and runs one batched forward per model,
   5. takes the ensemble decision on the device and copies probabilities + decisions back in
-     a single synchronisation.
+     a single synchronisation,
+  6. sends the reject / finish calls, THEN writes the CSV rows of the batch (the reference writes each row before the
+     calls; the file's content is the same, the pore learns its decision earlier).
 
-Host work per batch is numpy over arrays of the batch's reads; the only per-read Python is what the client's own
-interface forces (one `get_raw_signal` call and one `read.id` per read) and the text of the CSV rows.
+Host work per batch is numpy over arrays of the batch's reads.  What is left per read in Python is what the client's own
+interface forces - one `get_raw_signal` call and one `read.id` per read; a client that declares `raw_data_dtype = np.int16`
+(its get_raw_signal is np.frombuffer(read.raw_data, int16), as riser/client.py:46-47 is) has its reads walked by the C loops
+of riser_amd/_hostpack instead.
 
-The polyA cache only memoises a deterministic prefix property of a read, so its state
-never changes results; it is cleared at batch granularity once it holds >= 1000 entries
-(riser/control.py:96-97 does so per read).
+The polyA cache only memoises a deterministic prefix property of a read (the scan of riser/preprocess.py:42-79 is causal:
+an end found on a prefix is the end of every extension, tests/test_gpu_more.py), so its state never changes results; it
+is dropped at batch granularity once it holds >= 1000 entries (riser/control.py:96-97 does so per read).
 """
 from __future__ import annotations
 
@@ -34,6 +40,11 @@ import torch
 from . import _native as nv
 from .model import classify_raw_ensemble
 
+try:                                     # optional C loops over the reads of a batch (riser_amd/csrc/hostpack.c)
+    from . import _hostpack as _hp
+except ImportError:                      # not built: the Python loops below do the same work
+    _hp = None
+
 _MODE = {"enrich": nv.RS_ENRICH, "deplete": nv.RS_DEPLETE}
 
 # user-visible behaviour of the reference that a drop-in must keep (riser/control.py:100-103, 125-133, 145-148):
@@ -44,6 +55,8 @@ _WARN_STOP = 'RISER has stopped running.'
 _CSV_COLUMNS = ("batch_start", "read_id", "channel", "sig_length", "models", "prob_targets", "threshold", "mode",
                 "decision")
 _CACHE_LIMIT = 1000                  # poly(A) cache entries before it is dropped (riser/control.py:96-97)
+_MINION_CHANNELS = 512               # riser/client.py:11
+PHASES = ("client_reads", "stage_upload", "polya_sync", "gate_launch", "device_wait", "client_calls", "csv")
 
 
 class _MinuteTally:
@@ -95,21 +108,67 @@ class _Pinned:
         return host.to(self.device, non_blocking=True)
 
 
+class _Batch:
+    """The reads of one ReadUntil batch, as the store sees them: ids, lengths and a way to stage `raw[start:]` of every
+    read back to back.  Two implementations of the per-read walk: the client's own get_raw_signal (the eight-method duck
+    type), or the C loops of _hostpack for clients whose raw_data IS the int16 signal."""
+
+    def __init__(self, client, reads):
+        self.reads = reads
+        B = len(reads)
+        self.ids = np.fromiter((r.id for r in reads), dtype=object, count=B)
+        declared = getattr(client, "raw_data_dtype", None)
+        self.native = _hp is not None and declared is not None and np.dtype(declared) == np.int16
+        if self.native:
+            self.raws = None
+            self.lens = np.empty(B, dtype=np.int64)
+            _hp.lengths(reads, self.lens)
+        else:
+            get = client.get_raw_signal
+            raws = [get(r) for r in reads]
+            if B and raws[0].dtype != np.int16:
+                from .preprocess import _as_int16
+                raws = [_as_int16(s) for s in raws]
+            self.raws = raws
+            self.lens = np.fromiter((s.shape[0] for s in raws), dtype=np.int64, count=B)
+
+    def stage(self, start: np.ndarray, out: np.ndarray) -> int:
+        """out[: total] = concat(raw_i[start_i:]) -> total"""
+        if self.native:
+            return int(_hp.gather(self.reads, np.ascontiguousarray(start, dtype=np.int64), out))
+        total = int((self.lens - start).sum())
+        if start.any():
+            np.concatenate([r[s:] for r, s in zip(self.raws, start.tolist())], out=out[:total])
+        else:
+            np.concatenate(self.raws, out=out[:total])
+        return total
+
+
 class _SignalStore:
     """Raw int16 signals of a batch on the device -> per-read offsets into one device buffer.
 
-    resident=True: one row of `pitch` samples per channel holds the read currently in that pore; a read that was
-    already there (same id, not shorter) uploads only the samples behind what the row holds.  The client contract this
-    relies on is AccumulatingCache's: the same read id always carries the same signal prefix (riser/client.py:29-31).
+    resident=True: one row of `pitch` samples per channel holds the read currently in that pore.  A read that arrives
+    again under the same id, not shorter than what the row holds, is a CANDIDATE for the delta path: its samples from
+    TAIL before the held length on are staged and uploaded, and the first TAIL of them must equal the last TAIL samples
+    the row holds (kept on the host) before the upload is scattered behind the held prefix.  A candidate that fails the
+    comparison - a client that delivers disjoint chunks under one id, as ReadUntilClient.get_read_chunks does between two
+    pops of its cache (riser/client.py:44) - is uploaded whole, exactly as with resident=False; when most re-seen reads
+    of three consecutive batches fail, the store stops trying for the rest of the run (`auto_off`).  What the delta path
+    therefore rests on: the client re-sends the same samples for [have - TAIL, have) - for a re-sent prefix always true,
+    for a disjoint chunk of a noisy ADC signal never - not on a hash and not on trust in the client's contract.
     Reads longer than a row are uploaded whole into a spill area behind the rows.
-    resident=False: every batch uploads every read whole (the round-2 behaviour; kept for the A/B in bench.py)."""
+    resident=False: every batch uploads every read whole."""
 
-    def __init__(self, device, resident: bool = True, pitch: int = 32768):
+    TAIL = 32
+
+    def __init__(self, device, resident: bool = True, pitch: int = 32768, logger=None):
         self.device, self.resident, self.pitch = device, resident, int(pitch)
+        self.logger = logger
         self.rowmap = np.full(1024, -1, dtype=np.int64)          # channel -> row
         self.n_rows = 0
-        self.row_hash = np.zeros(0, dtype=np.int64)              # hash(read id) of the read a row holds
+        self.row_id = np.empty(0, dtype=object)                  # id of the read a row holds
         self.row_have = np.zeros(0, dtype=np.int64)              # samples of it on the device
+        self.row_tail = np.zeros((0, self.TAIL), dtype=np.int16)  # the last TAIL of them
         self.cap_rows = 0
         self.spill_cap = 0
         self.buf = None                                          # int16 [cap_rows * pitch + spill_cap]
@@ -117,6 +176,19 @@ class _SignalStore:
         self.stage_dev = None
         self.samples_uploaded = 0                                # statistics: what crossed PCIe / what a full re-upload
         self.samples_presented = 0                               # of every batch would have carried
+        self.delta_reads = 0                                     # reads that took the delta path
+        self.mismatches = 0                                      # candidates whose overlap did not match (uploaded whole)
+        self.auto_off = False
+        self._bad_streak = 0
+
+    def reserve(self, rows: int, samples: int):
+        """device rows / pinned staging for batches of up to `rows` reads carrying up to `samples` new samples"""
+        self._ensure(rows if self.resident else 0, 1 << 20)
+        self._stage(samples, exact=True)
+        if self.resident and rows > self.rowmap.shape[0]:
+            grown = np.full(rows + 1, -1, dtype=np.int64)
+            grown[: self.rowmap.shape[0]] = self.rowmap
+            self.rowmap = grown
 
     def _ensure(self, rows: int, spill: int):
         if self.buf is not None and rows <= self.cap_rows and spill <= self.spill_cap:
@@ -128,30 +200,15 @@ class _SignalStore:
             buf[: self.cap_rows * self.pitch].copy_(self.buf[: self.cap_rows * self.pitch])
         self.buf, self.cap_rows, self.spill_cap = buf, new_rows, new_spill
 
-    def _stage(self, n: int):
+    def _stage(self, n: int, exact: bool = False):
         if self.stage is None or self.stage.numel() < n:
-            cap = max(2 * n, 1 << 22)          # generous: pinning memory is a slow system call, growth must be rare
+            cap = max(n if exact else 2 * n, 1 << 22)   # generous: pinning memory is a slow system call, growth must be rare
             self.stage = torch.empty(cap, dtype=torch.int16).pin_memory()
             self.stage_dev = torch.empty(cap, dtype=torch.int16, device=self.device)
         return self.stage.numpy()
 
-    def update(self, channels: np.ndarray, ids, raws, lens: np.ndarray, pinned: _Pinned) -> np.ndarray:
-        """-> int64 [B]: offset of every read's first sample in self.buf"""
-        B = len(raws)
-        self.samples_presented += int(lens.sum())
-        # the staging buffers below are re-used: whatever the previous batch still has in flight must have landed
-        torch.cuda.current_stream(self.device).synchronize()
-        if not self.resident:
-            total = int(lens.sum())
-            offs = np.zeros(B, dtype=np.int64)
-            np.cumsum(lens[:-1], out=offs[1:])
-            self._ensure(0, total)
-            stage = self._stage(total)
-            np.concatenate(raws, out=stage[:total])
-            self.buf[:total].copy_(self.stage[:total], non_blocking=True)
-            self.samples_uploaded += total
-            return offs
-        # ---- rows: one per channel, assigned at first sight ---------------------------------------------------------
+    def _rows_of(self, channels: np.ndarray) -> np.ndarray:
+        """one row per channel, assigned at first sight"""
         if int(channels.min()) < 0:
             raise ValueError("negative channel number")
         cmax = int(channels.max())
@@ -162,19 +219,57 @@ class _SignalStore:
         rows = self.rowmap[channels]
         fresh = np.flatnonzero(rows < 0)
         if fresh.size:
-            uniq, first = np.unique(channels[fresh], return_index=True)     # a channel appears once per batch, but be safe
+            uniq = np.unique(channels[fresh])                           # a channel appears once per batch, but be safe
             self.rowmap[uniq] = self.n_rows + np.arange(uniq.size)
             self.n_rows += int(uniq.size)
-            self.row_hash = np.concatenate([self.row_hash, np.zeros(uniq.size, dtype=np.int64)])
+            self.row_id = np.concatenate([self.row_id, np.full(uniq.size, None, dtype=object)])
             self.row_have = np.concatenate([self.row_have, np.zeros(uniq.size, dtype=np.int64)])
+            self.row_tail = np.concatenate([self.row_tail, np.zeros((uniq.size, self.TAIL), dtype=np.int16)])
             rows = self.rowmap[channels]
-        hashes = np.fromiter(map(hash, ids), dtype=np.int64, count=B)
+        return rows
+
+    def update(self, channels: np.ndarray, batch: _Batch, pinned: _Pinned) -> np.ndarray:
+        """-> int64 [B]: offset of every read's first sample in self.buf"""
+        lens = batch.lens
+        B = lens.shape[0]
+        presented = int(lens.sum())
+        self.samples_presented += presented
+        # the staging buffers below are re-used: whatever the previous batch still has in flight must have landed
+        torch.cuda.current_stream(self.device).synchronize()
+        if not self.resident:
+            offs = np.zeros(B, dtype=np.int64)
+            np.cumsum(lens[:-1], out=offs[1:])
+            self._ensure(0, presented)
+            total = batch.stage(np.zeros(B, dtype=np.int64), self._stage(presented))
+            self.buf[:total].copy_(self.stage[:total], non_blocking=True)
+            self.samples_uploaded += total
+            return offs
+        T = self.TAIL
+        rows = self._rows_of(channels)
         fits = lens <= self.pitch
         if np.unique(rows).size != B:                               # two reads of one channel in one batch: nothing resident
             fits = np.zeros(B, dtype=bool)
-        same = fits & (self.row_hash[rows] == hashes) & (self.row_have[rows] <= lens) & (self.row_have[rows] > 0)
-        start = np.where(same, self.row_have[rows], 0)
-        seg_len = lens - start
+        have = self.row_have[rows]
+        reseen = fits & (self.row_id[rows] == batch.ids) & (have > 0)
+        cand = reseen & (have <= lens) & (have >= T)
+        stage = self._stage(presented)
+        tail_ix = np.arange(T, dtype=np.int64)
+        while True:
+            start = np.where(cand, have - T, 0)
+            seg_len = lens - start
+            src = np.zeros(B, dtype=np.int64)
+            np.cumsum(seg_len[:-1], out=src[1:])
+            total = batch.stage(start, stage)
+            ci = np.flatnonzero(cand)
+            if ci.size == 0:
+                break
+            ok = (stage[src[ci][:, None] + tail_ix] == self.row_tail[rows[ci]]).all(axis=1)
+            if ok.all():
+                break
+            cand[ci[~ok]] = False                                   # not the prefix the row holds: whole, and staged again
+            self.mismatches += int((~ok).sum())
+        n_reseen, n_delta = int(reseen.sum()), int(cand.sum())
+        self.delta_reads += n_delta
         # reads longer than a row: whole, into the spill area, nothing remembered
         spill_len = np.where(fits, 0, lens)
         spill_off = np.zeros(B, dtype=np.int64)
@@ -182,18 +277,16 @@ class _SignalStore:
         self._ensure(self.n_rows, int(spill_len.sum()))
         spill_base = self.cap_rows * self.pitch
         dst = np.where(fits, rows * self.pitch + start, spill_base + spill_off)
-        self.row_hash[rows[fits]] = hashes[fits]
-        self.row_have[rows[fits]] = lens[fits]
+        fi = np.flatnonzero(fits)
+        self.row_id[rows[fi]] = batch.ids[fi]
+        self.row_have[rows[fi]] = lens[fi]
         self.row_have[rows[~fits]] = 0
+        keep = fi[lens[fi] >= T]                                    # the new tails: the last T staged samples of each read
+        if keep.size:
+            self.row_tail[rows[keep]] = stage[(src[keep] + seg_len[keep] - T)[:, None] + tail_ix]
         # ---- the new samples, compacted: one transfer, one scatter ------------------------------------------------
-        total = int(seg_len.sum())
         self.samples_uploaded += total
         if total:
-            src = np.zeros(B, dtype=np.int64)
-            np.cumsum(seg_len[:-1], out=src[1:])
-            stage = self._stage(total)
-            st = start.tolist()
-            np.concatenate([r[s:] for r, s in zip(raws, st)], out=stage[:total])
             self.stage_dev[:total].copy_(self.stage[:total], non_blocking=True)
             live = np.flatnonzero(seg_len > 0)
             d_src = pinned.to_device(np.ascontiguousarray(src[live]))
@@ -202,35 +295,87 @@ class _SignalStore:
             nv.check(nv.lib().rs_copy_segments(self.stage_dev.data_ptr(), self.buf.data_ptr(), d_src.data_ptr(),
                                                d_dst.data_ptr(), d_len.data_ptr(), int(live.size),
                                                torch.cuda.current_stream(self.device).cuda_stream), "rs_copy_segments")
+        # a client whose re-seen reads are mostly NOT extensions of what the rows hold gains nothing from the rows
+        if n_reseen >= 16 and n_delta * 2 < n_reseen:
+            self._bad_streak += 1
+            if self._bad_streak >= 3:
+                self.resident, self.auto_off = False, True
+                if self.logger is not None:
+                    self.logger.info("Signal store: re-seen reads do not extend the signal already on the device (this client "
+                                     "delivers chunks, not whole reads): every read is uploaded whole from now on.")
+        elif n_reseen:
+            self._bad_streak = 0
         return np.where(fits, rows * self.pitch, spill_base + spill_off)
+
+
+class _Assessed:
+    """What one batch's assessment produced, as arrays over the ASSESSED reads in batch order."""
+    __slots__ = ("reads", "sel", "channels", "n_samples", "p_on", "decision")
+
+    def __init__(self, reads, sel, channels, n_samples, p_on, decision):
+        self.reads, self.sel, self.channels, self.n_samples, self.p_on, self.decision = (reads, sel, channels, n_samples,
+                                                                                         p_on, decision)
+
+    def __len__(self):
+        return int(self.sel.shape[0])
+
+    def records(self):
+        """one tuple per assessed read: (channel, read, sig_length, [p_on per model], decision str)"""
+        names = nv.DECISION_NAMES
+        return [(c, self.reads[i], n, p, names[d]) for i, c, n, p, d in
+                zip(self.sel.tolist(), self.channels.tolist(), self.n_samples.tolist(), self.p_on.tolist(),
+                    self.decision.tolist())]
 
 
 class SequencerControl:
     def __init__(self, client, models, processor, logger, out_file, signal_cache: bool = True):
-        """signal_cache=False re-uploads every read whole with every batch (no device-resident signals)."""
+        """signal_cache=False uploads every read whole with every batch (no device-resident signals)."""
         self.client, self.models, self.proc, self.logger = client, models, processor, logger
         self.out_filename = out_file
-        # host wall time of the most recent assessed batches (seconds): bounded, a run lasts tens of hours
+        # host wall time of the most recent assessed batches (seconds): bounded, a run lasts tens of hours.
+        # batch_latencies: get_read_batch() -> reject / finish calls sent (what the pore waits for);
+        # batch_loop_times: the whole iteration, CSV rows included; batch_phases: seconds per PHASES entry
         self.batch_latencies = deque(maxlen=4096)
-        self._store = _SignalStore(processor.device, resident=signal_cache)
+        self.batch_loop_times = deque(maxlen=4096)
+        self.batch_phases = deque(maxlen=4096)
+        self._store = _SignalStore(processor.device, resident=signal_cache, logger=logger)
         self._pinned = _Pinned(processor.device)
         self._res_probs = self._res_dec = None
         self._channels_seen = 0
         self._reserved_for = 0
+        self._ph = np.zeros(len(PHASES))
 
     # ------------------------------------------------------------------------------------
     def reserve(self, reads: int):
-        """Allocate the models' workspaces for batches of up to `reads` assessable reads now, so that no batch of the run
-        pays for a device allocation (a growing workspace is a multi-GB hipMalloc + hipFree inside a 1 s window)."""
+        """Allocate everything a batch of up to `reads` reads needs now - the models' workspaces, the signal store's
+        device rows, the pinned staging buffers and the result buffers - so that no batch of the run pays for a device
+        allocation or a page-locking system call (a growing workspace is a multi-GB hipMalloc + hipFree inside a 1 s
+        window)."""
         from .model import reserve_ensemble
-        reserve_ensemble(self.models, int(reads), self.proc.get_max_length())
-        self._reserved_for = max(self._reserved_for, int(reads))
+        reads = int(reads)
+        reserve_ensemble(self.models, reads, self.proc.get_max_length())
+        # a first batch carries every read whole: typically <= 6 s of signal per pore
+        self._store.reserve(reads, min(reads * 24576, 1 << 29))
+        self._pinned.reset(96 * reads + (1 << 12))
+        self._result_buffers(reads)
+        self._reserved_for = max(self._reserved_for, reads)
+
+    def _result_buffers(self, n: int):
+        n_models = len(self.models)
+        if self._res_probs is None or self._res_probs.dev.shape[1] < n or self._res_probs.dev.shape[0] != n_models:
+            dev = self.proc.device
+            cap = max(n, 512)
+            self._res_probs = _Pair(torch.empty((n_models, cap, 2), dtype=torch.float32, device=dev),
+                                    torch.empty((n_models, cap, 2), dtype=torch.float32).pin_memory())
+            self._res_dec = _Pair(torch.empty(cap, dtype=torch.uint8, device=dev),
+                                  torch.empty(cap, dtype=torch.uint8).pin_memory())
 
     def assess_batch(self, entries, mode, threshold, polyA_cache):
-        """entries: list of (channel, read).  Returns one record per ASSESSED read, in
-        batch order: (channel, read, sig_length, [p_on per model], decision str)."""
+        """entries: list of (channel, read).  -> _Assessed (the assessed reads in batch order) or None."""
         if not entries:
-            return []
+            return None
+        ph = self._ph
+        t = time.perf_counter()
         proc = self.proc
         dev = proc.device
         B = len(entries)
@@ -239,20 +384,20 @@ class SequencerControl:
             self.reserve(max(512, B))
         reads = [e[1] for e in entries]
         channels = np.fromiter((e[0] for e in entries), dtype=np.int64, count=B)
-        ids = [r.id for r in reads]
-        get = self.client.get_raw_signal
-        raws = [get(r) for r in reads]
-        if raws[0].dtype != np.int16:
-            from .preprocess import _as_int16
-            raws = [_as_int16(s) for s in raws]
-        lens = np.fromiter((s.shape[0] for s in raws), dtype=np.int64, count=B)
-        self._pinned.reset(64 * B + (1 << 12))
-        offs = self._store.update(channels, ids, raws, lens, self._pinned)
+        batch = _Batch(self.client, reads)
+        ids, lens = batch.ids, batch.lens
+        t, ph[0] = self._tick(t, 0)
+        self._pinned.reset(96 * B + (1 << 12))
+        offs = self._store.update(channels, batch, self._pinned)
         sig = self._store.buf
+        t, ph[1] = self._tick(t, 1)
 
         # -- poly(A) end for reads not in the cache: one launch -------------------------------
-        cget = polyA_cache.get
-        end = np.fromiter((cget(i, 0) for i in ids), dtype=np.int64, count=B)
+        if polyA_cache:
+            cget = polyA_cache.get
+            end = np.fromiter((cget(i, 0) for i in ids), dtype=np.int64, count=B)
+        else:
+            end = np.zeros(B, dtype=np.int64)
         need = np.flatnonzero(end == 0)
         if need.size:
             d_off = self._pinned.to_device(np.ascontiguousarray(offs[need]))
@@ -260,8 +405,8 @@ class SequencerControl:
             found = proc.polyA_end_device(sig, d_off, d_len, int(need.size)).cpu().numpy().astype(np.int64)
             hit = np.flatnonzero(found > 0)
             end[need[hit]] = found[hit]
-            for j in hit.tolist():
-                polyA_cache[ids[need[j]]] = int(found[j])
+            polyA_cache.update(zip(ids[need[hit]].tolist(), found[hit].tolist()))
+        t, ph[2] = self._tick(t, 2)
 
         # -- gating (riser/control.py:36-60) as offsets / lengths ------------------------------
         max_len, min_len = proc.get_max_length(), proc.get_min_length()
@@ -272,19 +417,14 @@ class SequencerControl:
         ok = np.where(has, length >= min_len, lens > fixed + max_len)       # :53-56 / should_trim_fixed_length :39-50
         sel = np.flatnonzero(ok)
         if sel.size == 0:
-            return []
+            return None
         lens_a = np.minimum(length[sel], max_len).astype(np.int32)
 
         # -- normalise once, one batched forward per model, decision on the device -------------
         n_sel, n_models = int(sel.size), len(self.models)
         off_d = self._pinned.to_device(np.ascontiguousarray(offs[sel] + start[sel]))
         len_d = self._pinned.to_device(lens_a)
-        if self._res_probs is None or self._res_probs.dev.shape[1] < n_sel or self._res_probs.dev.shape[0] != n_models:
-            cap = max(n_sel, 512)
-            self._res_probs = _Pair(torch.empty((n_models, cap, 2), dtype=torch.float32, device=dev),
-                                    torch.empty((n_models, cap, 2), dtype=torch.float32).pin_memory())
-            self._res_dec = _Pair(torch.empty(cap, dtype=torch.uint8, device=dev),
-                                  torch.empty(cap, dtype=torch.uint8).pin_memory())
+        self._result_buffers(n_sel)
         probs_d = self._res_probs.dev.view(-1)[: n_models * n_sel * 2].view(n_models, n_sel, 2)
         dec_d = self._res_dec.dev[:n_sel]
         classify_raw_ensemble(self.models, sig, off_d, len_d, lens_a, out=probs_d, decision=dec_d, max_len=max_len,
@@ -293,12 +433,17 @@ class SequencerControl:
         dec_p = self._res_dec.host[:n_sel]
         probs_p.copy_(probs_d, non_blocking=True)
         dec_p.copy_(dec_d, non_blocking=True)
+        t, ph[3] = self._tick(t, 3)
         torch.cuda.current_stream(dev).synchronize()
-        p_on = probs_p.numpy()[:, :, 1].T.astype(np.float64).tolist()          # [read][model]
-        dec_h = dec_p.numpy().tolist()
-        names = nv.DECISION_NAMES
-        return [(int(channels[i]), reads[i], n, p, names[d])
-                for i, n, p, d in zip(sel.tolist(), lens_a.tolist(), p_on, dec_h)]
+        p_on = np.ascontiguousarray(probs_p.numpy()[:, :, 1].T, dtype=np.float64)          # [read][model]
+        res = _Assessed(reads, sel, channels[sel], lens_a, p_on, dec_p.numpy().copy())
+        t, ph[4] = self._tick(t, 4)
+        return res
+
+    @staticmethod
+    def _tick(t_prev, _k):
+        now = time.perf_counter()
+        return now, now - t_prev
 
     # ------------------------------------------------------------------------------------
     def target(self, mode, duration_h, threshold, unblock_duration=0.1):
@@ -325,30 +470,56 @@ class SequencerControl:
 
     def _run_batch(self, sink, mode, threshold, unblock_duration, cache, tally):
         t0 = time.monotonic()
-        records = self.assess_batch(list(self.client.get_read_batch()), mode, threshold, cache)
-        decided = {"reject": [], "accept": [], "no_decision": []}          # "try_again" reads stay with the client
-        if records:
-            head = f"{t0:.0f},"
-            tail = "," + ";".join(m.target for m in self.models) + ","
-            tail2 = f",{threshold},{mode},"
+        self._ph[:] = 0.0
+        res = self.assess_batch(list(self.client.get_read_batch()), mode, threshold, cache)
+        n_acc = n_rej = 0
+        t = time.perf_counter()
+        if res is None:
+            self.client.reject_reads([], unblock_duration)
+            self.client.finish_processing_reads([])
+        else:
+            # the decided reads, in batch order per list: rejects are sent first, then every decided read is finished
+            # (riser/control.py:85-90,106-112); "try_again" reads stay with the client
             key = self._client_key
-            lines = []
-            for channel, read, n_samples, p_on, decision in records:
-                if decision in decided:
-                    decided[decision].append((channel, key(read)))
-                lines.append(f"{head}{read.id},{channel},{n_samples}{tail}{';'.join(map(str, p_on))}{tail2}{decision}")
-            sink.write("\n".join(lines) + "\n")
-        # riser/control.py:96-97 drops the cache at 1000 entries, two flow cells' worth of reads at 512 channels; the same
-        # proportion at any channel count (the cache never changes a result, only how often a read is re-scanned)
-        if len(cache) >= max(_CACHE_LIMIT, 2 * self._channels_seen):
-            cache = {}
-        self.client.reject_reads(decided["reject"], unblock_duration)
-        self.client.finish_processing_reads(decided["reject"] + decided["accept"] + decided["no_decision"])
-        if records:
+            reads, dec = res.reads, res.decision
+            chan, sel = res.channels.tolist(), res.sel.tolist()
+            lists = []
+            for code in (nv.RS_REJECT, nv.RS_ACCEPT, nv.RS_NO_DECISION):
+                lists.append([(chan[k], key(reads[sel[k]])) for k in np.flatnonzero(dec == code).tolist()])
+            rejected, accepted, undecided = lists
+            n_acc, n_rej = len(accepted), len(rejected)
+            self.client.reject_reads(rejected, unblock_duration)
+            self.client.finish_processing_reads(rejected + accepted + undecided)
             self.batch_latencies.append(time.monotonic() - t0)
-        tally.add(len(records), len(decided["accept"]), len(decided["reject"]))
+        t, self._ph[5] = self._tick(t, 5)
+        if res is not None:
+            sink.write(self._csv_rows(res, t0, mode, threshold))
+            t, self._ph[6] = self._tick(t, 6)
+            self.batch_loop_times.append(time.monotonic() - t0)
+            self.batch_phases.append(self._ph.copy())
+        # riser/control.py:96-97 drops the cache at 1000 entries, two flow cells' worth of reads at MinION's 512 channels;
+        # kept at exactly 1000 up to that channel count, the same proportion beyond it (the cache never changes a result,
+        # only how often a read is re-scanned)
+        limit = _CACHE_LIMIT if self._channels_seen <= _MINION_CHANNELS else 2 * self._channels_seen
+        if len(cache) >= limit:
+            cache = {}
+        tally.add(0 if res is None else len(res), n_acc, n_rej)
         tally.report_if_due(t0)
         return cache
+
+    def _csv_rows(self, res: _Assessed, t0: float, mode: str, threshold) -> str:
+        """the rows of riser/control.py:145-153 for one batch, as one string"""
+        head = f"{t0:.0f},"
+        mid = "," + ";".join(m.target for m in self.models) + ","
+        tail = f",{threshold},{mode},"
+        if _hp is not None:
+            return _hp.format_rows(head, res.reads, np.ascontiguousarray(res.sel, dtype=np.int64),
+                                   np.ascontiguousarray(res.channels, dtype=np.int64),
+                                   np.ascontiguousarray(res.n_samples, dtype=np.int32), mid, res.p_on, int(res.p_on.shape[1]),
+                                   tail, np.ascontiguousarray(res.decision, dtype=np.uint8), tuple(nv.DECISION_NAMES))
+        lines = [f"{head}{read.id},{channel},{n}{mid}{';'.join(map(str, p))}{tail}{decision}"
+                 for channel, read, n, p, decision in res.records()]
+        return "\n".join(lines) + "\n"
 
     def start(self):
         self.client.start_streaming_reads()

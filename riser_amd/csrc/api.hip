@@ -41,6 +41,7 @@ Hooks Hooks::from_env() {
     h.no_stream_f32 = flag("RS_NO_STREAM_F32");
     h.no_stream_h16 = flag("RS_NO_STREAM_H16");
     h.no_stream012 = flag("RS_NO_STREAM012");
+    h.ensemble_serial = flag("RS_ENSEMBLE_SERIAL");
     h.conv_stamps = flag("RS_CONV_STAMPS");
     text("RS_FORCE_SHAPE_F32", h.force_f32, sizeof(h.force_f32));
     text("RS_FORCE_SHAPE_WINO", h.force_wino, sizeof(h.force_wino));
@@ -94,6 +95,10 @@ struct rs_model {
     int prof_calls = 0;
     bool tuning = false;                  // rs_autotune: time every feasible tile shape of each tiled layer in place
     int tuned_changed = 0;                // layers whose measured best differs from the planner's choice
+    // rs_classify_ensemble: the forwards of models 1.. run on library-owned side streams next to model 0's on the
+    // caller's stream (created on first use)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
@@ -177,6 +182,17 @@ ConvPlan plan_static_wino4(int cp_in, int c_out, int layer, int num_cu) {
     }
     p.n_alloc = round_up(c_out, 16) + conv_wino4_max_bn();
     return p;
+}
+
+// measurement aid (libraries built with -DRS_X3_MASK only): RS_X3_TERMS = "layer:mask;layer:mask" picks the products a
+// split-precision layer of the ring kernel executes (1 = hi*hi, 2 = x lo * w hi, 4 = x hi * w lo; 7 = all, the shipped mode)
+int x3_terms_of(int layer) {
+    if (const char* e = getenv("RS_X3_TERMS")) {
+        int l, t;
+        for (const char* q = e; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
+            if (sscanf(q, "%d:%d", &l, &t) == 2 && l == layer) return (t & 7) | 1;
+    }
+    return 7;
 }
 
 // which layers of an RS_F32W model run F(4,3) instead of F(2,3): by default the wide ones (>= 96 input
@@ -400,6 +416,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         L.c_out = channels[i];
         L.cp_in = m->cp[i - 1];
         L.cp_out = m->cp[i];
+        L.x3_terms = x3_terms_of(i);
         if (dtype == RS_F32) {
             L.plan = plan_static_f32(L.cp_in, L.c_out);
             const ConvPlan& p = L.plan;
@@ -543,6 +560,9 @@ int rs_model_destroy(rs_model* m) {
     if (m->d_fcw) (void)hipFree(m->d_fcw);
     if (m->d_fcb) (void)hipFree(m->d_fcb);
     if (m->d_zero) (void)hipFree(m->d_zero);
+    if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
     return RS_OK;
@@ -844,6 +864,33 @@ int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
     return rc;
 }
 
+// the layout all models of an ensemble share: block table and normalised signals once, activation buffers sized for the
+// widest model
+static WsLayout ensemble_layout(rs_model* const* models, int n_models, int B, int Lmax) {
+    WsLayout w = ws_layout(models[0], B, Lmax);
+    for (int k = 1; k < n_models; ++k) {
+        const WsLayout wk = ws_layout(models[k], B, Lmax);
+        if (wk.bufb_off - wk.bufa_off > w.bufb_off - w.bufa_off) w = wk;
+    }
+    return w;
+}
+
+static bool ensemble_compatible(rs_model* const* models, int n_models) {
+    if (!models || n_models < 1 || !models[0]) return false;
+    const rs_model* m0 = models[0];
+    for (int k = 0; k < n_models; ++k)
+        if (!models[k] || models[k]->n_layers != m0->n_layers || models[k]->device != m0->device ||
+            esize(models[k]) != esize(m0) || models[k]->pad_shift != m0->pad_shift)
+            return false;
+    return true;
+}
+
+size_t rs_ensemble_workspace_bytes(rs_model* const* models, int n_models, int B, int Lmax) {
+    if (!ensemble_compatible(models, n_models) || B < 1 || Lmax < 1) return 0;
+    const WsLayout w = ensemble_layout(models, n_models, B, Lmax);
+    return w.bufa_off + (size_t)n_models * 2 * (w.bufb_off - w.bufa_off);
+}
+
 int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d_sig, const int64_t* d_off,
                          const int32_t* d_len, const int32_t* h_len, int B, int Lmin, int Lmax, void* d_ws, size_t ws_bytes,
                          float* d_probs, uint8_t* d_decision, int max_len, float threshold, int mode, void* stream) {
@@ -851,13 +898,11 @@ int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d
         set_error("rs_classify_ensemble: null argument or empty batch");
         return RS_ERR_ARG;
     }
+    if (!ensemble_compatible(models, n_models)) {
+        set_error("rs_classify_ensemble: a model is null or differs in depth / device / element size");
+        return RS_ERR_ARG;
+    }
     rs_model* m0 = models[0];
-    for (int k = 0; k < n_models; ++k)
-        if (!models[k] || models[k]->n_layers != m0->n_layers || models[k]->device != m0->device ||
-            esize(models[k]) != esize(m0) || models[k]->pad_shift != m0->pad_shift) {
-            set_error("rs_classify_ensemble: model %d is null or differs in depth / device / element size", k);
-            return RS_ERR_ARG;
-        }
     if (d_decision && mode != RS_ENRICH && mode != RS_DEPLETE) {
         set_error("rs_classify_ensemble: bad mode");
         return RS_ERR_ARG;
@@ -868,11 +913,7 @@ int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d
     }
     // the models share one plan and one copy of the normalised signals: same block size, same element size (checked
     // above), so one layout serves them all except for the width of the activation buffers
-    WsLayout w = ws_layout(m0, B, Lmax);
-    for (int k = 1; k < n_models; ++k) {
-        const WsLayout wk = ws_layout(models[k], B, Lmax);
-        if (wk.bufb_off - wk.bufa_off > w.bufb_off - w.bufa_off) w = wk;
-    }
+    const WsLayout w = ensemble_layout(models, n_models, B, Lmax);
     int rc = check_call("rs_classify_ensemble", m0, B, Lmax, w, ws_bytes);
     if (rc != RS_OK) return rc;
     Batch bt;
@@ -881,15 +922,53 @@ int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d
     DeviceGuard guard(m0->device);
     RS_HIP(guard.err);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // With a workspace of rs_ensemble_workspace_bytes() every model has its own pair of activation buffers and the
+    // forwards run CONCURRENTLY: model 0 on the caller's stream, model k on its own side stream, forked behind the
+    // normalise launch and joined in front of the decision.  The forwards are independent (they read the shared block table
+    // and normalised rows, write their own buffers and their own slice of d_probs), so the results are those of the serial
+    // order, bit for bit; what overlaps is one model's tile-round tails, prologues and launch gaps with another's tiles.
+    // A smaller workspace (rs_workspace_bytes of the widest model), a profiled or a tuning model, or RS_ENSEMBLE_SERIAL
+    // run the forwards back to back on the caller's stream.
+    const size_t buf_bytes = w.bufb_off - w.bufa_off;
+    bool concurrent = n_models > 1 && ws_bytes >= w.bufa_off + (size_t)n_models * 2 * buf_bytes && !m0->hooks.ensemble_serial;
+    for (int k = 0; k < n_models; ++k)
+        if (models[k]->prof_on || models[k]->tuning || models[k]->dbg_dst) concurrent = false;
+    for (int k = 1; k < n_models && concurrent; ++k)
+        for (int j = 0; j < k; ++j)
+            if (models[j] == models[k]) concurrent = false;                  // one handle twice: its side stream is one
+    if (concurrent)
+        for (int k = 1; k < n_models; ++k) {
+            rs_model* mk = models[k];
+            if (!mk->side_stream) RS_HIP(hipStreamCreateWithFlags(&mk->side_stream, hipStreamNonBlocking));
+            if (!mk->ev_fork) RS_HIP(hipEventCreateWithFlags(&mk->ev_fork, hipEventDisableTiming));
+            if (!mk->ev_join) RS_HIP(hipEventCreateWithFlags(&mk->ev_join, hipEventDisableTiming));
+        }
     prof_mark(m0, -1, st);
     rc = normalise_packed(m0, d_sig, d_off, d_len, B, Lmax, w, bt, d_ws, st);
     if (rc != RS_OK) return rc;
     prof_mark(m0, 0, st);
     const float* xn = reinterpret_cast<const float*>(static_cast<char*>(d_ws) + w.xnorm_off);
-    for (int k = 0; k < n_models; ++k) {
-        // every model keeps the block table and the normalised rows at the head of the workspace and ping-pongs behind them
-        rc = forward_impl(models[k], xn, w.U, d_len, B, bt, w, d_ws, d_probs + (size_t)k * B * 2, nullptr, stream, true);
+    if (concurrent) {
+        for (int k = 1; k < n_models; ++k) {
+            rs_model* mk = models[k];
+            RS_HIP(hipEventRecord(mk->ev_fork, st));
+            RS_HIP(hipStreamWaitEvent(mk->side_stream, mk->ev_fork, 0));
+            WsLayout wk = w;
+            wk.bufa_off += (size_t)k * 2 * buf_bytes;
+            wk.bufb_off += (size_t)k * 2 * buf_bytes;
+            rc = forward_impl(mk, xn, w.U, d_len, B, bt, wk, d_ws, d_probs + (size_t)k * B * 2, nullptr, mk->side_stream, true);
+            if (rc != RS_OK) return rc;
+            RS_HIP(hipEventRecord(mk->ev_join, mk->side_stream));
+        }
+        rc = forward_impl(m0, xn, w.U, d_len, B, bt, w, d_ws, d_probs, nullptr, stream, true);
         if (rc != RS_OK) return rc;
+        for (int k = 1; k < n_models; ++k) RS_HIP(hipStreamWaitEvent(st, models[k]->ev_join, 0));
+    } else {
+        for (int k = 0; k < n_models; ++k) {
+            // every model keeps the block table and the normalised rows at the head of the workspace and ping-pongs behind them
+            rc = forward_impl(models[k], xn, w.U, d_len, B, bt, w, d_ws, d_probs + (size_t)k * B * 2, nullptr, stream, true);
+            if (rc != RS_OK) return rc;
+        }
     }
     if (d_decision) rc = launch_decide(d_probs, n_models, B, d_len, max_len, threshold, mode, d_decision, st);
     return rc;

@@ -59,6 +59,7 @@ struct Hooks {
     bool no_stream_f32 = false;      // RS_NO_STREAM_F32 / _H16: tiled kernels instead of the streaming ones
     bool no_stream_h16 = false;
     bool no_stream012 = false;       // RS_NO_STREAM012: layers 0+1 and 2 of the 16-bit modes as two launches instead of one
+    bool ensemble_serial = false;    // RS_ENSEMBLE_SERIAL: rs_classify_ensemble runs its forwards back to back on the caller's stream
     bool conv_stamps = false;        // RS_CONV_STAMPS: in-kernel clock stamps of the direct fp32 kernel
     char force_f32[256] = "";        // RS_FORCE_SHAPE_F32 / _WINO / _WINO4 / _H16: "layer:wm,wn,mt,nt;..."
     char force_wino[256] = "";
@@ -126,6 +127,7 @@ struct ConvLayerDev {
     void* d_w;                // packed weights [n_alloc][nch][3][kc] (f32 or bf16)
     void* d_w2 = nullptr;     // 16-bit modes: ring packing [panel][tap][n_alloc][64] (conv_ring_h16.hip)
     int ring_panels = 0;      // panels of the ring packing: 64 channels each (plain) or 32 channels as hi | lo (x3)
+    int x3_terms = 7;         // split precision, -DRS_X3_MASK measurement builds only (RS_X3_TERMS): 1 hi*hi | 2 x lo*w hi | 4 x hi*w lo
     float* d_bias;            // [n_alloc] fp32, zero padded
     // rs_autotune: the measured-best entry of the kernel's tile-shape table per launch geometry (GEMM rows of the
     // launch -> shape index), consulted before the cost model; force_shape >= 0 overrides both while tuning

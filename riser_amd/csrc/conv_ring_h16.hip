@@ -81,6 +81,7 @@ struct RingArgs {
     int n_alloc;
     int n_reads;
     int shift_out;
+    int terms;                   // -DRS_X3_MASK builds: which products of split precision run (1 hi*hi | 2 x lo*w hi | 4 x hi*w lo)
     WalkArgs walk;
     unsigned long long* stamps;  // diagnostic builds only
 };
@@ -321,6 +322,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
 #if defined(RS_X2_DROP) && RS_X2_DROP == 2     // measurement build: split precision without the x hi * w lo term
         if constexpr (X3) return;
 #endif
+#ifdef RS_X3_MASK                              // measurement build: per-layer run-time choice of the terms (tools/x3_terms_sweep.py)
+        if (X3 && !(a.terms & 4)) return;
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -352,8 +356,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
             constexpr int pass = n / (MT * NT), ij = n % (MT * NT), i = ij / NT, j = ij % NT;
             if constexpr (pass == 0)
                 acc[i][j] = mfma16<F16>(a0[i], b0[j], acc[i][j]);       // hi * hi  (plain: h0 * h0)
-            else
+            else {
+#ifdef RS_X3_MASK
+                if (a.terms & 2)
+#endif
                 acc[i][j] = mfma16<F16>(a1[i], b0[j], acc[i][j]);       // lo * hi
+            }
             if constexpr (NDMA > 0 && n % GAP == GAP - 1 && n / GAP < NDMA) dma(std::integral_constant<int, n / GAP>{});
         });
 #pragma unroll
@@ -684,6 +692,7 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     a.n_alloc = L.plan.n_alloc;
     a.n_reads = B;
     a.shift_out = layer_index + 1;
+    a.terms = L.x3_terms;
     const int n_mtiles = (a.rows_in + BM - 1) / BM, n_ntiles = (n16 * 16 + BN - 1) / BN;
     a.cols_tiled = n_ntiles * BN;
     if (a.cols_out - a.cols_tiled > 16) {                          // cannot happen: a panel is 32 slots, a column group 16

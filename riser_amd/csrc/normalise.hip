@@ -177,10 +177,17 @@ __global__ __launch_bounds__(1024) void plan_kernel(const int32_t* __restrict__ 
         if (b < B) {
             pl.rbase[b] = base;
             if (b == B - 1) pl.rbase[B] = base + nb;
-            if (base + nb <= pl.nb_total)
-                for (int j = 0; j < nb; ++j) {
-                    pl.blen[base + j] = max(0, min(n - (j << pl.shift), 1 << pl.shift));
-                    pl.bread[base + j] = b;
+            // a read whose blocks do not fit the table (device length above the host's copy) is DROPPED: its slots inside the
+            // table become empty blocks of itself, so that every entry the host's block count covers names a valid read
+            const bool fits = base + nb <= pl.nb_total;
+            for (int j = 0; j < nb && base + j < pl.nb_total; ++j) {
+                pl.blen[base + j] = fits ? max(0, min(n - (j << pl.shift), 1 << pl.shift)) : 0;
+                pl.bread[base + j] = b;
+            }
+            if (b == B - 1)                                       // device lengths BELOW the host's: the unused tail
+                for (int k = base + nb; k < pl.nb_total; ++k) {
+                    pl.blen[k] = 0;
+                    pl.bread[k] = 0;
                 }
         }
         __syncthreads();
@@ -279,8 +286,22 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
             pl.rbase[b] = base;
             if (b == (int)gridDim.x - 1) pl.rbase[b + 1] = base + nblk;
         }
-        // device lengths that disagree with the host's copy (which sized the workspace): never write outside it
-        if (base + nblk > pl.nb_total) return;
+        // device lengths BELOW the host's copy leave a tail of the table unused: empty blocks of read 0, so that every entry
+        // the host's block count covers names a valid read (the conv kernels index len[] with it)
+        if (b == (int)gridDim.x - 1)
+            for (int k = base + nblk + tid; k < pl.nb_total; k += kThreads) {
+                pl.blen[k] = 0;
+                pl.bread[k] = 0;
+            }
+        // device lengths ABOVE the host's copy (which sized the workspace): never write outside it - the read is dropped,
+        // its slots inside the table become empty blocks of itself
+        if (base + nblk > pl.nb_total) {
+            for (int k = base + tid; k < pl.nb_total; k += kThreads) {
+                pl.blen[k] = 0;
+                pl.bread[k] = b;
+            }
+            return;
+        }
         if (tid < nblk) {
             pl.blen[base + tid] = max(0, min(n - (tid << pl.shift), 1 << pl.shift));
             pl.bread[base + tid] = b;

@@ -42,7 +42,8 @@ constexpr int kC0PosPerBlock = 1024;
 template <int DT>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, int64_t ldx,
                                                     const int32_t* __restrict__ len, const int32_t* __restrict__ rbase,
-                                                    const int32_t* __restrict__ bread, int P1, int cq, int cp,
+                                                    const int32_t* __restrict__ bread, const int32_t* __restrict__ blen,
+                                                    int P1, int cq, int cp,
                                                     const float4* __restrict__ w4, void* __restrict__ yv) {
     constexpr int CH = DT == 0 ? 4 : 8;
     const int ppi = 256 / cq;                                     // positions per iteration
@@ -52,7 +53,9 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
     const int kb = blockIdx.y;
     const int b = bread[kb];
     const int n = len[b];
-    const int half = n >> 1;
+    // pooled positions of THIS block that exist: blen >> 1 (= clamp(n / 2 - p_off, 0, P1) for a table that matches the
+    // lengths; 0 for the blocks of a read the plan dropped, whose signal rows were never written)
+    const int half_blk = blen[kb] >> 1;
     float4 w[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) w[j] = w4[q * CH + j];           // (w0, w1, w2, bias)
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
         float o[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) o[j] = 0.f;
-        if (p < half) {
+        if (pl < half_blk) {
             const float* xr = xr0 + 2 * p;
             const float xm = p > 0 ? xr[-1] : 0.0f;
             const float x0 = xr[0], x1 = xr[1];
@@ -242,7 +245,7 @@ int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, const Bloc
     dim3 grid((P1 + kC0PosPerBlock - 1) / kC0PosPerBlock, NB);
     auto fn = dtype == RS_F16 ? conv0_kernel<2> : dtype == RS_BF16 ? conv0_kernel<1>
             : dtype == RS_BF16X3 ? conv0_kernel<RS_BF16X3> : dtype == RS_F16X3 ? conv0_kernel<RS_F16X3> : conv0_kernel<0>;
-    hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, d_x, ldx, d_len, plan.rbase, plan.bread, P1, cq, cp_out,
+    hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, d_x, ldx, d_len, plan.rbase, plan.bread, plan.blen, P1, cq, cp_out,
                        reinterpret_cast<const float4*>(d_w4), d_y);
     RS_HIP(hipGetLastError());
     return RS_OK;

@@ -28,10 +28,16 @@ class FakeRead:
 
 class FakeClient:
     signal_dtype = np.int16
+    # get_raw_signal below IS np.frombuffer(read.raw_data, int16), as riser/client.py:46-47 is: declaring it lets the
+    # control loop walk the reads of a batch with the C loops of riser_amd/_hostpack instead of one Python call per read
+    raw_data_dtype = np.int16
 
-    def __init__(self, batches):
-        """batches: list of lists of (channel, FakeRead)."""
+    def __init__(self, batches, first_channel: int | None = None, last_channel: int | None = None):
+        """batches: list of lists of (channel, FakeRead).  first_channel / last_channel: the channel range this client
+        streams, as `ReadUntilClient.run(first_channel=, last_channel=)` takes it (riser/client.py:33-38): reads of other
+        channels are not delivered (one rank of a sharded run owns one range, riser_amd/launch.py)."""
         self._batches = list(batches)
+        self.first_channel, self.last_channel = first_channel, last_channel
         self._next = 0
         self.started = False
         self.was_reset = False
@@ -50,6 +56,10 @@ class FakeClient:
     def get_read_batch(self):
         b = self._batches[self._next]
         self._next += 1
+        if self.first_channel is not None or self.last_channel is not None:
+            lo = self.first_channel if self.first_channel is not None else -(1 << 62)
+            hi = self.last_channel if self.last_channel is not None else 1 << 62
+            b = [e for e in b if lo <= e[0] <= hi]
         return b
 
     def get_raw_signal(self, read):
@@ -67,3 +77,9 @@ class FakeClient:
 
     def send_warning(self, message):
         self.warnings.append(message)
+
+
+class PlainFakeClient(FakeClient):
+    """The same client WITHOUT the raw_data_dtype declaration: the control loop then uses nothing but the eight methods
+    (one get_raw_signal call per read), as it must for a client it knows nothing about."""
+    raw_data_dtype = None

@@ -37,14 +37,14 @@ class Workspace:
 
     def get(self, nbytes: int) -> torch.Tensor:
         key = _stream_ptr(self.device)
-        buf = self._bufs.get(key)
+        buf = self._bufs.pop(key, None)                      # re-inserted below: the dict's order is the order of last use
         if buf is None or buf.numel() < nbytes:
-            self._bufs[key] = None
-            if len(self._bufs) > self.MAX_STREAMS:           # drop the workspace of the stream used longest ago
-                del self._bufs[next(k for k in self._bufs if k != key)]
+            buf = None                                       # release the smaller one before the new one is allocated
+            if len(self._bufs) >= self.MAX_STREAMS:          # drop the workspace of the stream used longest ago
+                del self._bufs[next(iter(self._bufs))]
             with torch.cuda.stream(torch.cuda.current_stream(self.device)):
                 buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            self._bufs[key] = buf
+        self._bufs[key] = buf
         return buf
 
 
@@ -352,13 +352,20 @@ def _autotune(self, sig_dev: torch.Tensor, off_dev: torch.Tensor, len_dev: torch
 Model.autotune = _autotune
 
 
+def _ensemble_bytes(models, B: int, lmax: int) -> int:
+    """workspace of one rs_classify_ensemble call: a pair of activation buffers per model, so that the forwards of the
+    models run concurrently (include/riser_amd.h)"""
+    hs = (C.c_void_p * len(models))(*[m._h for m in models])
+    return nv.lib().rs_ensemble_workspace_bytes(hs, len(models), int(B), int(lmax))
+
+
 def reserve_ensemble(models, B: int, lmax: int):
     """The workspace classify_raw_ensemble will ask for (it lives with models[0]), allocated ahead of the run."""
     m0 = models[0]
     if any(m._h is None for m in models):
         return
     B = max(1, min(int(B), min(m.max_batch(lmax) for m in models)))
-    m0._ws.get(max(nv.lib().rs_workspace_bytes(m._h, B, int(lmax)) for m in models))
+    m0._ws.get(_ensemble_bytes(models, B, lmax))
 
 
 def classify_raw_ensemble(models, sig_dev: torch.Tensor, off_dev: torch.Tensor, len_dev: torch.Tensor,
@@ -393,8 +400,7 @@ def classify_raw_ensemble(models, sig_dev: torch.Tensor, off_dev: torch.Tensor, 
             probs[:, s0:s1] = part
         return probs
     L = nv.lib()
-    need = max(L.rs_workspace_bytes(m._h, B, lmax) for m in models)
-    ws = m0._ws.get(need)
+    ws = m0._ws.get(_ensemble_bytes(models, B, lmax))
     probs = out if out is not None else torch.empty((len(models), B, 2), dtype=torch.float32, device=m0.device)
     hs = (C.c_void_p * len(models))(*[m._h for m in models])
     nv.check(L.rs_classify_ensemble(hs, len(models), sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(),

@@ -60,12 +60,45 @@ def scripted_batches(n_batches: int, channels: int = 512, seed: int = 4242, min_
     return batches
 
 
+def chunked_batches(n_batches: int, channels: int = 512, seed: int = 4242, chunk: int = 8000, min_len: int = 9000,
+                    max_len: int = 30000, pool_reads: int | None = None):
+    """-> list of n_batches lists of (channel, FakeRead): the traffic of a client that POPS its cache with every batch.
+
+    `ReadUntilClient.get_read_chunks(last=True)` (riser/client.py:44) removes what it returns from the AccumulatingCache,
+    which only concatenates the chunks that arrive between two pops: a read that stays in its pore comes back under the SAME
+    id carrying only the samples since the last batch - here `chunk` samples (2 s at RNA004's 4 kHz: the reference's own
+    loop takes seconds per batch, so seconds of signal accumulate between its pops).  Consecutive deliveries of a read are
+    DISJOINT: nothing of an earlier delivery is re-sent, and the reference applies a cached poly(A) end of the first
+    delivery as an offset into the later ones (riser/preprocess.py:93-100) - a drop-in does the same."""
+    rng = np.random.default_rng(11)
+    pool_reads = pool_reads or min(2 * channels, 1024)
+    pool = []
+    for rid in range(pool_reads):
+        n = int(rng.integers(min_len, max_len))
+        sig = synth.make_raw_read(seed, rid, n, polya=(rid % 5 != 0))
+        pool.append((memoryview(np.ascontiguousarray(sig, dtype=np.int16).tobytes()), n))
+    visits = -(-max_len // chunk)
+    batches = []
+    for b in range(n_batches):
+        reads = []
+        for ch in range(channels):
+            age = (b + ch) % visits
+            turn = (b + ch) // visits
+            raw, n = pool[(turn * channels + ch) % pool_reads]
+            lo, hi = age * chunk, min(n, (age + 1) * chunk)
+            if hi - lo < 500:                                     # the pore is between reads
+                continue
+            reads.append((ch + 1, FakeRead(f"read-{turn}-{ch}", raw[2 * lo: 2 * hi])))
+        batches.append(reads)
+    return batches
+
+
 def run_replay(models, processor, batches, mode: str = "enrich", threshold: float = 0.9, skip: int = 3,
-               signal_cache: bool = True) -> dict:
+               signal_cache: bool = True, client_cls=FakeClient) -> dict:
     """Drive SequencerControl.target over `batches`; returns counts and per-batch latency percentiles
     (the first `skip` batches are warm-up: first launches, the signal store's first fill)."""
-    from .control import SequencerControl
-    client = FakeClient(batches)
+    from .control import PHASES, SequencerControl
+    client = client_cls(batches)
     with tempfile.TemporaryDirectory() as d:
         ctl = SequencerControl(client, models, processor, logging.getLogger("riser_amd.replay"),
                                os.path.join(d, "out"), signal_cache=signal_cache)
@@ -86,16 +119,27 @@ def run_replay(models, processor, batches, mode: str = "enrich", threshold: floa
         with open(os.path.join(d, "out.csv")) as f:
             rows = sum(1 for _ in f) - 1
     lat = np.asarray(list(ctl.batch_latencies)[skip:], dtype=np.float64) * 1e3
+    loop = np.asarray(list(ctl.batch_loop_times)[skip:], dtype=np.float64) * 1e3
     if lat.size == 0:
-        lat = np.zeros(1)
+        lat = loop = np.zeros(1)
+    phases = np.asarray(list(ctl.batch_phases)[skip:], dtype=np.float64).reshape(-1, len(PHASES)) * 1e3
+    worst = int(np.argmax(loop)) if phases.shape[0] == loop.shape[0] and loop.size else 0
     received = sum(len(b) for b in batches)
+    store = ctl._store
     return {"batches": len(batches), "reads_received": received, "reads_assessed": rows,
             "assessed_per_batch": round(rows / max(len(batches), 1), 1),
             "wall_s": round(wall, 3), "assessed_per_s": round(rows / wall, 1),
+            # decision latency: get_read_batch() -> reject / finish calls sent; loop: the whole iteration, CSV rows included
             "p50_ms": round(float(np.percentile(lat, 50)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
             "max_ms": round(float(lat.max()), 3), "latency_samples": int(lat.size),
+            "loop_p50_ms": round(float(np.percentile(loop, 50)), 3), "loop_max_ms": round(float(loop.max()), 3),
             "first_ms": [round(float(v) * 1e3, 2) for v in list(ctl.batch_latencies)[:8]],
-            "signal_cache": bool(signal_cache),
-            "pcie_samples_uploaded": int(ctl._store.samples_uploaded),
-            "pcie_samples_full_reupload": int(ctl._store.samples_presented),
+            "phase_ms_median": ({n: round(float(v), 3) for n, v in zip(PHASES, np.median(phases, axis=0))}
+                                if phases.size else {}),
+            "phase_ms_slowest_batch": ({n: round(float(v), 3) for n, v in zip(PHASES, phases[worst])} if phases.size else {}),
+            "gc_frozen": True, "host_loops": "native" if getattr(client, "raw_data_dtype", None) is not None else "python",
+            "signal_cache": bool(signal_cache), "signal_cache_auto_off": bool(store.auto_off),
+            "delta_reads": int(store.delta_reads), "overlap_mismatches": int(store.mismatches),
+            "pcie_samples_uploaded": int(store.samples_uploaded),
+            "pcie_samples_full_reupload": int(store.samples_presented),
             "rejected": sum(len(r) for r in client.rejected), "finished": sum(len(r) for r in client.finished)}

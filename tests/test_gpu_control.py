@@ -1,0 +1,266 @@
+"""GPU checks of the control loop's host side (round 4): both traffic models a ReadUntil client can present (whole reads
+re-sent, disjoint chunks under one id), the verified signal store, the C host loops against the eight-method duck type,
+the sharded launcher on one GPU, and the contained length mismatch on every entry."""
+import json
+import logging
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_path
+from riser_amd import synth
+from riser_amd.fake_client import FakeClient, FakeRead, PlainFakeClient
+
+from test_gpu_more import _oracle_loop
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOG = logging.getLogger("ctl4")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def _run(batches, models, proc, path, client_cls=FakeClient, signal_cache=True, mode="enrich"):
+    from riser_amd.control import SequencerControl
+    client = client_cls(batches)
+    ctl = SequencerControl(client, models, proc, LOG, path, signal_cache=signal_cache)
+    ctl.start(); ctl.target(mode, 0.5, 0.9); ctl.finish()
+    rows = [ln.split(",", 1)[1] for ln in open(path + ".csv").read().strip().split("\n")[1:]]
+    return rows, client.rejected, client.finished, ctl
+
+
+def test_same_id_disjoint_chunks(dev, tmp_path):
+    """a client that pops its cache delivers a read's NEXT chunk under the same id, not the read
+    again (riser/client.py:44).  The signal store must not treat it as an extension of what its row holds: same CSV rows
+    and client calls with the store on (C host loops and plain duck type), off, and as the oracle's per-read loop writes
+    them; the store notices and stops trying."""
+    from riser_amd import Kit, Model, SignalProcessor
+    from riser_amd.replay import chunked_batches
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    models = [Model(synth.make_state_dict(s), synth.Config(), None, f"t{s}", device=dev) for s in (1, 2)]
+    batches = chunked_batches(10, 192)
+    # equal-length consecutive chunks are the dangerous case (nothing "new" to upload if the row were trusted): make sure
+    # the script holds some
+    same_len = sum(1 for b0, b1 in zip(batches, batches[1:]) for (c0, r0) in b0 for (c1, r1) in b1
+                   if c0 == c1 and r0.id == r1.id and len(r0.raw_data) == len(r1.raw_data))
+    assert same_len > 50
+    runs = [_run(batches, models, proc, str(tmp_path / f"c{k}"), cls, cache)
+            for k, (cls, cache) in enumerate(((FakeClient, True), (PlainFakeClient, True), (FakeClient, False)))]
+    for r in runs[1:]:
+        assert r[:3] == runs[0][:3]
+    assert len(runs[0][0]) > 40
+    store = runs[0][3]._store
+    assert store.mismatches > 100 and store.delta_reads == 0 and store.auto_off and not store.resident
+    cpu_models = {s: torch_path.TorchCpuModel(synth.make_state_dict(s)) for s in (1, 2)}
+    want_rows, want_rej, want_fin = _oracle_loop(batches[:4], "RNA004", (1, 2), "enrich", 0.9, cpu_models)
+    got = [r.split(",") for r in runs[0][0][: len(want_rows)]]
+    assert len(got) == len(want_rows) > 15
+    for g, w in zip(got, want_rows):
+        assert (g[0], int(g[1]), int(g[2])) == w[:3]
+        assert np.allclose([float(v) for v in g[4].split(";")], w[4], atol=1e-3)
+    for m in models:
+        m.close()
+
+
+def test_store_verifies_the_overlap_not_the_id(dev, tmp_path):
+    """a read that comes back under its id, LONGER, but with other samples where the row's tail was (a client that
+    re-bases its buffer): caught by the overlap comparison and uploaded whole; a read that does extend its prefix takes
+    the delta path.  Either way the rows equal the store-less run."""
+    from riser_amd import Kit, Model, SignalProcessor
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", device=dev)
+    a = synth.make_raw_read(9, 1, 20000, True)
+    b = synth.make_raw_read(9, 2, 20000, True)
+    shifted = np.concatenate([a[:9000], b[9000:16000]])            # same id, longer, different samples behind 9000
+    shifted2 = np.concatenate([b[:12000], a[12000:17000]])         # differs everywhere the row's tail would be compared
+    batches = [[(1, FakeRead("x", a[:12000])), (2, FakeRead("y", a[:12000]))],
+               [(1, FakeRead("x", a[:15000])), (2, FakeRead("y", shifted2))],
+               [(1, FakeRead("x", shifted)), (2, FakeRead("y", shifted2))]]
+    on = _run(batches, [m], proc, str(tmp_path / "on"))
+    off = _run(batches, [m], proc, str(tmp_path / "off"), signal_cache=False)
+    assert on[:3] == off[:3] and len(on[0]) >= 4
+    st = on[3]._store
+    assert st.delta_reads == 2 and st.mismatches == 2            # x batch 1, y batch 2 extend; y batch 1, x batch 2 do not
+    m.close()
+
+
+def test_native_host_loops_equal_the_duck_type(dev, tmp_path):
+    """whole-read traffic (scripted_batches): the C loops over read.raw_data (a client that declares raw_data_dtype) and
+    the eight-method duck type give the same CSV TEXT (batch_start aside), the same client calls, the same PCIe bytes"""
+    from riser_amd import Kit, Model, SignalProcessor
+    from riser_amd.replay import scripted_batches
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    models = [Model(synth.make_state_dict(s), synth.Config(), None, t, device=dev) for s, t in ((1, "mRNA"), (3, "globin"))]
+    batches = scripted_batches(6, 80)
+    nat = _run(batches, models, proc, str(tmp_path / "n"))
+    py = _run(batches, models, proc, str(tmp_path / "p"), PlainFakeClient)
+    assert nat[:3] == py[:3] and len(nat[0]) > 150
+    assert nat[3]._store.samples_uploaded == py[3]._store.samples_uploaded < 0.5 * nat[3]._store.samples_presented
+    assert nat[3]._store.mismatches == 0 and nat[3]._store.delta_reads > 200
+    # every phase of every assessed batch was timed, and the decision latency excludes the CSV rows
+    ph = np.asarray(nat[3].batch_phases)
+    assert ph.shape == (len(nat[3].batch_loop_times), 7) and (ph >= 0).all()
+    assert all(a <= b for a, b in zip(nat[3].batch_latencies, nat[3].batch_loop_times))
+    for m in models:
+        m.close()
+
+
+def test_polya_kernel_is_prefix_stable(dev):
+    """the GPU detector (rs_polya_end) on prefixes of a read: an end found on a prefix is the end of the whole read
+    (what makes the per-id cache's lifetime irrelevant to the CSV, riser/control.py:96-97)"""
+    from riser_amd import Kit, SignalProcessor
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    reads, owner = [], []
+    for rid in range(24):
+        sig = synth.make_raw_read(31, rid, 26000, polya=(rid % 4 != 0))
+        for n in (3000, 5200, 7777, 9000, 12500, 18001, 24000, 26000):
+            reads.append(sig[:n])
+            owner.append(rid)
+    ends = proc.get_polyA_end_batch(reads)
+    full = {rid: int(e) for rid, e, r in zip(owner, ends, reads) if len(r) == 26000}
+    found = 0
+    for rid, e, r in zip(owner, ends, reads):
+        if e > 0:
+            assert int(e) == full[rid], (rid, len(r))
+            found += 1
+    assert found > 60
+
+
+def _launch(args):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["PYTHONPATH"] = ROOT
+    r = subprocess.run([sys.executable, "-m", "riser_amd.launch", *args], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("run_index", [5, 11])
+def test_sharded_launch_two_ranks_one_gpu(tmp_path, golden_dir, run_index):
+    """python -m riser_amd.launch --gpus 2 --share-gpus: two processes, each with its own client on its own channel range
+    and its own models on the (shared) GPU.  The union of the ranks' CSV rows and reject / finish lists equals the
+    single-rank run of the golden script - and the reference's own rows for that run (tests/golden/control.json)."""
+    with open(os.path.join(golden_dir, "control.json")) as f:
+        g = json.load(f)
+    run = g["runs"][run_index]
+    common = ["--channels", "22", "--replay-script", os.path.join(golden_dir, "control.json"), "--kit", g["kit"],
+              "--mode", run["mode"], "--threshold", str(run["threshold"]), "--seeds", ",".join(map(str, run["seeds"])),
+              "--duration-h", "1.0", "--share-gpus"]
+    _launch(["--gpus", "1", "--out", str(tmp_path / "one"), *common])
+    two = _launch(["--gpus", "2", "--out", str(tmp_path / "two"), *common])
+    assert two["ranks"] == 2 and two["channel_ranges"] == [[1, 11], [12, 22]]
+
+    def rows(path):
+        return [ln.split(",", 1)[1] for ln in open(path).read().strip().split("\n")[1:]]
+    single = rows(str(tmp_path / "one.rank0.csv"))
+    parts = [rows(str(tmp_path / f"two.rank{r}.csv")) for r in range(2)]
+    assert all(parts) and sorted(parts[0] + parts[1]) == sorted(single)
+    assert all(int(ln.split(",")[1]) <= 11 for ln in parts[0]) and all(int(ln.split(",")[1]) >= 12 for ln in parts[1])
+    # the reference's rows for this run: ids, channels, lengths, decisions; probabilities within the tolerance
+    assert len(single) == len(run["rows"])
+    for ln, want in zip(single, run["rows"]):
+        p = ln.split(",")
+        assert (p[0], int(p[1]), int(p[2]), p[3], p[7]) == (want["read_id"], want["channel"], want["sig_length"],
+                                                            want["models"], want["decision"])
+        assert np.allclose([float(v) for v in p[4].split(";")], want["prob_targets"], atol=1e-3)
+    # reject / finish lists per batch: the ranks' lists together are the single run's (and the reference's)
+    s1 = json.load(open(str(tmp_path / "one.summary.json")))["per_rank"][0]
+    s2 = json.load(open(str(tmp_path / "two.summary.json")))["per_rank"]
+    for key, ref in (("rejected_lists", run["rejected"]), ("finished_lists", run["finished"])):
+        assert s1[key] == ref
+        for b in range(len(ref)):
+            both = s2[0][key][b] + s2[1][key][b]
+            assert sorted(map(tuple, both)) == sorted(map(tuple, ref[b]))
+    assert two["reads_assessed"] == len(single) and two["rejected"] == sum(len(x) for x in run["rejected"])
+
+
+@pytest.mark.parametrize("dtype", ["f32w", "f32", "bf16x3"])
+def test_length_mismatch_is_contained_on_every_path(dev, dtype):
+    """host lengths that disagree with the device's - above AND below - on the fused path of every dtype
+    (the fp32 direct mode runs the stand-alone layer-0 kernel, which indexes len[] through the block table) and on
+    rs_forward: the reads whose lengths agree keep their bits, a read the plan had to drop is NaN, nothing faults"""
+    from riser_amd import Kit, Model, SignalProcessor
+    from riser_amd.preprocess import pack_reads
+    lens = np.array([5000, 9000, 4500, 16000, 6000], dtype=np.int32)
+    sigs = [synth.make_signals(20260103, 1, int(n), first_read=3500 + i)[0] for i, n in enumerate(lens)]
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    m = Model(synth.make_state_dict(1), synth.Config(), None, "m", dtype=dtype, device=dev)
+    good = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+    # the host understates read 3 (4096 instead of 16000; Lmax drops to 9000, so the device sees 3 blocks where the host
+    # counted 1): the reads in FRONT of it keep their bits, read 3 itself is computed on a wrong length (its result is
+    # meaningless), and the table runs out for read 4, which is dropped -> NaN
+    lied = lh.copy()
+    lied[3] = 4096
+    out = m.classify_raw(sig, off, ln, lied).cpu().numpy()
+    assert np.array_equal(out[:3], good[:3]) and np.isnan(out[4]).all()
+    # the host overstates read 1 (device 3 blocks, host 4): a tail of the table stays unused; every read keeps its bits
+    lied = lh.copy()
+    lied[1] = 16000
+    out = m.classify_raw(sig, off, ln, lied).cpu().numpy()
+    assert np.array_equal(out, good)
+    # rs_forward (signals that arrive normalised) with the same two lies
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    x = proc.normalise_device(sig, off, ln, len(lens), 16000)
+    gf = m.forward_batch(x, lh, lens_dev=ln).cpu().numpy()
+    assert np.abs(gf - good).max() < 1e-5
+    lied = lh.copy()
+    lied[3] = 4096
+    of = m.forward_batch(x, lied, lens_dev=ln).cpu().numpy()
+    assert np.array_equal(of[:3], gf[:3]) and np.isnan(of[4]).all()
+    lied = lh.copy()
+    lied[1] = 16000
+    assert np.array_equal(m.forward_batch(x, lied, lens_dev=ln).cpu().numpy(), gf)
+    assert np.array_equal(m.classify_raw(sig, off, ln, lh).cpu().numpy(), good)
+    m.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32w", "bf16x3"])
+def test_ensemble_concurrent_equals_serial(dev, dtype):
+    """rs_classify_ensemble with rs_ensemble_workspace_bytes() runs its forwards concurrently (model 0 on the caller's
+    stream, the others on side streams); with the single-model workspace, or RS_ENSEMBLE_SERIAL, back to back.  Same bits
+    and same decisions, at a live-sized batch and repeatedly (a race between the forks would show as a changed bit)."""
+    import ctypes as C
+    from conftest import hooked_model
+    from riser_amd import _native as nv
+    from riser_amd.model import Model, classify_raw_ensemble
+    from riser_amd.preprocess import pack_reads
+    specs = ((1, "mRNA"), (2, "mtRNA"), (3, "globin"))
+    models = [Model(synth.make_state_dict(k), synth.Config(), None, t, dtype=dtype, device=dev) for k, t in specs]
+    rng = np.random.default_rng(4)
+    lens = rng.integers(4096, 8616, size=150).tolist()
+    sigs = [synth.make_signals(20260103, 1, n, first_read=900 + i)[0] for i, n in enumerate(lens)]
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    B = len(lens)
+    dec = torch.empty(B, dtype=torch.uint8, device=dev)
+    want = torch.stack([m.classify_raw(sig, off, ln, lh) for m in models])
+    for _ in range(4):
+        got = classify_raw_ensemble(models, sig, off, ln, lh, decision=dec, max_len=8615, threshold=0.9)
+        assert torch.equal(got, want)
+    dec_par = dec.clone()
+    # the single-model workspace: the serial order through the same entry point
+    L = nv.lib()
+    hs = (C.c_void_p * 3)(*[m._h for m in models])
+    small = max(L.rs_workspace_bytes(m._h, B, int(lh.max())) for m in models)
+    assert small < L.rs_ensemble_workspace_bytes(hs, 3, B, int(lh.max()))
+    ws = torch.empty(small, dtype=torch.uint8, device=dev)
+    out = torch.empty((3, B, 2), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    nv.check(L.rs_classify_ensemble(hs, 3, sig.data_ptr(), off.data_ptr(), ln.data_ptr(), lh.ctypes.data, B, int(lh.min()),
+                                    int(lh.max()), ws.data_ptr(), ws.numel(), out.data_ptr(), dec.data_ptr(), 8615, 0.9,
+                                    nv.RS_ENRICH, st), "rs_classify_ensemble")
+    assert torch.equal(out, want) and torch.equal(dec, dec_par)
+    assert L.rs_classify_ensemble(hs, 3, sig.data_ptr(), off.data_ptr(), ln.data_ptr(), lh.ctypes.data, B, int(lh.min()),
+                                  int(lh.max()), ws.data_ptr(), small - 4096, out.data_ptr(), None, 8615, 0.9, nv.RS_ENRICH,
+                                  st) == -5                                      # RS_ERR_WORKSPACE
+    serial = [hooked_model({"RS_ENSEMBLE_SERIAL": "1"}, synth.make_state_dict(k), dtype, dev, target=t) for k, t in specs]
+    assert torch.equal(classify_raw_ensemble(serial, sig, off, ln, lh), want)
+    for m in models + serial:
+        m.close()

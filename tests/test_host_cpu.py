@@ -1,0 +1,159 @@
+"""CPU-side checks of the control loop's host pieces: the C loops of riser_amd/_hostpack against their Python
+equivalents, the FakeClient's channel range, the channel partition of the sharded launcher and the launcher itself
+(world size 2, stub step: no GPU), and the property the poly(A) cache rests on (oracle)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import riser_oracle as ro
+from riser_amd import synth
+from riser_amd.fake_client import FakeClient, FakeRead, PlainFakeClient
+from riser_amd.launch import rank_channel_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = ("try_again", "accept", "reject", "no_decision")
+
+
+@pytest.fixture(scope="module")
+def hp():
+    from riser_amd import build
+    build.build_hostpack()
+    from riser_amd import _hostpack
+    return _hostpack
+
+
+def _reads(n, rng, lo=0, hi=400):
+    return [FakeRead(f"id-{i}", rng.integers(-300, 4000, size=int(rng.integers(lo, hi)), dtype=np.int16)) for i in range(n)]
+
+
+def test_hostpack_lengths_and_gather(hp):
+    rng = np.random.default_rng(3)
+    reads = _reads(70, rng)
+    reads.append(FakeRead("mv", memoryview(np.arange(90, dtype=np.int16).tobytes())[20:120]))    # a slice of a shared buffer
+    lens = np.empty(len(reads), dtype=np.int64)
+    hp.lengths(reads, lens)
+    assert lens.tolist() == [len(r.raw_data) // 2 for r in reads]
+    for start in (np.zeros(len(reads), dtype=np.int64), np.minimum(lens, rng.integers(0, 60, size=len(reads)))):
+        out = np.full(int((lens - start).sum()) + 7, -1, dtype=np.int16)
+        n = hp.gather(reads, start, out)
+        want = np.concatenate([np.frombuffer(r.raw_data, np.int16)[s:] for r, s in zip(reads, start.tolist())])
+        assert n == want.size and np.array_equal(out[:n], want) and (out[n:] == -1).all()
+    with pytest.raises(ValueError):
+        hp.gather(reads, np.zeros(len(reads), dtype=np.int64), np.zeros(5, dtype=np.int16))          # staging too small
+    with pytest.raises(ValueError):
+        hp.gather(reads, lens + 1, np.zeros(10, dtype=np.int16))                                      # start behind the end
+    with pytest.raises(TypeError):
+        hp.lengths(tuple(reads), lens)
+    with pytest.raises(AttributeError):
+        hp.lengths([object()], lens)
+
+
+def test_hostpack_gather_threaded_path(hp):
+    """more than 8 MiB in one call takes the multi-threaded copy: same bytes"""
+    rng = np.random.default_rng(5)
+    pool = rng.integers(0, 4000, size=6_000_000, dtype=np.int16)
+    mv = memoryview(pool.tobytes())
+    reads = [FakeRead(f"r{i}", mv[2 * i * 9000: 2 * (i * 9000 + 8000 + 37 * (i % 11))]) for i in range(640)]
+    lens = np.empty(len(reads), dtype=np.int64)
+    hp.lengths(reads, lens)
+    start = (np.arange(len(reads)) % 5) * 100
+    out = np.empty(int((lens - start).sum()), dtype=np.int16)
+    assert out.nbytes > (8 << 20)
+    assert hp.gather(reads, start.astype(np.int64), out) == out.size
+    want = np.concatenate([np.frombuffer(r.raw_data, np.int16)[s:] for r, s in zip(reads, start.tolist())])
+    assert np.array_equal(out, want)
+
+
+def test_hostpack_csv_rows_match_the_reference_format(hp):
+    """riser/control.py:145-153 prints p.item() of an fp32 probability with str(): the repr of the widened double"""
+    rng = np.random.default_rng(9)
+    reads = _reads(40, rng)
+    reads[5].id = 12345                                           # minknow-api <= 5 style numeric ids still print
+    sel = np.array([0, 5, 17, 39], dtype=np.int64)
+    chan = np.array([1, 512, 3000, 18000], dtype=np.int64)
+    ns = np.array([4096, 8615, 12048, 5000], dtype=np.int32)
+    p32 = np.array([[0.5, 1e-5, 1.0], [0.9, 0.90000004, 0.0], [1e-30, 0.123456789, 3.0e-7], [0.99999994, 1e-45, 0.25]],
+                   dtype=np.float32)
+    p = np.ascontiguousarray(p32, dtype=np.float64)
+    dec = np.array([0, 2, 3, 1], dtype=np.uint8)
+    got = hp.format_rows("1700000000,", reads, sel, chan, ns, ",mRNA;mtRNA;globin,", p, 3, ",0.9,enrich,", dec, NAMES)
+    want = "".join(f"1700000000,{reads[i].id},{c},{n},mRNA;mtRNA;globin,{';'.join(str(float(q)) for q in row)},0.9,enrich,{NAMES[d]}\n"
+                   for i, c, n, row, d in zip(sel.tolist(), chan.tolist(), ns.tolist(), p32, dec.tolist()))
+    assert got == want
+    assert hp.format_rows("h,", reads, sel[:0], chan[:0], ns[:0], ",m,", p[:0], 3, ",t,", dec[:0], NAMES) == ""
+    with pytest.raises(ValueError):
+        hp.format_rows("h,", reads, np.array([40], dtype=np.int64), chan[:1], ns[:1], ",m,", p[:1], 3, ",t,", dec[:1], NAMES)
+
+
+def test_fake_client_channel_range_and_flags():
+    batches = [[(ch, FakeRead(f"r{ch}", np.zeros(10, dtype=np.int16))) for ch in range(1, 13)] for _ in range(2)]
+    c = FakeClient(batches, first_channel=5, last_channel=8)
+    assert [ch for ch, _ in c.get_read_batch()] == [5, 6, 7, 8]
+    assert len(FakeClient(batches).get_read_batch()) == 12
+    assert np.dtype(FakeClient.raw_data_dtype) == np.int16 and PlainFakeClient.raw_data_dtype is None
+
+
+def test_rank_channel_ranges_partition_the_flow_cell():
+    for channels, world in ((512, 1), (512, 8), (18000 * 8, 8), (3000, 7), (12, 2), (9, 9)):
+        ranges = [rank_channel_range(r, world, channels) for r in range(world)]
+        assert ranges[0][0] == 1 and ranges[-1][1] == channels
+        assert all(ranges[i][1] + 1 == ranges[i + 1][0] for i in range(world - 1))
+        sizes = [b - a + 1 for a, b in ranges]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        rank_channel_range(0, 8, 4)
+
+
+def _launch(args, cwd):
+    r = subprocess.run([sys.executable, "-m", "riser_amd.launch", *args], cwd=cwd, capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")} |
+                           {"PYTHONPATH": ROOT})
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_launcher_two_ranks_stub(tmp_path):
+    """python -m riser_amd.launch --gpus 2 (stub step): two fresh children, each on its own channel range, write their own
+    CSV; the union of their rows is the single-rank run's, the minute counters are merged"""
+    script = os.path.join(ROOT, "tests", "golden", "control.json")
+    common = ["--channels", "22", "--stub", "--replay-script", script]
+    one = _launch(["--gpus", "1", "--out", str(tmp_path / "one"), *common], ROOT)
+    two = _launch(["--gpus", "2", "--out", str(tmp_path / "two"), *common], ROOT)
+    assert two["ranks"] == 2 and two["channel_ranges"] == [[1, 11], [12, 22]]
+
+    def rows(path):
+        return sorted(ln.split(",", 1)[1] for ln in open(path).read().strip().split("\n")[1:])
+    single = rows(str(tmp_path / "one.rank0.csv"))
+    parts = [rows(str(tmp_path / f"two.rank{r}.csv")) for r in range(2)]
+    assert sorted(parts[0] + parts[1]) == single and len(single) == 25 and all(parts)
+    assert all(int(ln.split(",")[1]) <= 11 for ln in parts[0]) and all(int(ln.split(",")[1]) >= 12 for ln in parts[1])
+    assert two["reads_received"] == one["reads_received"] == 25
+    assert two["minutes_merged"]["0"]["assessed"] == one["minutes_merged"]["0"]["assessed"] == 25
+    assert json.load(open(str(tmp_path / "two.summary.json")))["ranks"] == 2
+
+
+def test_launcher_refuses_more_ranks_than_devices(tmp_path):
+    r = subprocess.run([sys.executable, "-m", "riser_amd.launch", "--gpus", "64", "--replay-synthetic", "1", "--out",
+                        str(tmp_path / "x")], cwd=ROOT, capture_output=True, text=True, timeout=120,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+    assert r.returncode != 0 and "device(s) visible" in r.stderr
+
+
+def test_polya_end_is_prefix_stable():
+    """what lets the loop cache a read's poly(A) end by id whatever the cache's lifetime (riser/control.py:96-97,
+    riser/preprocess.py:87-102): the scan of riser/preprocess.py:42-79 is causal - window i looks at samples before
+    i + 500 only - so an end found on a prefix of a read is the end found on every extension of it"""
+    checked = 0
+    for rid in range(40):
+        sig = synth.make_raw_read(31, rid, 26000, polya=(rid % 4 != 0))
+        full = ro.polya_end(sig)
+        for n in (3000, 5200, 7777, 9000, 12500, 18001, 24000):
+            part = ro.polya_end(sig[:n])
+            if part is not None:
+                assert part == full, (rid, n, part, full)
+                checked += 1
+    assert checked > 60

@@ -8,7 +8,8 @@ import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from riser_amd import synth
-from riser_amd.replay import run_replay, scripted_batches
+from riser_amd.replay import chunked_batches, run_replay, scripted_batches
+from riser_amd.fake_client import FakeClient, PlainFakeClient
 
 
 def main():
@@ -20,14 +21,19 @@ def main():
     ap.add_argument("--kit", default="RNA004")
     ap.add_argument("--mode", default="enrich")
     ap.add_argument("--full-reupload", action="store_true", help="no device-resident signals: every read whole, every batch")
+    ap.add_argument("--traffic", default="whole", choices=["whole", "chunks"],
+                    help="whole: every batch re-sends the read from its start; chunks: a popping client, disjoint 2 s chunks")
+    ap.add_argument("--python-loops", action="store_true", help="eight-method duck type only (no C host loops)")
     args = ap.parse_args()
     from riser_amd import Model, SignalProcessor, Kit
     dev = torch.device("cuda", 0)
     models = [Model(synth.make_state_dict(s), synth.Config(), None, t, dtype=args.dtype, device=dev)
               for s, t in list(zip((1, 2, 3), ("mRNA", "mtRNA", "globin")))[: args.models]]
     proc = SignalProcessor(Kit.create_from_version(args.kit), device=dev)
-    res = run_replay(models, proc, scripted_batches(args.batches, args.channels), mode=args.mode, signal_cache=not args.full_reupload)
-    res.update(channels=args.channels, models=args.models, dtype=args.dtype, kit=args.kit)
+    batches = (chunked_batches if args.traffic == "chunks" else scripted_batches)(args.batches, args.channels)
+    res = run_replay(models, proc, batches, mode=args.mode, signal_cache=not args.full_reupload,
+                     client_cls=PlainFakeClient if args.python_loops else FakeClient)
+    res.update(channels=args.channels, models=args.models, dtype=args.dtype, kit=args.kit, traffic=args.traffic)
     print(json.dumps(res))
 
 
