@@ -16,6 +16,11 @@ MAD-normalise + 12-layer ConvNet forward + softmax, through the C ABI.
   --config progressive   configs[4]: mixed 2 s / 3 s / 4 s chunks (8000 / 12000 / 16000 samples in equal thirds of
                          each 512-read batch), fused normalise + conv, fp16 in split precision (f16x3: within 1e-3 of
                          the reference; --dtype f16 is the fast, approximate plain mode)
+  --config promethion_live  configs[3] as a LIVE system: every rank runs the batched ReadUntil control loop
+                         (riser_amd.SequencerControl) over its own range of 18 000 channels of an 18 000 x N-channel flow
+                         cell (riser_amd.launch.rank_channel_range; scripted AccumulatingCache traffic).  One step = one
+                         ReadUntil batch of the rank's channels: upload of the new samples, poly(A) scan, gating, normalise,
+                         forward, decision, client calls, CSV rows.  value = reads ASSESSED per second over all ranks
 
 Ranks: with WORLD_SIZE in the environment (torch.distributed.run, one rank per GPU) this process is one rank.  With
 --gpus N > 1 and NO WORLD_SIZE the script starts the N ranks itself as child processes (before it makes any GPU
@@ -77,7 +82,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="rna004_b512", choices=["rna004_b512", "promethion", "progressive"])
+    ap.add_argument("--config", default="rna004_b512", choices=["rna004_b512", "promethion", "progressive", "promethion_live"])
     ap.add_argument("--dtype", default=None, choices=["f32", "f32_direct", "bf16", "f16", "bf16x3", "f16x3"])
     ap.add_argument("--batch", type=int, default=None, help="reads per library call (sub-batch for promethion)")
     ap.add_argument("--chunk", type=int, default=CHUNK)
@@ -96,9 +101,9 @@ def parse_args(argv=None):
     if args.batch is None:
         args.batch = 1024 if args.config == "promethion" else BATCH
     if args.steps is None:
-        args.steps = 3 if args.config == "promethion" else 50
+        args.steps = {"promethion": 3, "promethion_live": 30}.get(args.config, 50)
     if args.warmup is None:
-        args.warmup = 1 if args.config == "promethion" else 30     # ~60 ms: the shader clock needs ~20 steps to settle
+        args.warmup = {"promethion": 1, "promethion_live": 4}.get(args.config, 30)   # ~60 ms: the shader clock needs ~20 steps to settle
     return args
 
 
@@ -214,6 +219,62 @@ class Workload:
             self.model.classify_raw(self.sig, self.off, self.ln, self.lens_host, out=self.probs)
 
 
+def algorithmic_bytes_per_step(channels, lens, esize, fused01=True):
+    """HBM bytes the conv stack must move per step if every layer reads its input and writes its pooled output once
+    (layer-fused figure; layers 0+1 as one launch: the normalised signal in, layer 1's output out)."""
+    tot = 0.0
+    for n in lens:
+        n = int(n)
+        if fused01:
+            tot += 4.0 * n + channels[1] * (n >> 2) * esize
+            first = 2
+        else:
+            tot += 4.0 * n + channels[0] * (n >> 1) * esize
+            first = 1
+        for i in range(first, len(channels)):
+            tot += (channels[i - 1] * (n >> i) + channels[i] * (n >> (i + 1))) * esize
+    return tot
+
+
+def traffic_object(args, model, wl):
+    """HBM-side bytes of the conv stack per step from the TRACKED rocprofv3 PMC passes of this tree's kernels
+    (profiles/rNN_pmc_fetch_write_<mode>.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this same command,
+    KiB per dispatch, FETCH doubled for gfx950 as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside a
+    run, so the figure is the profiled run's, valid for the same workload (config, dtype, batch, chunk)."""
+    tag = {"f32": "f32", "bf16x3": "bf16x3"}.get(args.dtype) if args.config == "rna004_b512" else (
+        "prog" if args.config == "progressive" and args.dtype == "f16x3" else None)
+    if tag is None or args.batch != BATCH or args.chunk != CHUNK:
+        return None
+    for rnd in ("r04", "r03"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_fetch_write_{tag}.json")
+        if os.path.exists(path):
+            break
+    else:
+        return None
+    with open(path) as f:
+        pmc = json.load(f)
+    conv = {k: v for k, v in pmc.items() if k.startswith("conv_")}
+    if not conv:
+        return None
+    steps = max(v["dispatches"] for k, v in conv.items() if "stream" in k) if any("stream" in k for k in conv) else None
+    if not steps:
+        return None
+    fetched = sum(2.0 * v.get("FETCH_SIZE", 0.0) * 1024 * v["dispatches"] for v in conv.values()) / steps
+    written = sum(v.get("WRITE_SIZE", 0.0) * 1024 * v["dispatches"] for v in conv.values()) / steps
+    launches = sum(v["dispatches"] for v in conv.values()) / steps
+    esize = 4 if args.dtype in ("f32", "f32_direct") else (4 if args.dtype in ("bf16x3", "f16x3") else 2)
+    alg = algorithmic_bytes_per_step(model.channels, wl.lens_host, esize, fused01=args.dtype == "f32")
+    if args.dtype != "f32":                               # 16-bit modes: layers 0+1+2 are one launch
+        alg = sum(4.0 * int(n) + model.channels[2] * (int(n) >> 3) * esize +
+                  sum((model.channels[i - 1] * (int(n) >> i) + model.channels[i] * (int(n) >> (i + 1))) * esize
+                      for i in range(3, model.n_layers)) for n in wl.lens_host)
+    return {"bytes_per_launch": round((fetched + written) / launches, 1), "launches_per_step": round(launches, 2),
+            "bytes_per_step": round(fetched + written, 1), "fetched_bytes_per_step": round(fetched, 1),
+            "written_bytes_per_step": round(written, 1), "algorithmic_bytes_per_step": round(alg, 1),
+            "ratio_to_algorithmic": round((fetched + written) / alg, 3), "fetch_doubled_for_gfx950": True,
+            "source": os.path.relpath(path, ROOT)}
+
+
 def roofline_object(args, model, wl, conv_ms_total, conv_calls, stage_ms, detail_calls):
     """conv stack = layers 1..n-1.  conv_ms_total: HIP-event time of the conv stack summed over `conv_calls` library
     calls of the timed region; stage_ms / detail_calls: the per-launch pass."""
@@ -243,6 +304,7 @@ def roofline_object(args, model, wl, conv_ms_total, conv_calls, stage_ms, detail
                           "algorithmic_tflops": round(fl_call / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
                           "executed_tflops": round(ex / wl.calls_per_step / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
                           "tile": [info[i]["bm"], info[i]["bn"], info[i]["kc"]]})
+    traffic = traffic_object(args, model, wl)
     alg_tf = conv_flop_step / (conv_ms_step * 1e-3) / 1e12 if conv_ms_step > 0 else 0.0
     exe_tf = executed_step / (conv_ms_step * 1e-3) / 1e12 if conv_ms_step > 0 else 0.0
     peak = PEAK_F32_MFMA_TF if args.dtype in ("f32", "f32_direct") else PEAK_BF16_MFMA_TF
@@ -257,9 +319,11 @@ def roofline_object(args, model, wl, conv_ms_total, conv_calls, stage_ms, detail
                if getattr(args, "streams", 1) > 1 else {})
     return {**overlap, "bound": "mfma", "kernel": kname + f", {nl - 1} launches per call, layers 1-{nl - 1}",
             "achieved": round(exe_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(exe_tf / peak, 4),
-            "traffic": None,
-            "traffic_note": "HBM bytes are not measurable from inside the run; FETCH_SIZE / WRITE_SIZE passes of this tree "
-                            "are under profiles/ (named per round, with the commit they were taken on)",
+            "traffic": traffic["bytes_per_launch"] if traffic else None,
+            "traffic_detail": traffic,
+            "traffic_note": "HBM-side bytes per conv launch (FETCH_SIZE x 2 + WRITE_SIZE) from the tracked rocprofv3 PMC passes of "
+                            "this same command (traffic_detail.source): counters cannot be collected from inside a run; null "
+                            "for workloads without a tracked pass",
             "achieved_note": "MFMA FLOPs the kernels execute (tile padding included; Winograd F(2,3) issues 2/3, F(4,3) 1/2 "
                              "of the direct convolution's multiplications; split-precision modes three MFMAs per product) / "
                              "HIP-event time of the conv stack inside the timed steps",
@@ -423,13 +487,18 @@ def control_loop_object(device, dtype):
     from riser_amd.model import Model
     from riser_amd.preprocess import Kit, SignalProcessor
     from riser_amd.replay import run_replay, scripted_batches
+    from riser_amd.fake_client import PlainFakeClient
+    from riser_amd.replay import chunked_batches
     proc = SignalProcessor(Kit.create_from_version("RNA004"), device=device)
-    batches = scripted_batches(210, 512)
+    batches = scripted_batches(260, 512)
     out = {"kit": "RNA004", "channels": 512, "dtype": dtype, "window_s": 1.0,
-           "note": "host wall time per ReadUntil batch from get_read_batch() to the reject / finish calls "
+           "note": "p50 / p99 / max_ms: host wall time per ReadUntil batch from get_read_batch() to the reject / finish calls "
                    "(riser/control.py:31-106): upload of the new samples of every read, poly(A) scan, gating, normalise, one "
-                   "forward per model, decision, CSV rows; first 3 batches dropped as warm-up.  Traffic: every channel "
-                   "re-sends its read whole, 1600 samples longer per batch (AccumulatingCache, riser/client.py:29-31)"}
+                   "forward per model, decision; loop_*: the whole iteration including the batch's CSV rows (written after "
+                   "the calls); first 3 batches dropped as warm-up (first_ms lists them); the garbage collector is frozen over "
+                   "the scripted batches (gc_frozen).  Traffic: every channel re-sends its read whole, 1600 samples longer per "
+                   "batch (an accumulating client); models_1_chunk_traffic: a client that pops its cache, disjoint 2 s chunks "
+                   "under one read id (what riser/client.py:44 delivers) - the signal store detects it and uploads whole reads"}
     spec = list(zip((1, 2, 3), ("mRNA", "mtRNA", "globin")))
     for n_models in (1, 3):
         models = [Model(synth.make_state_dict(s), synth.Config(), None, t, dtype=dtype, device=device) for s, t in spec[:n_models]]
@@ -438,6 +507,9 @@ def control_loop_object(device, dtype):
             # the same replay with every read re-uploaded whole each batch (no device-resident signals): what the
             # signal store saves (the part of it that pays)
             out["models_1_full_reupload"] = run_replay(models, proc, batches, signal_cache=False)
+            # the eight-method duck type only (one get_raw_signal call per read) instead of the C host loops
+            out["models_1_python_host_loops"] = run_replay(models, proc, batches, client_cls=PlainFakeClient)
+            out["models_1_chunk_traffic"] = run_replay(models, proc, chunked_batches(260, 512))
         for m in models:
             m.close()
     # the same loop with the models in split precision (bf16x3: within 1e-3 of the reference, labels identical - the mode of
@@ -448,12 +520,91 @@ def control_loop_object(device, dtype):
         for m in models:
             m.close()
     del batches
-    big = scripted_batches(14, 18000)
+    big = scripted_batches(60, 18000)
     models = [Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dtype, device=device)]
     out["promethion_18000_channels"] = run_replay(models, proc, big)
     out["promethion_18000_channels_full_reupload"] = run_replay(models, proc, big, signal_cache=False)
     models[0].close()
     return out
+
+
+def run_promethion_live(args, model, lib_dtype, device, rank, world):
+    """BASELINE config 4 as a running system: one control loop per rank, each on its own channel range."""
+    import gc
+    import logging
+    import tempfile
+    from riser_amd.control import PHASES, SequencerControl
+    from riser_amd.fake_client import FakeClient
+    from riser_amd.launch import rank_channel_range
+    from riser_amd.preprocess import Kit, SignalProcessor
+    from riser_amd.replay import scripted_batches
+    per_rank = args.reads_per_gpu
+    first, last = rank_channel_range(rank, world, per_rank * world)
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=device)
+    W, K = max(args.warmup, 1), args.steps
+    client = FakeClient(scripted_batches(W, per_rank, first_channel=first), first_channel=first, last_channel=last)
+    timed = scripted_batches(K, per_rank, first_channel=first, first_batch=W)
+
+    def csv_rows(path):
+        with open(path) as f:
+            return sum(1 for ln in f if not ln.startswith("batch_start"))
+
+    with tempfile.TemporaryDirectory() as d:
+        out_file = os.path.join(d, f"live.rank{rank}")
+        ctl = SequencerControl(client, [model], proc, logging.getLogger("riser_amd.bench"), out_file)
+        ctl.reserve(per_rank)
+        ctl.start()
+        gc.collect()
+        gc.freeze()              # the scripted batches are ~1e6 long-lived objects a live run never holds (riser_amd/replay.py)
+        try:
+            ctl.target("enrich", 1.0, 0.9)                          # W untimed batches
+            n_warm, rows_warm = len(ctl.batch_latencies), csv_rows(out_file + ".csv")
+            client.extend(timed)
+            torch.cuda.synchronize(device)
+            rdist.barrier(device)
+            t0 = time.perf_counter()
+            ctl.target("enrich", 1.0, 0.9)                          # exactly K batches
+            torch.cuda.synchronize(device)
+            rdist.barrier(device)
+            elapsed = time.perf_counter() - t0
+        finally:
+            gc.unfreeze()
+        ctl.finish()
+        rows_timed = csv_rows(out_file + ".csv") - rows_warm
+    lat = np.asarray(list(ctl.batch_latencies)[n_warm:]) * 1e3
+    loop = np.asarray(list(ctl.batch_loop_times)[n_warm:]) * 1e3
+    phases = np.asarray(list(ctl.batch_phases)[n_warm:]).reshape(-1, len(PHASES)) * 1e3
+    elapsed = rdist.reduce_scalar(elapsed, "max", device)
+    received = rdist.reduce_scalar(per_rank * K, "sum", device)
+    p99 = rdist.reduce_scalar(float(np.percentile(lat, 99)) if lat.size else 0.0, "max", device)
+    rows_timed = rdist.reduce_scalar(rows_timed, "sum", device)
+    if rank != 0:
+        rdist.finalize()
+        return 0
+    out = {"metric": "reads assessed/sec through the live ReadUntil control loop (PromethION-scale flow cell, RNA004)",
+           "value": round(rows_timed / elapsed, 1), "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": W,
+           "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if lib_dtype in ("f32", "f32w") else lib_dtype, "data": "synthetic",
+           "config": {"workload": f"live control loop, {per_rank} channels per rank of a {per_rank * world}-channel flow cell "
+                                  f"(rank r drives channels [r x {per_rank} + 1, (r + 1) x {per_rank}]), scripted AccumulatingCache "
+                                  "traffic (every read re-sent whole, 1600 samples longer per batch), 1 model: upload of the new "
+                                  "samples, poly(A) scan, gating, MAD-normalise + 12-layer ConvNet forward + softmax, decision, "
+                                  f"client calls, CSV rows; {lib_dtype}",
+                      "name": args.config, "channels_per_rank": per_rank, "sharding": "channel ranges across ranks, no collectives"},
+           "reads_received_per_s": round(received / elapsed, 1),
+           "p50_batch_latency_ms": round(float(np.percentile(lat, 50)), 3) if lat.size else None,
+           "p99_batch_latency_ms": round(p99, 3), "latency_samples": int(lat.size),
+           "loop_p50_ms": round(float(np.percentile(loop, 50)), 3) if loop.size else None,
+           "latency_note": "rank 0's p50, max over ranks of p99: host wall time per ReadUntil batch from get_read_batch() to the "
+                           "reject / finish calls (riser/control.py:31-106); loop_p50_ms includes the CSV rows; gc frozen over the "
+                           "scripted batches",
+           "phase_ms_median": {n: round(float(v), 3) for n, v in zip(PHASES, np.median(phases, axis=0))} if phases.size else {},
+           "gc_frozen": True, "window_s": 1.0, "roofline": None,
+           "roofline_note": "a host + PCIe + device pipeline, not one kernel: the device share is phase_ms_median.device_wait "
+                            "(the kernels' own roofline is the rna004_b512 line)"}
+    print(json.dumps(out), flush=True)
+    rdist.finalize()
+    return 0
 
 
 def cpu_baseline_object(args, sigs):
@@ -525,6 +676,8 @@ def main(argv=None):
     if lib_dtype not in Model.dtypes():
         raise SystemExit(f"bench.py: dtype {args.dtype} is not built into this library")
     model = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=lib_dtype, device=device)
+    if args.config == "promethion_live":
+        return run_promethion_live(args, model, lib_dtype, device, rank, world)
     wl = Workload(args, model, device, rank, world)
     step = wl.step
 

@@ -202,7 +202,9 @@ RS_API int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, 
  * The workspace is shared by the models (block table and normalised signals once).  With
  * rs_ensemble_workspace_bytes(models, n_models, B, Lmax) bytes every model has its own pair of activation buffers and the
  * forwards run CONCURRENTLY (model 0 on `stream`, the others on library-owned side streams forked behind the normalise
- * launch and joined in front of the decision; everything the call enqueues is ordered on `stream` as before).  With less,
+ * launch and joined in front of the decision; everything the call enqueues is ordered on `stream` as before) whenever the
+ * batch under-fills the chip (fewer than ~1800 blocks of 4096 samples: a live ReadUntil batch; larger batches fill it by
+ * themselves and run back to back).  With less,
  * but at least the MAXIMUM of rs_workspace_bytes(models[k], B, Lmax) over the models, they run back to back on `stream`;
  * below that the call is refused with RS_ERR_WORKSPACE.  The probabilities are the same bits either way.
  */

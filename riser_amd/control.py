@@ -132,6 +132,15 @@ class _Batch:
             self.raws = raws
             self.lens = np.fromiter((s.shape[0] for s in raws), dtype=np.int64, count=B)
 
+    def view(self, lo: int, hi: int) -> "_Batch":
+        """reads lo .. hi - 1 of the batch as a batch of their own (a slice of a PromethION-scale batch)"""
+        if lo == 0 and hi == len(self.reads):
+            return self
+        v = object.__new__(_Batch)
+        v.reads, v.ids, v.lens, v.native = self.reads[lo:hi], self.ids[lo:hi], self.lens[lo:hi], self.native
+        v.raws = None if self.raws is None else self.raws[lo:hi]
+        return v
+
     def stage(self, start: np.ndarray, out: np.ndarray) -> int:
         """out[: total] = concat(raw_i[start_i:]) -> total"""
         if self.native:
@@ -228,26 +237,58 @@ class _SignalStore:
             rows = self.rowmap[channels]
         return rows
 
+    def begin_batch(self, channels: np.ndarray, lens: np.ndarray):
+        """Once per ReadUntil batch, before its slices are updated: every device allocation the batch can need (a buffer
+        that grew between two slices would move under the kernels of the earlier one) and the cursors of the areas the
+        slices fill one behind the other."""
+        self._dup_channels = False
+        if self.resident:
+            rows = self._rows_of(channels)
+            # two reads of one channel in one batch (no real client does that: its cache is keyed by channel): nothing of
+            # this batch goes to the rows - a later slice would overwrite a row an earlier slice's kernels still read
+            self._dup_channels = np.unique(rows).size != rows.shape[0]
+            self._ensure(self.n_rows, int(lens.sum()) if self._dup_channels else int(lens[lens > self.pitch].sum()))
+        elif self.buf is None or self.buf.numel() < int(lens.sum()):
+            self._ensure(0, int(lens.sum()))
+        self._spill_at = 0           # samples of the spill area (resident) / of the whole buffer (not resident) in use
+        self._slice_bad = self._slice_reseen = 0
+
+    def end_batch(self):
+        """a client whose re-seen reads are mostly NOT extensions of what the rows hold gains nothing from the rows"""
+        if not self.resident:
+            return
+        if self._slice_reseen >= 16 and (self._slice_reseen - self._slice_bad) * 2 < self._slice_reseen:
+            self._bad_streak += 1
+            if self._bad_streak >= 3:
+                self.resident, self.auto_off = False, True
+                if self.logger is not None:
+                    self.logger.info("Signal store: re-seen reads do not extend the signal already on the device (this client "
+                                     "delivers chunks, not whole reads): every read is uploaded whole from now on.")
+        elif self._slice_reseen:
+            self._bad_streak = 0
+
     def update(self, channels: np.ndarray, batch: _Batch, pinned: _Pinned) -> np.ndarray:
-        """-> int64 [B]: offset of every read's first sample in self.buf"""
+        """One slice of a batch (the whole batch, for all but PromethION-scale ones) -> int64 [B]: offset of every read's
+        first sample in self.buf.  Copies and launches go to the CURRENT stream, which is synchronised first: the staging
+        buffers are re-used from slice to slice."""
         lens = batch.lens
         B = lens.shape[0]
         presented = int(lens.sum())
         self.samples_presented += presented
-        # the staging buffers below are re-used: whatever the previous batch still has in flight must have landed
         torch.cuda.current_stream(self.device).synchronize()
         if not self.resident:
             offs = np.zeros(B, dtype=np.int64)
             np.cumsum(lens[:-1], out=offs[1:])
-            self._ensure(0, presented)
+            offs += self._spill_at
             total = batch.stage(np.zeros(B, dtype=np.int64), self._stage(presented))
-            self.buf[:total].copy_(self.stage[:total], non_blocking=True)
+            self.buf[self._spill_at: self._spill_at + total].copy_(self.stage[:total], non_blocking=True)
+            self._spill_at += total
             self.samples_uploaded += total
             return offs
         T = self.TAIL
         rows = self._rows_of(channels)
         fits = lens <= self.pitch
-        if np.unique(rows).size != B:                               # two reads of one channel in one batch: nothing resident
+        if self._dup_channels:
             fits = np.zeros(B, dtype=bool)
         have = self.row_have[rows]
         reseen = fits & (self.row_id[rows] == batch.ids) & (have > 0)
@@ -274,7 +315,8 @@ class _SignalStore:
         spill_len = np.where(fits, 0, lens)
         spill_off = np.zeros(B, dtype=np.int64)
         np.cumsum(spill_len[:-1], out=spill_off[1:])
-        self._ensure(self.n_rows, int(spill_len.sum()))
+        spill_off += self._spill_at
+        self._spill_at += int(spill_len.sum())
         spill_base = self.cap_rows * self.pitch
         dst = np.where(fits, rows * self.pitch + start, spill_base + spill_off)
         fi = np.flatnonzero(fits)
@@ -295,16 +337,8 @@ class _SignalStore:
             nv.check(nv.lib().rs_copy_segments(self.stage_dev.data_ptr(), self.buf.data_ptr(), d_src.data_ptr(),
                                                d_dst.data_ptr(), d_len.data_ptr(), int(live.size),
                                                torch.cuda.current_stream(self.device).cuda_stream), "rs_copy_segments")
-        # a client whose re-seen reads are mostly NOT extensions of what the rows hold gains nothing from the rows
-        if n_reseen >= 16 and n_delta * 2 < n_reseen:
-            self._bad_streak += 1
-            if self._bad_streak >= 3:
-                self.resident, self.auto_off = False, True
-                if self.logger is not None:
-                    self.logger.info("Signal store: re-seen reads do not extend the signal already on the device (this client "
-                                     "delivers chunks, not whole reads): every read is uploaded whole from now on.")
-        elif n_reseen:
-            self._bad_streak = 0
+        self._slice_reseen += n_reseen
+        self._slice_bad += n_reseen - n_delta
         return np.where(fits, rows * self.pitch, spill_base + spill_off)
 
 
@@ -341,6 +375,7 @@ class SequencerControl:
         self._store = _SignalStore(processor.device, resident=signal_cache, logger=logger)
         self._pinned = _Pinned(processor.device)
         self._res_probs = self._res_dec = None
+        self._side, self._events = None, []       # PromethION-scale batches: the upload / poly(A) stream of the slice pipeline
         self._channels_seen = 0
         self._reserved_for = 0
         self._ph = np.zeros(len(PHASES))
@@ -370,8 +405,15 @@ class SequencerControl:
             self._res_dec = _Pair(torch.empty(cap, dtype=torch.uint8, device=dev),
                                   torch.empty(cap, dtype=torch.uint8).pin_memory())
 
+    SLICE_READS = 4096          # a batch of more than 1.5 x this many reads is assessed in slices of about this size
+
     def assess_batch(self, entries, mode, threshold, polyA_cache):
-        """entries: list of (channel, read).  -> _Assessed (the assessed reads in batch order) or None."""
+        """entries: list of (channel, read).  -> _Assessed (the assessed reads in batch order) or None.
+
+        A PromethION-scale batch (thousands of reads) is cut into SLICES that are pipelined over two HIP streams: while the
+        kernels of slice k classify on the caller's stream, the host stages slice k + 1 and a side stream uploads it,
+        scatters it and scans it for poly(A) ends - the host's share of the batch and the device's overlap instead of adding
+        up.  A MinION-sized batch is one slice on the caller's stream."""
         if not entries:
             return None
         ph = self._ph
@@ -385,58 +427,98 @@ class SequencerControl:
         reads = [e[1] for e in entries]
         channels = np.fromiter((e[0] for e in entries), dtype=np.int64, count=B)
         batch = _Batch(self.client, reads)
-        ids, lens = batch.ids, batch.lens
         t, ph[0] = self._tick(t, 0)
         self._pinned.reset(96 * B + (1 << 12))
-        offs = self._store.update(channels, batch, self._pinned)
-        sig = self._store.buf
-        t, ph[1] = self._tick(t, 1)
-
-        # -- poly(A) end for reads not in the cache: one launch -------------------------------
-        if polyA_cache:
-            cget = polyA_cache.get
-            end = np.fromiter((cget(i, 0) for i in ids), dtype=np.int64, count=B)
+        store = self._store
+        store.begin_batch(channels, batch.lens)
+        n_slices = 1 if B <= self.SLICE_READS * 3 // 2 else -(-B // self.SLICE_READS)
+        bounds = [B * k // n_slices for k in range(n_slices + 1)]
+        caller = torch.cuda.current_stream(dev)
+        if n_slices > 1:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            while len(self._events) < n_slices:
+                self._events.append(torch.cuda.Event())
+            side = self._side
+            side.wait_stream(caller)
         else:
-            end = np.zeros(B, dtype=np.int64)
-        need = np.flatnonzero(end == 0)
-        if need.size:
-            d_off = self._pinned.to_device(np.ascontiguousarray(offs[need]))
-            d_len = self._pinned.to_device(lens[need].astype(np.int32))
-            found = proc.polyA_end_device(sig, d_off, d_len, int(need.size)).cpu().numpy().astype(np.int64)
-            hit = np.flatnonzero(found > 0)
-            end[need[hit]] = found[hit]
-            polyA_cache.update(zip(ids[need[hit]].tolist(), found[hit].tolist()))
-        t, ph[2] = self._tick(t, 2)
-
-        # -- gating (riser/control.py:36-60) as offsets / lengths ------------------------------
+            side = caller
         max_len, min_len = proc.get_max_length(), proc.get_min_length()
         fixed = proc.get_fixed_trim_length()
-        has = end > 0
-        start = np.where(has, end + 1, fixed)
-        length = lens - start
-        ok = np.where(has, length >= min_len, lens > fixed + max_len)       # :53-56 / should_trim_fixed_length :39-50
-        sel = np.flatnonzero(ok)
-        if sel.size == 0:
+        n_models = len(self.models)
+        self._result_buffers(B)
+        flat_p, flat_d = self._res_probs.dev.view(-1), self._res_dec.dev
+        parts, keep, n_total = [], [], 0
+        for k in range(n_slices):
+            lo, hi = bounds[k], bounds[k + 1]
+            part = batch.view(lo, hi)
+            ids, lens = part.ids, part.lens
+            with torch.cuda.stream(side):
+                offs = store.update(channels[lo:hi], part, self._pinned)
+                sig = store.buf
+                t, dt = self._tick(t, 1)
+                ph[1] += dt
+                # -- poly(A) end for reads not in the cache: one launch -------------------------------
+                if polyA_cache:
+                    cget = polyA_cache.get
+                    end = np.fromiter((cget(i, 0) for i in ids), dtype=np.int64, count=hi - lo)
+                else:
+                    end = np.zeros(hi - lo, dtype=np.int64)
+                need = np.flatnonzero(end == 0)
+                if need.size:
+                    d_off = self._pinned.to_device(np.ascontiguousarray(offs[need]))
+                    d_len = self._pinned.to_device(lens[need].astype(np.int32))
+                    found = proc.polyA_end_device(sig, d_off, d_len, int(need.size)).cpu().numpy().astype(np.int64)
+                    hit = np.flatnonzero(found > 0)
+                    end[need[hit]] = found[hit]
+                    polyA_cache.update(zip(ids[need[hit]].tolist(), found[hit].tolist()))
+                t, dt = self._tick(t, 2)
+                ph[2] += dt
+                # -- gating (riser/control.py:36-60) as offsets / lengths ------------------------------
+                has = end > 0
+                start = np.where(has, end + 1, fixed)
+                length = lens - start
+                ok = np.where(has, length >= min_len, lens > fixed + max_len)   # :53-56 / should_trim_fixed_length :39-50
+                sel = np.flatnonzero(ok)
+                if sel.size == 0:
+                    continue
+                lens_a = np.minimum(length[sel], max_len).astype(np.int32)
+                off_d = self._pinned.to_device(np.ascontiguousarray(offs[sel] + start[sel]))
+                len_d = self._pinned.to_device(lens_a)
+                if side is not caller:
+                    self._events[k].record(side)
+            if side is not caller:
+                caller.wait_event(self._events[k])
+            # -- normalise once, one batched forward per model, decision on the device -------------
+            n_sel = int(sel.size)
+            probs_d = flat_p[n_models * 2 * n_total: n_models * 2 * (n_total + n_sel)].view(n_models, n_sel, 2)
+            dec_d = flat_d[n_total: n_total + n_sel]
+            classify_raw_ensemble(self.models, sig, off_d, len_d, lens_a, out=probs_d, decision=dec_d, max_len=max_len,
+                                  threshold=threshold, mode=_MODE[mode])
+            keep.append((off_d, len_d))                 # allocated on the side stream, read on the caller's: alive until the end
+            parts.append((lo + sel, lens_a, n_total, n_sel))
+            n_total += n_sel
+            t, dt = self._tick(t, 3)
+            ph[3] += dt
+        store.end_batch()
+        if n_total == 0:
+            if side is not caller:
+                caller.wait_stream(side)
             return None
-        lens_a = np.minimum(length[sel], max_len).astype(np.int32)
-
-        # -- normalise once, one batched forward per model, decision on the device -------------
-        n_sel, n_models = int(sel.size), len(self.models)
-        off_d = self._pinned.to_device(np.ascontiguousarray(offs[sel] + start[sel]))
-        len_d = self._pinned.to_device(lens_a)
-        self._result_buffers(n_sel)
-        probs_d = self._res_probs.dev.view(-1)[: n_models * n_sel * 2].view(n_models, n_sel, 2)
-        dec_d = self._res_dec.dev[:n_sel]
-        classify_raw_ensemble(self.models, sig, off_d, len_d, lens_a, out=probs_d, decision=dec_d, max_len=max_len,
-                              threshold=threshold, mode=_MODE[mode])
-        probs_p = self._res_probs.host.view(-1)[: n_models * n_sel * 2].view(n_models, n_sel, 2)
-        dec_p = self._res_dec.host[:n_sel]
-        probs_p.copy_(probs_d, non_blocking=True)
-        dec_p.copy_(dec_d, non_blocking=True)
-        t, ph[3] = self._tick(t, 3)
-        torch.cuda.current_stream(dev).synchronize()
-        p_on = np.ascontiguousarray(probs_p.numpy()[:, :, 1].T, dtype=np.float64)          # [read][model]
-        res = _Assessed(reads, sel, channels[sel], lens_a, p_on, dec_p.numpy().copy())
+        probs_h = self._res_probs.host.view(-1)[: n_models * 2 * n_total]
+        dec_h = self._res_dec.host[:n_total]
+        probs_h.copy_(flat_p[: n_models * 2 * n_total], non_blocking=True)
+        dec_h.copy_(flat_d[:n_total], non_blocking=True)
+        caller.synchronize()
+        if side is not caller:
+            side.synchronize()
+        del keep
+        pn, dn = probs_h.numpy(), dec_h.numpy()
+        p_on = np.empty((n_total, n_models), dtype=np.float64)                              # [read][model]
+        for _, _, at, n in parts:
+            p_on[at: at + n] = pn[n_models * 2 * at: n_models * 2 * (at + n)].reshape(n_models, n, 2)[:, :, 1].T
+        sel_all = np.concatenate([p[0] for p in parts])
+        res = _Assessed(reads, sel_all, channels[sel_all], np.concatenate([p[1] for p in parts]), p_on, dn.copy())
         t, ph[4] = self._tick(t, 4)
         return res
 

@@ -49,6 +49,8 @@ Hooks Hooks::from_env() {
     text("RS_FORCE_SHAPE_H16", h.force_h16, sizeof(h.force_h16));
     text("RS_H16_PANEL", h.h16_panel, sizeof(h.h16_panel));
     text("RS_FORCE_SHAPE_RING", h.force_ring, sizeof(h.force_ring));
+    text("RS_EMU_ROWS", h.emu_rows, sizeof(h.emu_rows));
+    if (const char* e = getenv("RS_SMALL_F32_WAVES")) h.small_f32_waves = atoi(e);
     if (const char* e = getenv("RS_H16_RING")) h.h16_ring = atoi(e) != 0;
     if (const char* e = getenv("RS_H16_WRES")) h.h16_wres = atoi(e) != 0;
     return h;
@@ -667,7 +669,7 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
     char* ws = static_cast<char*>(d_ws);
     void* buf[2] = {ws + w.bufa_off, ws + w.bufb_off};
     // from here on the kernels see NB blocks of U samples as NB reads in slots of U (common.hpp: BlockPlan)
-    const int NB = bt.NB, U = w.U;
+    const int U = w.U;
     const int32_t* d_blen = bt.plan.blen;
     const int Lmin = bt.Lmin_blk;
 
@@ -683,13 +685,22 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
     int rc = RS_OK;
     // unfused layer 0: ldx < 0 tells the kernel that read b's samples start at block rbase[b] of d_x
     if (!fuse0 && !fuse0h)
-        rc = launch_conv0(d_x, packed_x ? -1 : ldx, d_len, bt.plan, NB, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
+        rc = launch_conv0(d_x, packed_x ? -1 : ldx, d_len, bt.plan, bt.NB, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
     if (rc != RS_OK) return rc;
     prof_mark(m, 1, st);
     int cur = 0;
+    const int NB_all = bt.NB;
     for (int i = 1; i < m->n_layers; ++i) {
         ConvLayerDev& L = m->layers[i];
         const int P_in = U >> i;
+        // RS_EMU_ROWS (timing experiments only, results WRONG): run this layer on a share of the blocks, to price a layout
+        // with fewer rows before building it (compact rows)
+        int NB = NB_all;
+        if (*m->hooks.emu_rows) {
+            int l, pm;
+            for (const char* q = m->hooks.emu_rows; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
+                if (sscanf(q, "%d:%d", &l, &pm) == 2 && l == i) NB = std::max(1, (int)((int64_t)NB_all * pm / 1000));
+        }
         if (i == 1 && fuse0h && m->n_layers > 2 && !(m->dbg_dst && m->dbg_layer <= 2) &&
             conv_stream012_h16_ok(L, m->layers[2], m->channels[0], P_in)) {
             // layers 0 + 1 + 2 of the 16-bit modes in one streaming kernel; its output takes the place of layer 2's
@@ -715,7 +726,24 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         const bool ring = !stream16 && (x3 || (is16 && m->hooks.h16_ring && L.d_w2));
         // ... and narrow layers whose whole weight tensor fits LDS next to two activation slabs on the weights-resident kernel
         const bool wres = ring && conv_wres_h16_ok(L, x3);
-        const int kind = (stream32 || stream16 || wres) ? 0 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)
+        // fp32 Winograd layers of a launch with only a handful of rows (Model.classify at batch 1, a thin ReadUntil batch):
+        // one wave per 16 x 16 tile instead of 256-row tiles that are mostly padding (conv_small_f32.hip; same bits)
+        bool small32 = m->dtype == RS_F32W && !stream32 && !m->tuning && m->hooks.small_f32_waves != 0 && conv_small_f32_ok(L);
+        if (small32) {
+            const int64_t rows_in = (int64_t)NB * P_in;
+            if (m->hooks.small_f32_waves > 0)                           // forced limit (tests, A/B runs)
+                small32 = conv_small_f32_waves(L, rows_in) <= m->hooks.small_f32_waves;
+            else {
+                // the launch planner's own estimate of the tiled kernel against the small kernel's (both in cycles, both
+                // rough): take the small kernel where it is clearly ahead
+                const int n16 = round_up(L.c_out, 16) / 16;
+                const double tiled = L.wino_m == 4
+                    ? conv_wino4_plan_cost((rows_in + 3) / 4, n16, L.plan.kc, L.plan.nch, m->num_cu)
+                    : conv_wino_plan_cost(rows_in / 2, n16, L.plan.kc, L.plan.nch, m->num_cu);
+                small32 = conv_small_f32_waves(L, rows_in) <= 4096 && conv_small_f32_cost(L, rows_in, m->num_cu) < 0.8 * tiled;
+            }
+        }
+        const int kind = (stream32 || stream16 || wres || small32) ? 0 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)
                                                                     : m->dtype == RS_F32 ? 3 : 4;
         m->last_ring[i] = ring;
         auto launch_layer = [&]() -> int {
@@ -725,7 +753,10 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                                             m->num_cu, st);
                 m->last_bm[i] = 32;
                 m->last_bn[i] = round_up(L.c_out, 16);
-            } else if (m->dtype == RS_F32W && L.wino_m == 4)
+            } else if (small32)
+                rc = launch_conv_small_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_blen, NB, P_in,
+                                           i, st, &m->last_bm[i], &m->last_bn[i]);
+            else if (m->dtype == RS_F32W && L.wino_m == 4)
                 rc = launch_conv_wino4(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_blen, NB,
                                        P_in, i, m->num_cu, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
             else if (m->dtype == RS_F32W)
@@ -930,7 +961,13 @@ int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d
     // A smaller workspace (rs_workspace_bytes of the widest model), a profiled or a tuning model, or RS_ENSEMBLE_SERIAL
     // run the forwards back to back on the caller's stream.
     const size_t buf_bytes = w.bufb_off - w.bufa_off;
-    bool concurrent = n_models > 1 && ws_bytes >= w.bufa_off + (size_t)n_models * 2 * buf_bytes && !m0->hooks.ensemble_serial;
+    // ... and so does a batch that fills the chip by itself: measured (tools/ensemble_probe.py, three models, same box,
+    // interleaved) concurrent / serial = 2.4x at 32 reads, 1.5x at 128, 1.14x (fp32) / 1.13x (bf16x3) at the live 357 x 8615
+    // batch (1071 blocks), 1.01x / 0.99x at 512 x 16000 (2048 blocks): beyond ~1800 blocks of 4096 samples one model's
+    // launches leave nothing for another's to use, and the fork / join is pure overhead
+    constexpr int64_t kConcurrentBelowSamples = 1800LL * 4096;
+    bool concurrent = n_models > 1 && ws_bytes >= w.bufa_off + (size_t)n_models * 2 * buf_bytes &&
+                      !m0->hooks.ensemble_serial && (int64_t)bt.NB * w.U < kConcurrentBelowSamples;
     for (int k = 0; k < n_models; ++k)
         if (models[k]->prof_on || models[k]->tuning || models[k]->dbg_dst) concurrent = false;
     for (int k = 1; k < n_models && concurrent; ++k)

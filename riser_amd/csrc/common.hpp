@@ -59,6 +59,8 @@ struct Hooks {
     bool no_stream_f32 = false;      // RS_NO_STREAM_F32 / _H16: tiled kernels instead of the streaming ones
     bool no_stream_h16 = false;
     bool no_stream012 = false;       // RS_NO_STREAM012: layers 0+1 and 2 of the 16-bit modes as two launches instead of one
+    int small_f32_waves = -1;        // RS_SMALL_F32_WAVES: fp32 Winograd launches of at most this many 16 x 16 tiles run the
+                                     // small-batch kernel (0 = never; default -1: wherever its cost estimate beats the tiled kernel's)
     bool ensemble_serial = false;    // RS_ENSEMBLE_SERIAL: rs_classify_ensemble runs its forwards back to back on the caller's stream
     bool conv_stamps = false;        // RS_CONV_STAMPS: in-kernel clock stamps of the direct fp32 kernel
     char force_f32[256] = "";        // RS_FORCE_SHAPE_F32 / _WINO / _WINO4 / _H16: "layer:wm,wn,mt,nt;..."
@@ -67,6 +69,7 @@ struct Hooks {
     char force_h16[256] = "";
     char force_ring[256] = "";       // RS_FORCE_SHAPE_RING
     char h16_panel[128] = "";        // RS_H16_PANEL: "64" or "layer:64;..."
+    char emu_rows[128] = "";         // RS_EMU_ROWS "layer:permille;...": TIMING ONLY - the layer runs on that share of the batch's blocks
     bool h16_ring = true;            // RS_H16_RING=0: plain 16-bit tiled layers on conv_h16.hip instead of the LDS-DMA ring kernel
     bool h16_wres = true;            // RS_H16_WRES=0: narrow 16-bit layers on the ring kernel instead of the weights-resident one
     static Hooks from_env();
@@ -163,6 +166,14 @@ bool conv_stream_f32_ok(const ConvLayerDev& L1, int c0, int P_in1);
 int launch_conv_stream_f32(const ConvLayerDev& L1, const float* d_xs, const float* d_w0, int c0, float* d_y,
                            const int32_t* d_len, int B, int P_in1, int num_cu, hipStream_t st);
 int conv_wino_max_bn();
+// fp32 Winograd for launches of a few rows (small batches): one wave per 16 x 16 tile, no LDS (conv_small_f32.hip);
+// bit-identical to conv_wino.hip / conv_wino4.hip
+bool conv_small_f32_ok(const ConvLayerDev& L);
+int64_t conv_small_f32_waves(const ConvLayerDev& L, int64_t rows_in);        // workgroups (16 x 16 tiles) of such a launch
+double conv_small_f32_cost(const ConvLayerDev& L, int64_t rows_in, int num_cu);   // estimate, shader cycles
+double conv_wino_plan_cost(int64_t rows_out, int n16, int kc, int nch, int num_cu);
+int launch_conv_small_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
+                          int layer_index, hipStream_t st, int* bm_out, int* bn_out);
 // narrow 16-bit layers (C_in <= 32, C_out <= 48): per-wave streaming kernel, optionally with ConvNet
 // layer 0 folded in (fuse_xs = normalised signals at the padded pitch behind 16 zero bytes)
 bool conv_stream_h16_ok(const ConvLayerDev& L, int P_in);

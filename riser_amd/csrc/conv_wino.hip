@@ -574,6 +574,12 @@ const Shape* choose_shape(int64_t rows_out, int n16, int kc, int nch, int num_cu
 }  // namespace
 
 int conv_wino_max_bn() { return 256; }
+// planner's estimate (SIMD cycles) of one launch with the best tile shape (compared with the small-batch kernel's in api.hip)
+double conv_wino_plan_cost(int64_t rows_out, int n16, int kc, int nch, int num_cu) {
+    double cost = 1e300;
+    choose_shape(rows_out, n16, kc, nch, num_cu, &cost);
+    return cost;
+}
 int conv_wino_num_shapes() { return kNumShapes; }
 bool conv_wino_shape_ok(const ConvLayerDev& L, int k) {
     return k >= 0 && k < kNumShapes && (L.plan.kc == 16 || L.plan.kc == 20 || L.plan.kc == 24) &&

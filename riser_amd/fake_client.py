@@ -46,6 +46,10 @@ class FakeClient:
         self.finished = []
         self.unblock_durations = []
 
+    def extend(self, batches):
+        """more scripted batches behind the ones already played (the loop's is_running() turns true again)"""
+        self._batches.extend(batches)
+
     # --- the eight methods of riser/client.py ---------------------------------------
     def start_streaming_reads(self):
         self.started = True

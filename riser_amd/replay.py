@@ -30,7 +30,7 @@ VISITS = 5                         # batches a read stays in its pore before the
 
 
 def scripted_batches(n_batches: int, channels: int = 512, seed: int = 4242, min_len: int = 7000,
-                     max_len: int = 22000, pool_reads: int | None = None):
+                     max_len: int = 22000, pool_reads: int | None = None, first_channel: int = 1, first_batch: int = 0):
     """-> list of n_batches lists of (channel, FakeRead).
 
     The traffic of an AccumulatingCache client (riser/client.py:29-31, `get_read_chunks(last=True)`): every channel
@@ -38,7 +38,8 @@ def scripted_batches(n_batches: int, channels: int = 512, seed: int = 4242, min_
     before, for VISITS batches; channels are staggered so every batch carries reads of every age.  Reads come from a
     pool of synthetic raw reads (adapter + poly(A) plateau + RNA squiggle, synth.make_raw_read); a read's id is unique
     to its (channel, turn), and its raw_data is a memoryview of the pool (no copies, so PromethION-scale batches of
-    18 000 channels stay cheap to script)."""
+    18 000 channels stay cheap to script).  `first_channel`: the channel numbers run from there (one rank's range of a
+    sharded flow cell, riser_amd/launch.py); `first_batch`: continue a script where an earlier call stopped."""
     rng = np.random.default_rng(7)
     pool_reads = pool_reads or min(2 * channels, 1024)
     pool = []
@@ -47,7 +48,7 @@ def scripted_batches(n_batches: int, channels: int = 512, seed: int = 4242, min_
         sig = synth.make_raw_read(seed, rid, n, polya=(rid % 5 != 0))
         pool.append((memoryview(np.ascontiguousarray(sig, dtype=np.int16).tobytes()), n))
     batches = []
-    for b in range(n_batches):
+    for b in range(first_batch, first_batch + n_batches):
         reads = []
         for ch in range(channels):
             age = (b + ch) % VISITS                              # batches this read has been in the pore
@@ -55,7 +56,7 @@ def scripted_batches(n_batches: int, channels: int = 512, seed: int = 4242, min_
             raw, n = pool[(turn * channels + ch) % pool_reads]
             seen = min(n, n - (VISITS - 1 - age) * SAMPLES_PER_BATCH)
             seen = max(seen, min(n, 2000))
-            reads.append((ch + 1, FakeRead(f"read-{turn}-{ch}", raw[: 2 * seen])))
+            reads.append((first_channel + ch, FakeRead(f"read-{turn}-{first_channel + ch - 1}", raw[: 2 * seen])))
         batches.append(reads)
     return batches
 

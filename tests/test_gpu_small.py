@@ -1,0 +1,107 @@
+"""Small batches (round 4): the per-wave fp32 Winograd kernel (csrc/conv_small_f32.hip) that runs the conv layers of
+launches with only a handful of rows - Model.classify at batch 1, thin ReadUntil batches - against the tiled kernels it
+replaces: bit for bit, at every batch size around the hand-over, and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import riser_oracle as ro
+from riser_amd import synth
+
+from conftest import hooked_model
+
+pytestmark = pytest.mark.gpu
+SIG_SEED = 20260103
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def models(dev):
+    from riser_amd.model import Model
+    sd = synth.make_state_dict(1)
+    small = Model(sd, synth.Config(), None, "m", dtype="f32w", device=dev)          # default: small kernel where it applies
+    tiled = hooked_model({"RS_SMALL_F32_WAVES": "0"}, sd, "f32w", dev)              # never
+    always = hooked_model({"RS_SMALL_F32_WAVES": "100000000"}, sd, "f32w", dev)     # on every Winograd layer but the fused 0 + 1
+    yield small, tiled, always
+    for m in (small, tiled, always):
+        m.close()
+
+
+def _reads(lens, first=4100):
+    return [synth.make_signals(SIG_SEED, 1, int(n), first_read=first + i)[0] for i, n in enumerate(lens)]
+
+
+@pytest.mark.parametrize("lens", [[16000], [4096], [8615], [12000, 4097], [5000, 16000, 8191], [8615] * 8,
+                                  [4096, 4097, 6024, 8000, 8192, 8615, 12048, 16000]])
+def test_small_batches_equal_the_tiled_kernels_bitwise(dev, models, lens):
+    from riser_amd.preprocess import pack_reads
+    small, tiled, always = models
+    sigs = _reads(lens)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    want = tiled.classify_raw(sig, off, ln, lh, return_logits=True)
+    got = small.classify_raw(sig, off, ln, lh, return_logits=True)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # the small kernel really ran: its tile report for the last layer is 16 channels wide
+    assert small.layer_info()[11]["bn"] == 16 and tiled.layer_info()[11]["bn"] > 16
+    oracle = ro.classify_reads(synth.make_state_dict(1), sigs)
+    assert np.abs(got[0].cpu().numpy() - oracle).max() < 1e-4
+
+
+def test_a_read_alone_equals_its_row_of_a_large_batch(dev, models):
+    """Model.classify (batch 1, riser/model.py:22-28) against the same read inside a 300-read batch, which runs the tiled
+    kernels on every layer: the same bits"""
+    from riser_amd.preprocess import pack_reads
+    small, _, _ = models
+    rng = np.random.default_rng(2)
+    lens = rng.integers(4096, 16001, size=300)
+    sigs = _reads(lens, first=9000)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    big = small.classify_raw(sig, off, ln, lh).cpu().numpy()
+    assert small.layer_info()[11]["bn"] > 16                      # the large batch stayed on the tiled kernels
+    for k in (0, 17, 151, 299):
+        s1, o1, l1, h1 = pack_reads([sigs[k]], dev)
+        assert np.array_equal(small.classify_raw(s1, o1, l1, h1).cpu().numpy()[0], big[k])
+    # the reference's own entry point: a normalised signal at batch 1
+    x = ro.mad_normalise(sigs[17])
+    p = small.classify(x).cpu().numpy()
+    pb = small.classify_batch([ro.mad_normalise(s) for s in sigs[15:20]]).cpu().numpy()
+    assert np.array_equal(p, pb[2])
+
+
+@pytest.mark.parametrize("B", [12, 24, 48, 96])
+def test_hand_over_between_the_kernels(dev, models, B):
+    """batch sizes where some layers are below the wave limit and others above it, and the small kernel forced onto every
+    layer (hundreds of row tiles, several reads per tile, ragged ends): always the tiled kernels' bits"""
+    from riser_amd.preprocess import pack_reads
+    small, tiled, always = models
+    rng = np.random.default_rng(B)
+    lens = rng.integers(4096, 12049, size=B)
+    sigs = _reads(lens, first=20000 + B)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    want = tiled.classify_raw(sig, off, ln, lh)
+    assert torch.equal(small.classify_raw(sig, off, ln, lh), want)
+    assert torch.equal(always.classify_raw(sig, off, ln, lh), want)
+    info = always.layer_info()
+    assert all(info[i]["bn"] == 16 for i in range(2, 12))
+
+
+def test_forward_path_and_uniform_layout(dev, models):
+    """rs_forward (signals that arrive normalised: layer 1 is a Winograd launch of its own) and the layout without host
+    lengths (every read in the blocks of the longest)"""
+    from riser_amd import Kit, SignalProcessor
+    from riser_amd.preprocess import pack_reads
+    small, tiled, always = models
+    lens = [6000, 4096, 9000]
+    sigs = _reads(lens, first=777)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    x = proc.normalise_device(sig, off, ln, 3, 9000)
+    want = tiled.forward_batch(x, lh, lens_dev=ln)
+    assert torch.equal(small.forward_batch(x, lh, lens_dev=ln), want)
+    assert torch.equal(always.forward_batch(x, lh, lens_dev=ln), want)
+    assert torch.equal(small.classify_raw(sig, off, ln, lh, packed=False), tiled.classify_raw(sig, off, ln, lh, packed=False))
