@@ -264,3 +264,29 @@ def test_ensemble_concurrent_equals_serial(dev, dtype):
     assert torch.equal(classify_raw_ensemble(serial, sig, off, ln, lh), want)
     for m in models + serial:
         m.close()
+
+
+@pytest.mark.parametrize("traffic", ["whole", "chunks", "whole_no_store"])
+def test_sliced_pipeline_equals_one_slice(dev, tmp_path, monkeypatch, traffic):
+    """a PromethION-scale batch is assessed in slices pipelined over two streams (upload / poly(A) scan of slice k + 1 under
+    the kernels of slice k): forced onto 150-channel batches (slices of ~16 reads) it writes the same rows and sends the
+    same lists as the single-slice path, with the signal store, with a chunk client (store switched off mid-run) and without
+    the store; reads longer than a store row (spill area) and duplicate channels in one batch included"""
+    from riser_amd import Kit, Model, SignalProcessor
+    from riser_amd.control import SequencerControl
+    from riser_amd.replay import chunked_batches, scripted_batches
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    models = [Model(synth.make_state_dict(s), synth.Config(), None, f"t{s}", device=dev) for s in (1, 3)]
+    batches = chunked_batches(9, 150) if traffic == "chunks" else scripted_batches(7, 150)
+    long_read = FakeRead("long", synth.make_raw_read(5, 5, 40000, True))
+    batches[2].append((3000, long_read))
+    batches[3].append((3000, long_read))
+    batches[4].append((7, FakeRead("dup-channel", synth.make_raw_read(5, 6, 15000, True))))     # channel 7 twice in one batch
+    cache = traffic != "whole_no_store"
+    one = _run(batches, models, proc, str(tmp_path / "one"), signal_cache=cache)
+    monkeypatch.setattr(SequencerControl, "SLICE_READS", 16)
+    many = _run(batches, models, proc, str(tmp_path / "many"), signal_cache=cache)
+    assert many[:3] == one[:3] and len(one[0]) > (40 if traffic == "chunks" else 300)
+    assert many[3]._side is not None and one[3]._side is None               # the pipeline really ran / really did not
+    for m in models:
+        m.close()
