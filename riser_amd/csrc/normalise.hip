@@ -88,8 +88,13 @@ __device__ void block_select2(KeyFn key, int n, int R, int k_lo, int k_hi, unsig
     // level for tens of samples, so with lanes on CONSECUTIVE samples most lanes of an instruction hit the same bin and
     // the LDS atomic unit serialises them.
     const int chunk = ((n + kThreads - 1) / kThreads) | 1;
-    // (reading four keys ahead of their four atomics was measured: +40 % on the pass - the LDS atomic unit, at ~3 lane
-    // atomics per clock on this data, is what bounds the two selects: 10-12 k of the kernel's 58 k cycles each)
+    // (reading four keys ahead of their four atomics was measured: +40 % on the pass.  Round 4 tried to cut the atomics
+    // instead - histogram a SAMPLE (every 8th key), bound a window around the wanted ranks, count exactly in registers,
+    // histogram only the ~9 % of keys inside the window, with lane-replicated counters: exact, and TWICE as slow (19-21 k
+    // cycles per select against 10-12 k; in-kernel stamps: sample 1.2 k, each of the two block scans 3 k, the counting pass
+    // 7 k, the window pass 5.5 k).  A pass over a read is ~5 k cycles of per-element VALU work and barrier / scan latency at
+    // this occupancy whatever it does with the key - it is not the atomic unit that bounds the selects, and more passes
+    // with fewer atomics lose.  DESIGN.md 5, K1 in phases.)
     for (int k = 0, i = tid * chunk; k < chunk; ++k, ++i)
         if (i < n) atomicAdd(&hist[key(i) >> shift], 1u);
     __syncthreads();

@@ -105,3 +105,44 @@ def test_forward_path_and_uniform_layout(dev, models):
     assert torch.equal(small.forward_batch(x, lh, lens_dev=ln), want)
     assert torch.equal(always.forward_batch(x, lh, lens_dev=ln), want)
     assert torch.equal(small.classify_raw(sig, off, ln, lh, packed=False), tiled.classify_raw(sig, off, ln, lh, packed=False))
+
+
+def test_normalise_selects_on_hostile_long_reads(dev):
+    """K1's exact selects on LONG reads built to stress a histogram select (the short adversarial cases of
+    tests/test_gpu_parity.py never leave one bin per key): period-8 patterns, bimodal data with the median in the gap, ramps,
+    plateaus with the median at a plateau edge, half-constant reads, int16 extremes (range > 4096 bins: the refinement pass),
+    MAD = 0 and near-MAD = 0 - all bit-exact float64 against the oracle, at 4096 ... 65536 samples.  (Written for a sampled,
+    windowed select that round 4 built and measured at half the speed of the plain pass: DESIGN.md 5, K1.)"""
+    from riser_amd import Kit, SignalProcessor
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    rng = np.random.default_rng(12)
+    reads = []
+    for n in (4096, 4097, 5000, 8615, 16000, 16001, 33333, 65536):
+        t = np.arange(n)
+        base = rng.normal(500, 60, n)
+        reads += [
+            np.round(base),                                                        # nanopore-like
+            np.where(t % 8 == 0, 900, np.round(base)),                             # every sampled key is an outlier level
+            np.where(t % 8 == 0, np.round(base), 100 + (t % 7)),                   # the sample sees only the minority
+            np.where(t % 2 == 0, 300, 700) + (t % 5),                              # bimodal, median in the gap
+            np.where(t < n // 2, 400, 401),                                        # median at a plateau edge (even n: 400.5)
+            t % 3000,                                                              # ramp
+            np.sort(np.round(base)),                                               # sorted: systematic sampling is exact ...
+            np.sort(np.round(base))[::-1].copy(),
+            np.where(t < n // 2 + 1, 512, np.round(base)),                         # > half identical: MAD = 0
+            np.where(t < n // 2 - 3, 512, np.round(base)),                         # just under half identical
+            np.where(t % 97 == 0, 32767, np.where(t % 89 == 0, -32768, np.round(base))),   # int16 extremes: range 65535
+            rng.integers(-32768, 32768, n),                                        # uniform over all of int16
+            np.full(n, -7),                                                        # constant
+            np.where(t % 16 < 8, 510, 511),                                        # two values, period 16
+        ]
+    sigs = [np.clip(np.asarray(r), -32768, 32767).astype(np.int16) for r in reads]
+    got, stats = proc.mad_normalise_batch(sigs, return_stats=True)
+    for k, (g, s) in enumerate(zip(got, sigs)):
+        med, mad = ro.median_mad(s)
+        assert (stats[k, 0], stats[k, 1]) == (med, mad), (k, len(s), stats[k], med, mad)
+        want = ro.mad_normalise(s)
+        if mad == 0:
+            assert not g.any()
+        else:
+            assert np.array_equal(g, want), (k, len(s))
