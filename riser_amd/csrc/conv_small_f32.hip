@@ -216,8 +216,13 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, int
     static_for<kDepth>([&](auto D_) { load_chunk(D_, decltype(D_)::value); });
     store_chunk(std::integral_constant<int, 0>{}, lds);
     load_chunk(std::integral_constant<int, 0>{}, kDepth);
-    Frag cur;
-    read_frag(cur, lds, std::integral_constant<int, 0>{});
+    // fragments are read kAhead k-steps before their MFMA (a ring of kAhead + 1 register sets, indexed statically: the body
+    // unrolled below holds kDepth * KQ k-steps, a multiple of kAhead + 1)
+    constexpr int kAhead = 2;
+    static_assert((kDepth * KQ) % (kAhead + 1) == 0 && KQ > kAhead, "static fragment ring");
+    Frag fr[kAhead + 1];
+    read_frag(fr[0], lds, std::integral_constant<int, 0>{});
+    read_frag(fr[1], lds, std::integral_constant<int, 1>{});
     for (int c = 0; c < a.nch; c += kDepth) {
         static_for<kDepth>([&](auto D_) {
             constexpr int dd = decltype(D_)::value;
@@ -226,24 +231,23 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, int
             const float* here = lds + (cc & 1) * BUF;
             float* next = lds + ((cc + 1) & 1) * BUF;
             // chunk cc + 1: its registers (loaded kDepth - 1 steps ago) -> the other LDS buffer, then the set is free for
-            // chunk cc + 1 + kDepth
+            // chunk cc + 1 + kDepth.  (Every fragment read of chunk cc - 1, whose image this overwrites, was issued during
+            // chunk cc - 1's own k-steps: the look-ahead never reaches back.)
             store_chunk(std::integral_constant<int, nx>{}, next);
             load_chunk(std::integral_constant<int, nx>{}, cc + 1 + kDepth);
             if (cc < a.nch) {                                          // wave-uniform
                 static_for<KQ>([&](auto ST_) {
                     constexpr int st = decltype(ST_)::value;
-                    Frag nxt;
-                    if constexpr (st + 1 < KQ)
-                        read_frag(nxt, here, std::integral_constant<int, st + 1>{});
+                    constexpr int i = dd * KQ + st;                    // k-step of the unrolled body
+                    if constexpr (st + kAhead < KQ)
+                        read_frag(fr[(i + kAhead) % (kAhead + 1)], here, std::integral_constant<int, st + kAhead>{});
                     else
-                        read_frag(nxt, next, std::integral_constant<int, 0>{});
-                    kstep(cur);
-                    cur = nxt;
+                        read_frag(fr[(i + kAhead) % (kAhead + 1)], next, std::integral_constant<int, st + kAhead - KQ>{});
+                    kstep(fr[i % (kAhead + 1)]);
                 });
             }
         });
     }
-
     return acc;
 }
 
