@@ -292,10 +292,10 @@ def roofline_object(args, model, wl, conv_ms_total, conv_calls, stage_ms, detail
     info = model.layer_info()
     passes = MFMA_PASSES.get(args.dtype, 1)
     per_layer, executed_step = [], 0.0
-    U = model.block_samples()                                                    # packed layout: len // U + 1 blocks per read
-    blocks_step = int((lens.astype(np.int64) // U + 1).sum())
     for i in range(1, nl):
         ms = float(stage_ms[1 + i]) / max(detail_calls, 1)                       # per library call
+        U = info[i]["block_samples"]                                             # packed layout: len // U + 1 blocks per read,
+        blocks_step = int((lens.astype(np.int64) // U + 1).sum())               # finer blocks below the last three layers
         rows = blocks_step * -(-(U >> i) // info[i]["gemm_row_div"])              # GEMM rows of a step
         ex = 2.0 * rows * info[i]["n_pad"] * info[i]["k_pad"] * passes
         executed_step += ex

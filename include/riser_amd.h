@@ -118,8 +118,12 @@ RS_API size_t rs_workspace_bytes(const rs_model* m, int B, int Lmax);
 RS_API int rs_max_batch(const rs_model* m, int Lmax);
 
 /* Block size U of the packed activation layout in samples: 2^max(n_layers, 12) (4096 for the shipped net; doubled when
- * RS_WINO4 puts the last layer on the F(4,3) lowering).  Read b of a batch starts at sample U * sum_{i<b}(len_i / U + 1)
- * of the normalised-signal region and at row (that >> (layer + 1)) of conv layer `layer`'s output buffer. */
+ * RS_WINO4 puts the last layer on the F(4,3) lowering).  Read b of a batch occupies len_b / U + 1 blocks.  Since ABI 2.1 the
+ * layout has TWO LEVELS: this is the block of the last three conv layers and of the head; the layers before them (and the
+ * normalised signal) run on finer blocks - rs_layer_info.block_samples, 1024 samples for the shipped net - so that a read
+ * costs its own length more closely (a live 8615-sample read: 9 x 1024 instead of 3 x 4096 samples of rows); the library
+ * re-packs the (small) buffer in between.  In conv layer `layer`'s output buffer read b starts at row
+ * (Uf * sum_{i<b}(len_i / Uf + 1)) >> (layer + 1), Uf = that layer's block_samples.  Results do not depend on the layout. */
 RS_API int rs_block_samples(const rs_model* m);
 
 /*
@@ -256,6 +260,8 @@ typedef struct rs_layer_info {
     int32_t n_pad;              /* padded output channels the MFMA tiles cover */
     int32_t bm, bn, kc;         /* workgroup tile (rows x couts) and channel chunk of the last launch (0 if never run) */
     int32_t gemm_row_div;       /* conv rows per GEMM row: 1 direct lowering, 2 Winograd F(2,3), 4 Winograd F(4,3) */
+    int32_t block_samples;      /* ABI 2.1: block size (samples) of the packed layout this layer runs on - its input rows and
+                                   its output rows; the output of the last fine layer is then re-packed to coarse blocks */
 } rs_layer_info;
 RS_API int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out);
 

@@ -34,7 +34,7 @@ class SeqOp(C.Structure):
 
 class LayerInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("c_in", "c_out", "cp_in", "cp_out", "k_pad", "n_pad", "bm", "bn", "kc", "gemm_row_div")]
+                ("c_in", "c_out", "cp_in", "cp_out", "k_pad", "n_pad", "bm", "bn", "kc", "gemm_row_div", "block_samples")]
 
 
 class NativeError(RuntimeError):

@@ -42,6 +42,7 @@ Hooks Hooks::from_env() {
     h.no_stream_h16 = flag("RS_NO_STREAM_H16");
     h.no_stream012 = flag("RS_NO_STREAM012");
     h.ensemble_serial = flag("RS_ENSEMBLE_SERIAL");
+    h.one_level = flag("RS_ONE_LEVEL");
     h.conv_stamps = flag("RS_CONV_STAMPS");
     text("RS_FORCE_SHAPE_F32", h.force_f32, sizeof(h.force_f32));
     text("RS_FORCE_SHAPE_WINO", h.force_wino, sizeof(h.force_wino));
@@ -74,7 +75,12 @@ struct rs_model {
     int device = 0;
     int dtype = RS_F32;
     int n_layers = 0;
-    int pad_shift = 0;                    // row pitch of the signals is a multiple of 1 << pad_shift (>= n_layers)
+    int pad_shift = 0;                    // log2 of the block size of the (late layers') packed layout (>= n_layers)
+    // two-level packed layout: conv layers 0 .. split - 1 run on FINE blocks of 1 << fine_shift samples, a
+    // re-pack of layer split - 1's (small) output moves the batch to the blocks of 1 << pad_shift samples the late layers and
+    // the head need.  split == n_layers / fine_shift == pad_shift: one level.
+    int fine_shift = 0;
+    int split = 0;
     int n_classes = 2;
     int channels[kMaxLayers] = {0};
     int cp[kMaxLayers] = {0};             // padded row width of layer i's OUTPUT buffer
@@ -222,56 +228,87 @@ bool use_wino4(int layer, int n_layers, int c_in, int c_out) {
     return c_in >= 96 || (c_in >= 32 && (round_up(c_out, 16) / 16) % 5 == 0);
 }
 
-// Workspace: [block table][16 zero bytes | normalised signals, NB blocks of U floats][activation buffer A][B].
-// Laid out for the upper bound NB = B * (Lmax / U + 1) blocks, so the offsets depend on (B, Lmax) only; a batch of
-// mixed lengths uses a prefix of every region.
+// Workspace: [coarse block table][fine block table][16 zero bytes | normalised signals, fine blocks of Uf floats][activation
+// buffer A][B].  Laid out for the upper bounds NB = B * (Lmax / U + 1) blocks of either size, so the offsets depend on
+// (B, Lmax) only; a batch of mixed lengths uses a prefix of every region.  With one level the fine table IS the coarse one.
 struct WsLayout {
-    size_t rbase_off, blen_off, bread_off, xnorm_off, bufa_off, bufb_off, total;
-    int U;                  // block size in samples (1 << pad_shift)
-    int nblk_max;           // blocks of a read of Lmax samples
-    int64_t nb_max;         // B * nblk_max
+    size_t rbase_off, blen_off, bread_off;          // coarse table
+    size_t rbase_f_off, blen_f_off, bread_f_off;    // fine table (== coarse when the model has one level)
+    size_t xnorm_off, bufa_off, bufb_off, total;
+    int U, Uf;              // block sizes in samples (1 << pad_shift, 1 << fine_shift)
+    int nblk_max, nblk_f_max;   // blocks of a read of Lmax samples
+    int64_t nb_max, nb_f_max;   // B * nblk_max
 };
+
+inline bool two_level(const rs_model* m) { return m->split < m->n_layers && m->fine_shift < m->pad_shift; }
+// block size (log2) of the layout conv layer i READS (i = 0: the normalised signal); its output is in the same layout, except
+// that layer split - 1's output is re-packed to the coarse layout before layer `split` reads it
+inline int layer_shift(const rs_model* m, int i) { return (two_level(m) && i < m->split) ? m->fine_shift : m->pad_shift; }
 
 WsLayout ws_layout(const rs_model* m, int B, int Lmax) {
     WsLayout w{};
+    const bool two = two_level(m);
     w.U = 1 << m->pad_shift;
+    w.Uf = two ? 1 << m->fine_shift : w.U;
     w.nblk_max = (Lmax >> m->pad_shift) + 1;
     w.nb_max = (int64_t)B * w.nblk_max;
+    w.nblk_f_max = two ? (Lmax >> m->fine_shift) + 1 : w.nblk_max;
+    w.nb_f_max = (int64_t)B * w.nblk_f_max;
     size_t buf = 0;
-    for (int i = 0; i < m->n_layers; ++i) {
-        const size_t rows = (size_t)w.nb_max * (w.U >> (i + 1));
+    for (int i = 0; i < m->n_layers; ++i) {                       // layer i's output buffer
+        const bool fine = two && i < m->split;
+        const size_t rows = fine ? (size_t)w.nb_f_max * (w.Uf >> (i + 1)) : (size_t)w.nb_max * (w.U >> (i + 1));
         buf = std::max(buf, rows * m->cp[i] * esize(m));
+        if (two && i == m->split - 1)                             // ... and its re-packed copy in the coarse layout
+            buf = std::max(buf, (size_t)w.nb_max * (w.U >> (i + 1)) * m->cp[i] * esize(m));
     }
     buf = align_up(buf + kAlign);
     w.rbase_off = 0;
     w.blen_off = align_up((size_t)(B + 1) * 4);
     w.bread_off = w.blen_off + align_up((size_t)w.nb_max * 4);
-    w.xnorm_off = w.bread_off + align_up((size_t)w.nb_max * 4) + kAlign;   // the last 16 bytes before the rows are a zero prefix
-    w.bufa_off = align_up(w.xnorm_off + (size_t)w.nb_max * w.U * sizeof(float));
+    size_t at = w.bread_off + align_up((size_t)w.nb_max * 4);
+    if (two) {
+        w.rbase_f_off = at;
+        w.blen_f_off = w.rbase_f_off + align_up((size_t)(B + 1) * 4);
+        w.bread_f_off = w.blen_f_off + align_up((size_t)w.nb_f_max * 4);
+        at = w.bread_f_off + align_up((size_t)w.nb_f_max * 4);
+    } else {
+        w.rbase_f_off = w.rbase_off;
+        w.blen_f_off = w.blen_off;
+        w.bread_f_off = w.bread_off;
+    }
+    w.xnorm_off = at + kAlign;                                    // the last 16 bytes before the rows are a zero prefix
+    w.bufa_off = align_up(w.xnorm_off + (size_t)w.nb_f_max * w.Uf * sizeof(float));
     w.bufb_off = w.bufa_off + buf;
     w.total = w.bufb_off + buf;
     return w;
 }
 
-// What one call runs on: the block table in the workspace and the number of blocks in use (host-known: from the host's
+// What one call runs on: the block table(s) in the workspace and the number of blocks in use (host-known: from the host's
 // copy of the lengths, or nblk_max blocks for every read when it has none)
 struct Batch {
-    BlockPlan plan;
-    int NB = 0;             // blocks in use
-    int Lmin_blk = 0;       // lower bound of blen over the blocks (dead-tile hint), 0 = unknown
+    BlockPlan plan;         // coarse: late layers, head
+    BlockPlan fine;         // early layers, normalised rows (a copy of `plan` when the model has one level)
+    int NB = 0, NBf = 0;    // blocks in use
+    int Lmin_blk = 0, Lmin_blk_f = 0;   // lower bound of blen over the reads' last blocks (dead-tile hint), 0 = unknown
 };
 
 // h_len may be NULL.  Returns RS_OK or RS_ERR_LENGTH (a host length outside [2^n_layers, Lmax]).
 int make_batch(const rs_model* m, const WsLayout& w, void* d_ws, const int32_t* h_len, int B, int Lmin, int Lmax, Batch* out) {
     char* ws = static_cast<char*>(d_ws);
+    const bool two = two_level(m);
     Batch bt;
     bt.plan.rbase = reinterpret_cast<int32_t*>(ws + w.rbase_off);
     bt.plan.blen = reinterpret_cast<int32_t*>(ws + w.blen_off);
     bt.plan.bread = reinterpret_cast<int32_t*>(ws + w.bread_off);
     bt.plan.shift = m->pad_shift;
+    bt.fine.rbase = reinterpret_cast<int32_t*>(ws + w.rbase_f_off);
+    bt.fine.blen = reinterpret_cast<int32_t*>(ws + w.blen_f_off);
+    bt.fine.bread = reinterpret_cast<int32_t*>(ws + w.bread_f_off);
+    bt.fine.shift = two ? m->fine_shift : m->pad_shift;
     if (h_len) {
-        int64_t nb = 0;
-        int lmin_blk = w.U;
+        int64_t nb = 0, nbf = 0;
+        int lmin_blk = w.U, lmin_blk_f = w.Uf;
         for (int b = 0; b < B; ++b) {
             const int n = h_len[b];
             if (n < (1 << m->n_layers) || n > Lmax) {
@@ -279,18 +316,26 @@ int make_batch(const rs_model* m, const WsLayout& w, void* d_ws, const int32_t* 
                 return RS_ERR_LENGTH;
             }
             nb += (n >> m->pad_shift) + 1;
+            nbf += (n >> bt.fine.shift) + 1;
             lmin_blk = std::min(lmin_blk, n & (w.U - 1));            // the read's last block holds len mod U samples
+            lmin_blk_f = std::min(lmin_blk_f, n & (w.Uf - 1));
         }
-        bt.plan.uniform_nblk = 0;
+        bt.plan.uniform_nblk = bt.fine.uniform_nblk = 0;
         bt.NB = (int)nb;
+        bt.NBf = (int)nbf;
         bt.Lmin_blk = lmin_blk;
+        bt.Lmin_blk_f = lmin_blk_f;
     } else {
         bt.plan.uniform_nblk = w.nblk_max;
+        bt.fine.uniform_nblk = w.nblk_f_max;
         bt.NB = (int)w.nb_max;
+        bt.NBf = (int)w.nb_f_max;
         // every read has nblk_max blocks: the last one of the shortest read holds max(Lmin - (nblk_max - 1) U, 0) samples
         bt.Lmin_blk = Lmin > 0 ? std::max(0, std::min(w.U, Lmin - (w.nblk_max - 1) * w.U)) : 0;
+        bt.Lmin_blk_f = Lmin > 0 ? std::max(0, std::min(w.Uf, Lmin - (w.nblk_f_max - 1) * w.Uf)) : 0;
     }
     bt.plan.nb_total = bt.NB;
+    bt.fine.nb_total = bt.NBf;
     *out = bt;
     return RS_OK;
 }
@@ -344,7 +389,7 @@ extern "C" {
 
 const char* rs_last_error(void) { return g_err; }
 
-int rs_version(void) { return (2 << 16) | 0; }
+int rs_version(void) { return (2 << 16) | 1; }
 
 int rs_device_count(void) {
     int n = 0;
@@ -532,6 +577,23 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
     m->pad_shift = std::max(n_layers, 12);
     for (int i = 1; i < n_layers; ++i)
         if (m->layers[i].wino_m == 4) m->pad_shift = std::max(m->pad_shift, i + 2);
+    // Two-level layout: the last three layers (and the head) need the coarse blocks - their launches are one round of
+    // tiles at a ReadUntil batch whatever the row count - everything before them runs on blocks a quarter the size (1024
+    // samples for the shipped net: a live 8615-sample read occupies 9216 samples of rows there instead of 12288).  The
+    // fine block must give layer split - 1 a whole output row per block, every F(4,3) layer below the split its group
+    // alignment, and the streaming kernels of layers 0-2 their 32-row steps.
+    m->split = n_layers;
+    m->fine_shift = m->pad_shift;
+    if (!m->hooks.one_level && n_layers >= 6) {
+        const int split = n_layers - 3;
+        int fs = std::max(split + 1, 8);
+        for (int i = 1; i < split; ++i)
+            if (m->layers[i].wino_m == 4) fs = std::max(fs, i + 2);
+        if (fs < m->pad_shift) {
+            m->split = split;
+            m->fine_shift = fs;
+        }
+    }
     if (rc == RS_OK) rc = upload(&m->d_zero, std::vector<float>(64, 0.0f));
     if (rc == RS_OK) {
         const int cl = channels[n_layers - 1];
@@ -580,10 +642,9 @@ int rs_block_samples(const rs_model* m) { return m ? 1 << m->pad_shift : 0; }
 int rs_max_batch(const rs_model* m, int Lmax) {
     if (!m || Lmax < 1) return 0;
     // every activation buffer (and the normalised signals) is addressed through a 2 GiB buffer-resource window
-    const int64_t U = 1 << m->pad_shift, nblk = (Lmax >> m->pad_shift) + 1;
-    int64_t per_block = U * 4;
-    for (int i = 0; i < m->n_layers; ++i) per_block = std::max<int64_t>(per_block, (U >> (i + 1)) * m->cp[i] * esize(m));
-    return (int)std::max<int64_t>(1, ((1LL << 31) - (1 << 16)) / (per_block * nblk));
+    const WsLayout w1 = ws_layout(m, 1, Lmax);
+    const int64_t per_read = std::max<int64_t>((int64_t)(w1.bufb_off - w1.bufa_off), (int64_t)w1.nb_f_max * w1.Uf * 4);
+    return (int)std::max<int64_t>(1, ((1LL << 31) - (1 << 20)) / per_read);
 }
 
 size_t rs_workspace_bytes(const rs_model* m, int B, int Lmax) {
@@ -626,7 +687,7 @@ static int check_call(const char* who, const rs_model* m, int B, int Lmax, const
         set_error("%s: workspace %zu < required %zu", who, ws_bytes, w.total);
         return RS_ERR_WORKSPACE;
     }
-    if (w.nb_max * (w.U / 2) > 0x7fffffffLL) {
+    if (w.nb_max * (w.U / 2) > 0x7fffffffLL || w.nb_f_max * (w.Uf / 2) > 0x7fffffffLL) {
         set_error("%s: batch too large, split it (%d reads of up to %d samples)", who, B, Lmax);
         return RS_ERR_ARG;
     }
@@ -657,6 +718,7 @@ int rs_forward(rs_model* m, const float* d_x, int64_t ldx, const int32_t* d_len,
     RS_HIP(guard.err);
     if (!m->prof_open) prof_mark(m, -1, static_cast<hipStream_t>(stream));
     rc = launch_plan(d_len, B, Lmax, bt.plan, static_cast<hipStream_t>(stream));
+    if (rc == RS_OK && two_level(m)) rc = launch_plan(d_len, B, Lmax, bt.fine, static_cast<hipStream_t>(stream));
     if (rc != RS_OK) return rc;
     return forward_impl(m, d_x, ldx, d_len, B, bt, w, d_ws, d_probs, d_logits, stream, false);
 }
@@ -669,29 +731,48 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
     char* ws = static_cast<char*>(d_ws);
     void* buf[2] = {ws + w.bufa_off, ws + w.bufb_off};
     // from here on the kernels see NB blocks of U samples as NB reads in slots of U (common.hpp: BlockPlan)
-    const int U = w.U;
-    const int32_t* d_blen = bt.plan.blen;
-    const int Lmin = bt.Lmin_blk;
+    // the layout a conv layer reads: fine blocks below the split, coarse ones from it on (one level: the same table)
+    const bool two = two_level(m);
+    auto fine_layer = [&](int i) { return two && i < m->split; };
+    const int U0 = w.Uf;                                          // block size of the normalised rows and of layers 0, 1
 
     // Winograd fp32 path: ConvNet layer 0 (one input channel) is folded into the staging of layer 1
     // when the signal rows are in the packed layout (always true via rs_classify)
-    const bool fuse0 = packed_x && m->dtype == RS_F32W && conv_wino_can_fuse0(m->layers[1], U >> 1);
+    // (either into the streaming kernel of layers 0 + 1, which only needs 64-row blocks, or - RS_NO_STREAM_F32 - into the tiled
+    // kernel's staging, which needs a tile to span at most two blocks)
+    const bool stream32_l1 = packed_x && m->dtype == RS_F32W && !m->hooks.no_fuse0 &&
+                             conv_stream_f32_ok(m->layers[1], m->channels[0], U0 >> 1);
+    const bool fuse0 = stream32_l1 || (packed_x && m->dtype == RS_F32W && conv_wino_can_fuse0(m->layers[1], U0 >> 1));
     // 16-bit paths: the narrow layers 1 and 2 run the per-wave streaming kernel; on the rs_classify path
     // layer 0 is folded into layer 1 there as well ("fused preprocess + conv")
     const bool x3 = is_x3(m->dtype);
     const bool is16 = m->dtype == RS_BF16 || m->dtype == RS_F16;          // plain 16-bit
     const bool f16 = is_f16_family(m->dtype);
-    const bool fuse0h = (is16 || x3) && packed_x && m->channels[0] <= 32 && conv_stream_h16_ok(m->layers[1], U >> 1);
+    const bool fuse0h = (is16 || x3) && packed_x && m->channels[0] <= 32 && conv_stream_h16_ok(m->layers[1], U0 >> 1);
     int rc = RS_OK;
     // unfused layer 0: ldx < 0 tells the kernel that read b's samples start at block rbase[b] of d_x
     if (!fuse0 && !fuse0h)
-        rc = launch_conv0(d_x, packed_x ? -1 : ldx, d_len, bt.plan, bt.NB, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
+        rc = launch_conv0(d_x, packed_x ? -1 : ldx, d_len, bt.fine, bt.NBf, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
     if (rc != RS_OK) return rc;
     prof_mark(m, 1, st);
     int cur = 0;
-    const int NB_all = bt.NB;
     for (int i = 1; i < m->n_layers; ++i) {
         ConvLayerDev& L = m->layers[i];
+        // layer split - 1 wrote its rows on fine blocks; the late layers read coarse ones: a re-pack of that (small) buffer -
+        // per read, its rows in order, zero rows up to the end of its coarse blocks - into the other buffer.  Not needed when
+        // every read fills its coarse blocks with fine ones (16000, 12000, 8000 samples: 16 / 12 / 8 blocks of 1024 = 4 / 3 / 2
+        // of 4096): then the two layouts put every row in the same place.
+        if (two && i == m->split && (int64_t)bt.NBf * w.Uf != (int64_t)bt.NB * w.U) {
+            const size_t row_bytes = (size_t)m->cp[i - 1] * esize(m);
+            rc = launch_repack_rows(buf[cur], buf[cur ^ 1], bt.fine, bt.plan, bt.NB, w.Uf >> i, w.U >> i, row_bytes, st);
+            if (rc != RS_OK) return rc;
+            cur ^= 1;
+        }
+        const bool fine = fine_layer(i);
+        const int U = fine ? w.Uf : w.U;
+        const int NB_all = fine ? bt.NBf : bt.NB;
+        const int32_t* d_blen = fine ? bt.fine.blen : bt.plan.blen;
+        const int Lmin = fine ? bt.Lmin_blk_f : bt.Lmin_blk;
         const int P_in = U >> i;
         // RS_EMU_ROWS (timing experiments only, results WRONG): run this layer on a share of the blocks, to price a layout
         // with fewer rows before building it (compact rows)
@@ -720,7 +801,7 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         // Lmin == 0 means "unknown": keep the test
         const int check_dead = (Lmin <= 0 || (U >> i) - (Lmin >> i) >= 64) ? 1 : 0;
         // kind of kernel this layer runs: 0 streaming (not tuned), 1 F(4,3), 2 F(2,3), 3 direct fp32, 4 tiled 16-bit
-        const bool stream32 = m->dtype == RS_F32W && fuse0 && i == 1 && conv_stream_f32_ok(L, m->channels[0], P_in);
+        const bool stream32 = i == 1 && stream32_l1;
         const bool stream16 = (is16 || x3) && i <= 2 && conv_stream_h16_ok(L, P_in);
         // split precision runs the LDS-DMA ring kernel on every layer, plain 16-bit on its tiled layers with RS_H16_RING
         const bool ring = !stream16 && (x3 || (is16 && m->hooks.h16_ring && L.d_w2));
@@ -839,7 +920,8 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         cur ^= 1;
     }
     rc = launch_head(buf[cur], act_dtype(m), m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
-                     U >> m->n_layers, m->n_layers, d_len, B, bt.plan, m->d_fcw, m->d_fcb, d_probs, d_logits, st);
+                     w.U >> m->n_layers, m->n_layers, d_len, B, bt.plan, two ? &bt.fine : nullptr, m->d_fcw, m->d_fcb, d_probs,
+                     d_logits, st);
     if (rc == RS_OK) prof_mark(m, m->n_layers + 1, st);
     return rc;
 }
@@ -848,7 +930,8 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
 static int normalise_packed(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
                             const WsLayout& w, const Batch& bt, void* d_ws, hipStream_t st) {
     float* xn = reinterpret_cast<float*>(static_cast<char*>(d_ws) + w.xnorm_off);
-    return launch_normalise(d_sig, d_off, d_len, B, Lmax, xn, 0, 0, nullptr, 0, nullptr, st, /*zero_prefix=*/1, &bt.plan);
+    return launch_normalise(d_sig, d_off, d_len, B, Lmax, xn, 0, 0, nullptr, 0, nullptr, st, /*zero_prefix=*/1, &bt.fine,
+                            two_level(m) ? &bt.plan : nullptr);
 }
 
 int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, const int32_t* h_len, int B,
@@ -875,7 +958,7 @@ int rs_classify(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const i
     if (rc != RS_OK) return rc;
     prof_mark(m, 0, st);
     const float* xn = reinterpret_cast<const float*>(static_cast<char*>(d_ws) + w.xnorm_off);
-    return forward_impl(m, xn, w.U, d_len, B, bt, w, d_ws, d_probs, d_logits, stream, true);
+    return forward_impl(m, xn, w.Uf, d_len, B, bt, w, d_ws, d_probs, d_logits, stream, true);
 }
 
 int rs_autotune(rs_model* m, const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, const int32_t* h_len, int B,
@@ -911,7 +994,8 @@ static bool ensemble_compatible(rs_model* const* models, int n_models) {
     const rs_model* m0 = models[0];
     for (int k = 0; k < n_models; ++k)
         if (!models[k] || models[k]->n_layers != m0->n_layers || models[k]->device != m0->device ||
-            esize(models[k]) != esize(m0) || models[k]->pad_shift != m0->pad_shift)
+            esize(models[k]) != esize(m0) || models[k]->pad_shift != m0->pad_shift || models[k]->fine_shift != m0->fine_shift ||
+            models[k]->split != m0->split)
             return false;
     return true;
 }
@@ -993,17 +1077,17 @@ int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d
             WsLayout wk = w;
             wk.bufa_off += (size_t)k * 2 * buf_bytes;
             wk.bufb_off += (size_t)k * 2 * buf_bytes;
-            rc = forward_impl(mk, xn, w.U, d_len, B, bt, wk, d_ws, d_probs + (size_t)k * B * 2, nullptr, mk->side_stream, true);
+            rc = forward_impl(mk, xn, w.Uf, d_len, B, bt, wk, d_ws, d_probs + (size_t)k * B * 2, nullptr, mk->side_stream, true);
             if (rc != RS_OK) return rc;
             RS_HIP(hipEventRecord(mk->ev_join, mk->side_stream));
         }
-        rc = forward_impl(m0, xn, w.U, d_len, B, bt, w, d_ws, d_probs, nullptr, stream, true);
+        rc = forward_impl(m0, xn, w.Uf, d_len, B, bt, w, d_ws, d_probs, nullptr, stream, true);
         if (rc != RS_OK) return rc;
         for (int k = 1; k < n_models; ++k) RS_HIP(hipStreamWaitEvent(st, models[k]->ev_join, 0));
     } else {
         for (int k = 0; k < n_models; ++k) {
             // every model keeps the block table and the normalised rows at the head of the workspace and ping-pongs behind them
-            rc = forward_impl(models[k], xn, w.U, d_len, B, bt, w, d_ws, d_probs + (size_t)k * B * 2, nullptr, stream, true);
+            rc = forward_impl(models[k], xn, w.Uf, d_len, B, bt, w, d_ws, d_probs + (size_t)k * B * 2, nullptr, stream, true);
             if (rc != RS_OK) return rc;
         }
     }
@@ -1099,6 +1183,7 @@ int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out) {
         out->k_pad = 3;
         out->n_pad = m->cp[0];
         out->gemm_row_div = 1;
+        out->block_samples = 1 << layer_shift(m, 0);
         return RS_OK;
     }
     const ConvLayerDev& L = m->layers[layer];
@@ -1111,6 +1196,7 @@ int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out) {
     out->bn = m->last_bn[layer];
     out->kc = L.plan.kc;
     out->gemm_row_div = m->dtype == RS_F32W ? L.wino_m : 1;
+    out->block_samples = 1 << layer_shift(m, layer);
     return RS_OK;
 }
 

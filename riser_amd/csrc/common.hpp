@@ -61,6 +61,7 @@ struct Hooks {
     bool no_stream012 = false;       // RS_NO_STREAM012: layers 0+1 and 2 of the 16-bit modes as two launches instead of one
     int small_f32_waves = -1;        // RS_SMALL_F32_WAVES: fp32 Winograd launches of at most this many 16 x 16 tiles run the
                                      // small-batch kernel (0 = never; default -1: wherever its cost estimate beats the tiled kernel's)
+    bool one_level = false;          // RS_ONE_LEVEL: every layer on the coarse blocks (the round-3 layout; bit-identical results)
     bool ensemble_serial = false;    // RS_ENSEMBLE_SERIAL: rs_classify_ensemble runs its forwards back to back on the caller's stream
     bool conv_stamps = false;        // RS_CONV_STAMPS: in-kernel clock stamps of the direct fp32 kernel
     char force_f32[256] = "";        // RS_FORCE_SHAPE_F32 / _WINO / _WINO4 / _H16: "layer:wm,wn,mt,nt;..."
@@ -105,7 +106,8 @@ struct BlockPlan {
 // plan != nullptr: the fp32 rows go to the packed block layout (ld32 / pad_to ignored) and the block table is written
 int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
                      float* d_out32, int64_t ld32, int32_t pad_to, double* d_out64, int64_t ld64,
-                     double* d_stats, hipStream_t st, int zero_prefix = 0, const BlockPlan* plan = nullptr);
+                     double* d_stats, hipStream_t st, int zero_prefix = 0, const BlockPlan* plan = nullptr,
+                     const BlockPlan* plan2 = nullptr);   // plan2: a second table (the late layers' coarser blocks), no rows
 // the block table alone (signals that arrive normalised: rs_forward)
 int launch_plan(const int32_t* d_len, int B, int Lmax, const BlockPlan& plan, hipStream_t st);
 
@@ -208,9 +210,13 @@ bool conv_h16_shape_ok(const ConvLayerDev& L, int k);
 int conv_f32_kc_max();
 
 // rows of read b: (rbase[b] * P_last) + t, t < len[b] >> n_layers (P_last = rows per block of the last buffer)
+// fine: the early layers' block table of a two-level layout (a read that did not fit EITHER table is reported as NaN), or null
 int launch_head(const void* d_y, int dtype, int cp, int c, int P_last, int n_layers,
-                const int32_t* d_len, int B, const BlockPlan& plan, const float* d_fcw, const float* d_fcb,
+                const int32_t* d_len, int B, const BlockPlan& plan, const BlockPlan* fine, const float* d_fcw, const float* d_fcb,
                 float* d_probs, float* d_logits, hipStream_t st);
+// rows of layer `split - 1`'s output from the fine block layout (Pf rows per block) to the coarse one (Pc rows per block)
+int launch_repack_rows(const void* d_src, void* d_dst, const BlockPlan& fine, const BlockPlan& coarse, int NB_coarse, int Pf,
+                       int Pc, size_t row_bytes, hipStream_t st);
 
 int launch_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len,
                   float thr, int mode, uint8_t* d_out, hipStream_t st);

@@ -39,6 +39,7 @@ constexpr int kSubBins = 32;           // refinement pass: keys < 2^17 -> shift 
 
 struct Scratch {
     int wave_tot[kWaves];
+    int wave_tot2[kWaves];
     int red_a[kWaves];
     int red_b[kWaves];
     int sel_bin[2];
@@ -199,10 +200,39 @@ __global__ __launch_bounds__(1024) void plan_kernel(const int32_t* __restrict__ 
     }
 }
 
+// A read's entries of one block table (every thread of the read's workgroup calls it).  Device lengths BELOW the host's
+// copy leave a tail of the table unused - empty blocks of read 0, written by the last read - so that every entry the host's
+// block count covers names a valid read (the conv kernels index len[] with it); a read whose blocks do not fit the table
+// (device length ABOVE the host's copy, which sized the workspace) is DROPPED: its slots inside the table become empty blocks
+// of itself and false is returned.
+__device__ __forceinline__ bool write_block_table(const BlockPlan& pl, int b, int n, int base, int nblk, bool last_read, int tid) {
+    if (tid == 0) {
+        pl.rbase[b] = base;
+        if (last_read) pl.rbase[b + 1] = base + nblk;
+    }
+    if (last_read)
+        for (int k = base + nblk + tid; k < pl.nb_total; k += kThreads) {
+            pl.blen[k] = 0;
+            pl.bread[k] = 0;
+        }
+    if (base + nblk > pl.nb_total) {
+        for (int k = base + tid; k < pl.nb_total; k += kThreads) {
+            pl.blen[k] = 0;
+            pl.bread[k] = b;
+        }
+        return false;
+    }
+    for (int j = tid; j < nblk; j += kThreads) {
+        pl.blen[base + j] = max(0, min(n - (j << pl.shift), 1 << pl.shift));
+        pl.bread[base + j] = b;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(kThreads) void normalise_kernel(
     const int16_t* __restrict__ sig, const int64_t* __restrict__ off, const int32_t* __restrict__ len,
     float* __restrict__ out32, int64_t ld32, int32_t pad_to, double* __restrict__ out64, int64_t ld64,
-    double* __restrict__ stats, int lmax, int zero_prefix, const BlockPlan pl) {
+    double* __restrict__ stats, int lmax, int zero_prefix, const BlockPlan pl, const BlockPlan pl2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     RS_K1_STAMP(0);
     // rs_classify lays the fp32 rows out behind 16 zero bytes: the conv kernel that folds layer 0
@@ -223,9 +253,14 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
     double* o64 = out64 ? out64 + (int64_t)b * ld64 : nullptr;
     // packed block layout: the read's first block is the number of blocks of the reads before it.  The length loads are
     // issued here and reduced together with min / max below, so their latency hides behind the staging of the read.
-    int nblk_before = 0;
+    // (two tables when the conv stack runs its early layers on finer blocks than its late ones: pl = the layout of the
+    // normalised rows and of the early layers, pl2 = the late layers'; the two sums travel in one 64-bit reduction)
+    long long nblk_before = 0;
     if (pl.rbase && pl.uniform_nblk <= 0)
-        for (int i = tid; i < b; i += kThreads) nblk_before += (min(len[i], lmax) >> pl.shift) + 1;
+        for (int i = tid; i < b; i += kThreads) {
+            const int li = min(len[i], lmax);
+            nblk_before += (long long)((li >> pl.shift) + 1) | ((long long)(pl2.rbase ? (li >> pl2.shift) + 1 : 0) << 32);
+        }
     RS_K1_STAMP(1);
     // ---- stage the read into LDS, min / max on the way ------------------------------------
     // 16-byte loads over the 16-byte-aligned body of the read (the LDS copy is shifted by the same
@@ -269,48 +304,33 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
     if (lane == 0) {
         sc->red_a[w] = mn;
         sc->red_b[w] = mx;
-        sc->wave_tot[w] = nblk_before;
+        sc->wave_tot[w] = (int)(nblk_before & 0xffffffffLL);
+        sc->wave_tot2[w] = (int)(nblk_before >> 32);
     }
     __syncthreads();
     mn = sc->red_a[0];
     mx = sc->red_b[0];
-    nblk_before = sc->wave_tot[0];
+    int nblk_before1 = sc->wave_tot[0], nblk_before2 = sc->wave_tot2[0];
 #pragma unroll
     for (int i = 1; i < kWaves; ++i) {
         mn = min(mn, sc->red_a[i]);
         mx = max(mx, sc->red_b[i]);
-        nblk_before += sc->wave_tot[i];
+        nblk_before1 += sc->wave_tot[i];
+        nblk_before2 += sc->wave_tot2[i];
     }
     __syncthreads();
     if (pl.rbase) {
         // this read's fp32 row starts at its first block, is zero-filled to the end of its last one, and the workgroup
-        // writes the read's entries of the block table the conv stack runs on
-        const int base = pl.uniform_nblk > 0 ? b * pl.uniform_nblk : nblk_before;
+        // writes the read's entries of the block table(s) the conv stack runs on
+        const bool last_read = b == (int)gridDim.x - 1;
+        const int base = pl.uniform_nblk > 0 ? b * pl.uniform_nblk : nblk_before1;
         const int nblk = plan_nblk(n, pl);
-        if (tid == 0) {
-            pl.rbase[b] = base;
-            if (b == (int)gridDim.x - 1) pl.rbase[b + 1] = base + nblk;
+        bool fits = write_block_table(pl, b, n, base, nblk, last_read, tid);
+        if (pl2.rbase) {
+            const int base2 = pl2.uniform_nblk > 0 ? b * pl2.uniform_nblk : nblk_before2;
+            fits = write_block_table(pl2, b, n, base2, plan_nblk(n, pl2), last_read, tid) && fits;
         }
-        // device lengths BELOW the host's copy leave a tail of the table unused: empty blocks of read 0, so that every entry
-        // the host's block count covers names a valid read (the conv kernels index len[] with it)
-        if (b == (int)gridDim.x - 1)
-            for (int k = base + nblk + tid; k < pl.nb_total; k += kThreads) {
-                pl.blen[k] = 0;
-                pl.bread[k] = 0;
-            }
-        // device lengths ABOVE the host's copy (which sized the workspace): never write outside it - the read is dropped,
-        // its slots inside the table become empty blocks of itself
-        if (base + nblk > pl.nb_total) {
-            for (int k = base + tid; k < pl.nb_total; k += kThreads) {
-                pl.blen[k] = 0;
-                pl.bread[k] = b;
-            }
-            return;
-        }
-        if (tid < nblk) {
-            pl.blen[base + tid] = max(0, min(n - (tid << pl.shift), 1 << pl.shift));
-            pl.bread[base + tid] = b;
-        }
+        if (!fits) return;                        // dropped (the head kernel reports NaN for it): never write outside the workspace
         o32 = out32 + ((int64_t)base << pl.shift);
         pad_to = nblk << pl.shift;
     }
@@ -419,7 +439,7 @@ int launch_plan(const int32_t* d_len, int B, int Lmax, const BlockPlan& plan, hi
 
 int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int Lmax,
                      float* d_out32, int64_t ld32, int32_t pad_to, double* d_out64, int64_t ld64,
-                     double* d_stats, hipStream_t st, int zero_prefix, const BlockPlan* plan) {
+                     double* d_stats, hipStream_t st, int zero_prefix, const BlockPlan* plan, const BlockPlan* plan2) {
     if (B <= 0) return RS_OK;
     if (Lmax < 1 || Lmax > kMaxNormLen) {
         set_error("rs_normalise: read length %d outside [1, %d]", Lmax, kMaxNormLen);
@@ -437,7 +457,7 @@ int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* 
         if (dev >= 0 && dev < kMaxDevices) attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(normalise_kernel, dim3(B), dim3(kThreads), lds, st, d_sig, d_off, d_len, d_out32, ld32,
-                       pad_to, d_out64, ld64, d_stats, Lmax, zero_prefix, plan ? *plan : BlockPlan{});
+                       pad_to, d_out64, ld64, d_stats, Lmax, zero_prefix, plan ? *plan : BlockPlan{}, plan2 ? *plan2 : BlockPlan{});
     RS_HIP(hipGetLastError());
 #ifdef RS_K1_STAMPS
     {

@@ -127,6 +127,7 @@ template <int DT>
 __global__ __launch_bounds__(kHeadThreads) void head_kernel(const void* __restrict__ yv, int cp, int c, int P_last,
                                                            int n_layers, const int32_t* __restrict__ len,
                                                            const int32_t* __restrict__ rbase, int nb_total,
+                                                           const int32_t* __restrict__ rbase_f, int nb_total_f,
                                                            const float* __restrict__ fcw, const float* __restrict__ fcb,
                                                            float* __restrict__ probs, float* __restrict__ logits) {
     __shared__ float red[kHeadThreads / 64][2];
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(const void* __restri
     const int rows = len[b] >> n_layers;
     const float inv = 1.0f / (float)rows;
     const int64_t row0 = (int64_t)rbase[b] * P_last;              // the read's first row (packed block layout)
-    if (rbase[b + 1] > nb_total) {                                // the read was dropped by the plan (see normalise_kernel)
+    // the read was dropped by the plan (see normalise_kernel): its blocks did not fit one of the tables
+    if (rbase[b + 1] > nb_total || (rbase_f && rbase_f[b + 1] > nb_total_f)) {
         if (tid < 2) {
             probs[2 * b + tid] = __builtin_nanf("");
             if (logits) logits[2 * b + tid] = __builtin_nanf("");
@@ -228,6 +230,45 @@ __global__ __launch_bounds__(256) void decide_kernel(const float* __restrict__ p
 
 }  // namespace
 
+// ---- re-pack between the two levels of the packed layout ---------------------------------------------------
+// The early conv layers run on fine blocks (Pf rows of the buffer per block), the late ones on coarse blocks (Pc rows):
+// read b's rows are contiguous from row rbase_f[b] * Pf resp. rbase_c[b] * Pc on, valid ones first, zeros behind them.
+// One workgroup per COARSE block: its Pc rows of `row_bytes` bytes come from the read's fine rows t = j * Pc + r (j = the
+// block's index inside the read) while the read's fine blocks last, zeros beyond.  The buffer is small at this depth (a few
+// MB for 512 reads at layer 8): one pass of 16-byte pieces.
+namespace {
+__global__ __launch_bounds__(256) void repack_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                          const int32_t* __restrict__ rbase_f, const int32_t* __restrict__ rbase_c,
+                                                          const int32_t* __restrict__ bread_c, int nb_f_total, int Pf, int Pc,
+                                                          int pieces_per_row) {
+    const int k = blockIdx.x;                                    // coarse block
+    const int b = bread_c[k];
+    const int j = k - rbase_c[b];
+    const int blocks_f = min(rbase_f[b + 1], nb_f_total) - rbase_f[b];        // the read's fine blocks (<= 0 if it was dropped)
+    const int64_t src0 = (int64_t)rbase_f[b] * Pf * pieces_per_row, dst0 = (int64_t)k * Pc * pieces_per_row;
+    const int limit = max(blocks_f, 0) * Pf;                     // fine rows the read owns
+    for (int f = threadIdx.x; f < Pc * pieces_per_row; f += blockDim.x) {
+        const int r = f / pieces_per_row, c = f - r * pieces_per_row;
+        const int t = j * Pc + r;
+        dst[dst0 + f] = t < limit ? src[src0 + (int64_t)t * pieces_per_row + c] : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+}  // namespace
+
+int launch_repack_rows(const void* d_src, void* d_dst, const BlockPlan& fine, const BlockPlan& coarse, int NB_coarse, int Pf,
+                       int Pc, size_t row_bytes, hipStream_t st) {
+    if (NB_coarse <= 0) return RS_OK;
+    if (row_bytes % 16 != 0 || Pf < 1 || Pc < 1) {
+        set_error("repack_rows: rows of %zu bytes / %d, %d rows per block", row_bytes, Pf, Pc);
+        return RS_ERR_ARG;
+    }
+    hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)NB_coarse), dim3(256), 0, st, static_cast<const uint4*>(d_src),
+                       static_cast<uint4*>(d_dst), fine.rbase, coarse.rbase, coarse.bread, fine.nb_total, Pf, Pc,
+                       (int)(row_bytes / 16));
+    RS_HIP(hipGetLastError());
+    return RS_OK;
+}
+
 int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, const BlockPlan& plan, int NB, const float* d_w4,
                  int cp_out, void* d_y, int dtype, hipStream_t st) {
     const int P1 = (1 << plan.shift) / 2;
@@ -252,12 +293,12 @@ int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, const Bloc
 }
 
 int launch_head(const void* d_y, int dtype, int cp, int c, int P_last, int n_layers, const int32_t* d_len,
-                int B, const BlockPlan& plan, const float* d_fcw, const float* d_fcb, float* d_probs, float* d_logits,
-                hipStream_t st) {
+                int B, const BlockPlan& plan, const BlockPlan* fine, const float* d_fcw, const float* d_fcb, float* d_probs,
+                float* d_logits, hipStream_t st) {
     auto fn = dtype == RS_F16 ? head_kernel<2> : dtype == RS_BF16 ? head_kernel<1>
             : dtype == RS_BF16X3 ? head_kernel<RS_BF16X3> : dtype == RS_F16X3 ? head_kernel<RS_F16X3> : head_kernel<0>;
     hipLaunchKernelGGL(fn, dim3(B), dim3(kHeadThreads), 0, st, d_y, cp, c, P_last, n_layers, d_len, plan.rbase,
-                       plan.nb_total, d_fcw, d_fcb, d_probs, d_logits);
+                       plan.nb_total, fine ? fine->rbase : nullptr, fine ? fine->nb_total : 0, d_fcw, d_fcb, d_probs, d_logits);
     RS_HIP(hipGetLastError());
     return RS_OK;
 }

@@ -164,15 +164,18 @@ class Model:
             return int(lmax)
         return nv.lib().rs_padded_length(self._h, int(lmax))
 
-    def block_samples(self) -> int:
-        """Block size U of the packed activation layout (rs_block_samples)."""
+    def block_samples(self, layer: int | None = None) -> int:
+        """Block size of the packed activation layout in samples: of the late layers and the head (rs_block_samples), or,
+        with `layer`, of the layout conv layer `layer` runs on (the early layers use finer blocks: rs_layer_info)."""
         self._need_handle("block_samples")
-        return nv.lib().rs_block_samples(self._h)
+        if layer is None:
+            return nv.lib().rs_block_samples(self._h)
+        return self.layer_info()[layer]["block_samples"]
 
-    def block_bases(self, lens_host) -> np.ndarray:
+    def block_bases(self, lens_host, layer: int | None = None) -> np.ndarray:
         """First block of every read of a batch in the packed layout (+ the total as the last entry): read b's rows
-        in conv layer i's output start at row bases[b] * (U >> (i + 1))."""
-        U = self.block_samples()
+        in conv layer i's output start at row bases[b] * (U >> (i + 1)), U = block_samples(i)."""
+        U = self.block_samples(layer)
         nblk = np.asarray(lens_host, dtype=np.int64) // U + 1
         return np.concatenate([[0], np.cumsum(nblk)]).astype(np.int64)
 

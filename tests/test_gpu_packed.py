@@ -51,6 +51,7 @@ def test_uniform_random_lengths_vs_oracle(dev):
     m = get_model(1, dev)
     U = m.block_samples()
     assert U == 4096 and m.block_bases(lh)[-1] == int((lh // U + 1).sum())
+    assert m.block_samples(3) == 1024 and m.block_bases(lh, 3)[-1] == int((lh // 1024 + 1).sum())
 
 
 @pytest.mark.parametrize("dtype", ["f32w", "f32", "f16", "bf16", "bf16x3", "f16x3"])
@@ -74,6 +75,39 @@ def test_packed_equals_uniform_pitch_bitwise(dev, dtype):
         xs = [ro.mad_normalise(s) for s in sigs]
         unf = m.classify_batch(xs).cpu().numpy()
         assert np.array_equal(unf, packed), np.abs(unf - packed).max()
+
+
+@pytest.mark.parametrize("dtype", ["f32w", "f32", "f16", "bf16", "bf16x3", "f16x3"])
+def test_two_level_layout_equals_one_level_bitwise(dev, dtype):
+    """round 4: conv layers 0-8 run on fine blocks of 1024 samples, layers 9-11 and the head on 4096-sample blocks behind a
+    re-pack of layer 8's output (a live 8615-sample read occupies 9216 samples of rows in the early layers instead of
+    12288).  RS_ONE_LEVEL=1 keeps every layer on the coarse blocks - the round-3 layout.  Identical bits in every mode, with and
+    without the host's lengths, through the fused path, rs_forward and the ensemble entry; lengths at every block edge of
+    either size."""
+    from conftest import hooked_model
+    from riser_amd.model import classify_raw_ensemble
+    lens = np.array([8615, 4096, 4097, 5119, 5120, 5121, 8191, 8192, 8193, 9215, 9216, 12287, 12288, 16000, 6024, 7168, 10240,
+                     16383, 4607], dtype=np.int32)
+    sigs = _reads(lens, 5200)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    two = get_model(2, dev, dtype)
+    one = hooked_model({"RS_ONE_LEVEL": "1"}, synth.make_state_dict(2), dtype, dev)
+    info2, info1 = two.layer_info(), one.layer_info()
+    assert [info2[i]["block_samples"] for i in (1, 8, 9, 11)] == [1024, 1024, 4096, 4096]
+    assert {info1[i]["block_samples"] for i in range(12)} == {4096}
+    want = one.classify_raw(sig, off, ln, lh, return_logits=True)
+    got = two.classify_raw(sig, off, ln, lh, return_logits=True)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (dtype, (got[0] - want[0]).abs().max().item())
+    assert torch.equal(two.classify_raw(sig, off, ln, lh, packed=False), want[0])          # no host lengths: uniform slots
+    if dtype in ("f32w", "f32"):
+        xs = [ro.mad_normalise(s) for s in sigs]
+        assert torch.equal(two.classify_batch(xs), one.classify_batch(xs))                 # rs_forward: plan kernel, conv0 kernel
+    dec2 = torch.empty(len(lens), dtype=torch.uint8, device=dev)
+    dec1 = torch.empty(len(lens), dtype=torch.uint8, device=dev)
+    e2 = classify_raw_ensemble([two, two], sig, off, ln, lh, decision=dec2, max_len=16000)
+    e1 = classify_raw_ensemble([one, one], sig, off, ln, lh, decision=dec1, max_len=16000)
+    assert torch.equal(e2, e1) and torch.equal(dec2, dec1)
+    one.close()
 
 
 def test_ensemble_on_packed_blocks(dev):

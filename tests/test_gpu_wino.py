@@ -118,7 +118,9 @@ def test_wino_layer01_variants_bit_identical(dev):
     from riser_amd.preprocess import pack_reads
     from conftest import hooked_model
     m = get_model(3, dev)
-    m_folded = hooked_model({"RS_NO_STREAM_F32": "1"}, synth.make_state_dict(3), "f32w", dev)
+    # the tiled kernel's fold needs a tile to span at most two blocks: blocks of 4096 samples (one-level layout)
+    m_folded = hooked_model({"RS_NO_STREAM_F32": "1", "RS_ONE_LEVEL": "1"}, synth.make_state_dict(3), "f32w", dev)
+    m_nostream = hooked_model({"RS_NO_STREAM_F32": "1"}, synth.make_state_dict(3), "f32w", dev)   # fine blocks: conv0 + tiled
     for lens in ([16000] * 5, [4096, 16000, 8615, 5000, 12001, 4097, 16383, 9999, 4100]):
         sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=400 + i)[0] for i, n in enumerate(lens)]
         sig, off, ln, lh = pack_reads(sigs, dev)
@@ -128,7 +130,9 @@ def test_wino_layer01_variants_bit_identical(dev):
         folded = m_folded.classify_raw(sig, off, ln, lh).cpu().numpy()
         assert np.array_equal(stream, unfused), np.abs(stream - unfused).max()
         assert np.array_equal(folded, unfused), np.abs(folded - unfused).max()
+        assert np.array_equal(m_nostream.classify_raw(sig, off, ln, lh).cpu().numpy(), unfused)
     m_folded.close()
+    m_nostream.close()
 
 
 @pytest.mark.parametrize("dtype", ["f32w", "f32"])
@@ -148,11 +152,13 @@ def test_layerwise_activations_vs_oracle(dev, dtype):
         x = ro.mad_normalise(s).astype(np.float32)[None, :]
         _, layers = ro.convnet_forward(sd, x, acc=np.float64, return_layers=True)
         want.append(layers)
-    # packed block layout: read b owns the blocks bases[b] .. bases[b + 1] of U samples, U >> (i + 1) rows each
-    U, bases = m.block_samples(), m.block_bases(lens)
-    assert list(np.diff(bases)) == [n // U + 1 for n in lens]
+    # packed block layout: read b owns the blocks bases[b] .. bases[b + 1] of U samples, U >> (i + 1) rows each; two levels:
+    # fine blocks for the early layers, coarse ones for the last three (the buffer captured is the layer's own output)
     info = m.layer_info()
+    assert {info[i]["block_samples"] for i in range(1, 9)} == {1024} and {info[i]["block_samples"] for i in (9, 10, 11)} == {4096}
     for i in range(1, m.n_layers):
+        U, bases = m.block_samples(i), m.block_bases(lens, i)
+        assert list(np.diff(bases)) == [n // U + 1 for n in lens]
         P_out, cp = U >> (i + 1), info[i]["cp_out"]
         cap = torch.full((int(bases[-1]) * P_out, cp), float("nan"), dtype=torch.float32, device=dev)
         nv.check(nv.lib().rs_debug_capture_layer(m._h, i, cap.data_ptr(), cap.numel() * 4), "capture")
@@ -198,8 +204,9 @@ def test_winograd_f43_layers(dev, monkeypatch):
     sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=820 + i)[0] for i, n in enumerate(lens)]
     sig, off, ln, lh = pack_reads(sigs, dev)
     i = 8
-    U, bases = m.block_samples(), m.block_bases(lens)
-    assert U == 8192                                              # F(4,3) on the last layer doubles the block
+    assert m.block_samples() == 8192                              # F(4,3) on the last layer doubles the (coarse) block
+    U, bases = m.block_samples(i), m.block_bases(lens, i)
+    assert U == 1024                                              # ... the early layers keep their fine blocks
     P_out, cp = U >> (i + 1), m.layer_info()[i]["cp_out"]
     cap = torch.full((int(bases[-1]) * P_out, cp), float("nan"), dtype=torch.float32, device=dev)
     nv.check(nv.lib().rs_debug_capture_layer(m._h, i, cap.data_ptr(), cap.numel() * 4), "capture")
