@@ -114,7 +114,7 @@ def spawn_ranks(args, argv):
     """Start N fresh child processes, one rank per GPU, and relay rank 0's JSON line.  The parent makes no GPU
     call (torch.cuda.device_count() does not initialise the runtime on this image)."""
     n = args.gpus
-    if not args.stub:
+    if not args.stub and not os.environ.get("RS_DIST_BACKEND"):          # RS_DIST_BACKEND=gloo: several ranks rehearse on one GPU
         ndev = torch.cuda.device_count()
         if ndev < n:
             raise SystemExit(f"bench.py: --gpus {n} but only {ndev} ROCm device(s) visible")
