@@ -47,12 +47,9 @@ Hooks Hooks::from_env() {
     text("RS_FORCE_SHAPE_F32", h.force_f32, sizeof(h.force_f32));
     text("RS_FORCE_SHAPE_WINO", h.force_wino, sizeof(h.force_wino));
     text("RS_FORCE_SHAPE_WINO4", h.force_wino4, sizeof(h.force_wino4));
-    text("RS_FORCE_SHAPE_H16", h.force_h16, sizeof(h.force_h16));
-    text("RS_H16_PANEL", h.h16_panel, sizeof(h.h16_panel));
     text("RS_FORCE_SHAPE_RING", h.force_ring, sizeof(h.force_ring));
     text("RS_EMU_ROWS", h.emu_rows, sizeof(h.emu_rows));
     if (const char* e = getenv("RS_SMALL_F32_WAVES")) h.small_f32_waves = atoi(e);
-    if (const char* e = getenv("RS_H16_RING")) h.h16_ring = atoi(e) != 0;
     if (const char* e = getenv("RS_H16_WRES")) h.h16_wres = atoi(e) != 0;
     return h;
 }
@@ -516,7 +513,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             rc = upload(&dw, wp);
             L.d_w = dw;
         } else {
-            // 16-bit: panels of 32 input channels, packed [panel][tap][n_alloc][32] (conv_h16.hip, conv_stream_h16.hip)
+            // 16-bit: panels of 32 input channels, packed [panel][tap][n_alloc][32] (conv_stream_h16.hip: layers 1-2)
             const int st16 = base16(dtype);
             const bool x3 = is_x3(dtype);
             ConvPlan& p = L.plan;
@@ -524,7 +521,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             p.nch = (L.c_in + 31) / 32;
             // rows of the packed weight / bias tables: the channels (split precision: all 32 slots of the last panel,
             // every one of which a tile covers) plus zero rows for the widest tile's overhang
-            p.n_alloc = (x3 ? 32 * ((L.c_out + 31) / 32) : round_up(L.c_out, 16)) + std::max(conv_h16_max_bn(), conv_ring_max_bn());
+            p.n_alloc = (x3 ? 32 * ((L.c_out + 31) / 32) : round_up(L.c_out, 16)) + conv_ring_max_bn();
             if (!x3) {
                 p.nch = (L.cp_in + 31) / 32;
                 std::vector<unsigned short> wp((size_t)p.nch * 3 * p.n_alloc * 32, 0);
@@ -542,7 +539,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             // ring packing [panel][tap][n_alloc][64] (conv_ring_h16.hip): a panel is 64 input channels, or 32 input
             // channels as [hi x 32 | lo x 32] with lo = round(w - hi) in split precision
             L.ring_panels = x3 ? (L.c_in + 31) / 32 : (L.cp_in + 63) / 64;
-            if (rc == RS_OK && (x3 || m->hooks.h16_ring)) {
+            if (rc == RS_OK) {
                 std::vector<unsigned short> wr((size_t)L.ring_panels * 3 * p.n_alloc * 64, 0);
                 for (int n = 0; n < L.c_out; ++n)
                     for (int ci = 0; ci < L.c_in; ++ci)
@@ -803,8 +800,9 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         // kind of kernel this layer runs: 0 streaming (not tuned), 1 F(4,3), 2 F(2,3), 3 direct fp32, 4 tiled 16-bit
         const bool stream32 = i == 1 && stream32_l1;
         const bool stream16 = (is16 || x3) && i <= 2 && conv_stream_h16_ok(L, P_in);
-        // split precision runs the LDS-DMA ring kernel on every layer, plain 16-bit on its tiled layers with RS_H16_RING
-        const bool ring = !stream16 && (x3 || (is16 && m->hooks.h16_ring && L.d_w2));
+        // every tiled 16-bit layer runs the LDS-DMA ring kernel (the register-staged kernel of round 1, conv_h16.hip, was its
+        // bit-for-bit cross-check through round 3 and has been removed)
+        const bool ring = !stream16 && (x3 || is16);
         // ... and narrow layers whose whole weight tensor fits LDS next to two activation slabs on the weights-resident kernel
         const bool wres = ring && conv_wres_h16_ok(L, x3);
         // fp32 Winograd layers of a launch with only a handful of rows (Model.classify at batch 1, a thin ReadUntil batch):
@@ -859,20 +857,21 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
             else if (ring)
                 rc = launch_conv_ring_h16(L, buf[cur], buf[cur ^ 1], d_blen, NB, P_in, i, m->num_cu, f16, x3, check_dead, st,
                                           &m->last_bm[i], &m->last_bn[i]);
-            else
-                rc = launch_conv_h16(L, buf[cur], buf[cur ^ 1], d_blen, NB, P_in, i, m->num_cu, m->d_zero,
-                                     f16, check_dead, st, &m->last_bm[i], &m->last_bn[i]);
+            else {
+                set_error("no kernel for layer %d in this mode", i);
+                rc = RS_ERR_ARG;
+            }
             return rc;
         };
-        if (m->tuning && (kind == 1 || kind == 2 || kind == 4 || kind == 5)) {
+        if (m->tuning && (kind == 1 || kind == 2 || kind == 5)) {
             // rs_autotune: every feasible entry of the kernel's shape table on THIS layer's real input (the buffers hold the
             // activations of the batch; re-running a layer rewrites the same output), 1 warm + 3 timed launches each;
             // a shape replaces the planner's choice only if it is > 3 % faster
             const int n = kind == 1 ? conv_wino4_num_shapes() : kind == 2 ? conv_wino_num_shapes()
-                        : kind == 5 ? conv_ring_num_shapes() : conv_h16_num_shapes();
+                        : conv_ring_num_shapes();
             auto ok = [&](int k) {
                 return kind == 1 ? conv_wino4_shape_ok(L, k) : kind == 2 ? conv_wino_shape_ok(L, k)
-                     : kind == 5 ? conv_ring_shape_ok(L, k) : conv_h16_shape_ok(L, k);
+                     : conv_ring_shape_ok(L, k);
             };
             hipEvent_t e0, e1;
             RS_HIP(hipEventCreate(&e0));

@@ -67,11 +67,8 @@ struct Hooks {
     char force_f32[256] = "";        // RS_FORCE_SHAPE_F32 / _WINO / _WINO4 / _H16: "layer:wm,wn,mt,nt;..."
     char force_wino[256] = "";
     char force_wino4[256] = "";
-    char force_h16[256] = "";
     char force_ring[256] = "";       // RS_FORCE_SHAPE_RING
-    char h16_panel[128] = "";        // RS_H16_PANEL: "64" or "layer:64;..."
     char emu_rows[128] = "";         // RS_EMU_ROWS "layer:permille;...": TIMING ONLY - the layer runs on that share of the batch's blocks
-    bool h16_ring = true;            // RS_H16_RING=0: plain 16-bit tiled layers on conv_h16.hip instead of the LDS-DMA ring kernel
     bool h16_wres = true;            // RS_H16_WRES=0: narrow 16-bit layers on the ring kernel instead of the weights-resident one
     static Hooks from_env();
 };
@@ -151,9 +148,6 @@ inline int tuned_shape(const ConvLayerDev& L, int64_t rows) {
 int launch_conv_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len,
                     int B, int P_in, int layer_index, int num_cu, const float* d_zero, int check_dead,
                     hipStream_t st, int* bm_out, int* bn_out);
-int launch_conv_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
-                    int layer_index, int num_cu, const void* d_zero, bool f16, int check_dead, hipStream_t st,
-                    int* bm_out, int* bn_out);
 int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len,
                      int B, int P_in, int layer_index, int num_cu, const float* d_zero, int check_dead,
                      hipStream_t st, int* bm_out, int* bn_out, const float* fuse_xs = nullptr,
@@ -198,15 +192,12 @@ int launch_conv_wres_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
 int conv_ring_max_bn();
 int conv_ring_num_shapes();
 bool conv_ring_shape_ok(const ConvLayerDev& L, int k);
-int conv_h16_max_bn();
 int conv_f32_max_bn();
 // tile-shape tables of the tiled kernels (rs_autotune): number of entries, and whether entry k can run layer L
 int conv_wino_num_shapes();
 bool conv_wino_shape_ok(const ConvLayerDev& L, int k);
 int conv_wino4_num_shapes();
 bool conv_wino4_shape_ok(const ConvLayerDev& L, int k);
-int conv_h16_num_shapes();                      // shape index + table size * (panel of 64 ? 1 : 0)
-bool conv_h16_shape_ok(const ConvLayerDev& L, int k);
 int conv_f32_kc_max();
 
 // rows of read b: (rbase[b] * P_last) + t, t < len[b] >> n_layers (P_last = rows per block of the last buffer)

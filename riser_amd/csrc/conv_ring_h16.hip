@@ -4,7 +4,7 @@
 //
 //   Conv1d(C_in -> C_out, k=3, 'same', bias) -> ReLU -> MaxPool1d(2,2)   (riser/nets/cnn.py:52-65)
 //
-// Same lowering as conv_h16.hip (position-major activations, GEMM M = positions, N = output channels, K = 3 * C_in,
+// Same lowering as the round-1 register-staged 16-bit kernel (removed in round 4) (position-major activations, GEMM M = positions, N = output channels, K = 3 * C_in,
 // bias + ReLU + MaxPool fused in registers) with the staging rebuilt around LDS-DMA:
 //   * an LDS row is 128 bytes = one PANEL of one position / output channel: 64 input channels (plain), or 32 input
 //     channels as [hi x 32 | lo x 32] (x3).  The x3 activation buffers and the weights are laid out in HBM in exactly
@@ -22,7 +22,7 @@
 //     s_waitcnt vmcnt(0) + s_barrier - no counted waits, no register staging, no LDS writes by the waves;
 //   * the tile's bias / length look-ups are loaded when the tile starts and consumed right after a sub-stage's barrier,
 //     when the vector-memory queue is empty, so the compiler's own wait for them costs nothing.
-// The accumulation order over K is panel -> tap -> half, identical to conv_h16.hip with 64-channel panels: plain-mode
+// The accumulation order over K is panel -> tap -> half, identical to the round-1 kernel with 64-channel panels: plain-mode
 // results are bit-identical to that kernel.
 #include "common.hpp"
 #include "tile_walk.hpp"
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- tile walk (tile_walk.hpp) with dead-tile elimination, as in conv_h16.hip -----------------------------
+    // ---- tile walk (tile_walk.hpp) with dead-tile elimination, as in the fp32 tiled kernels -----------------------------
     const int tiles = a.walk.q_total;
     const int P_in_ = 2 * a.P_out;
     auto tile_origin = [&](int q, int& tm0, int& tn0) -> bool {

@@ -1,4 +1,4 @@
-// Persistent tile walk shared by the tiled conv kernels (conv_f32 / conv_wino / conv_wino4 / conv_h16).
+// Persistent tile walk shared by the tiled conv kernels (conv_f32 / conv_wino / conv_wino4 / conv_ring_h16).
 //
 // A launch has n_mtiles x n_ntiles output tiles and (at most) one workgroup per CU.  Round k of the walk gives
 // workgroup w the ORDER INDEX k * nwg + block(w) + slot_k(w), where block(w) is the contiguous range of nwg / 8

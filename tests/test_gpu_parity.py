@@ -550,19 +550,9 @@ def test_full_size_batch_properties(dev):
         assert np.array_equal(want_bits, mo.classify_raw(sig, off, ln, lens).cpu().numpy()), dt
         mo.close()
     md.close()
-    # (f) the three 16-bit tiled implementations: the LDS-DMA ring kernel (default: conv_ring_h16.hip, 64-channel
-    # panels) must reproduce the register-staged kernel conv_h16.hip with 64-channel panels BIT FOR BIT (same MFMA
-    # sequence per accumulator); conv_h16.hip with 32-channel panels accumulates in another order: same probabilities
-    # to fp32-accumulation round-off
-    mw = hooked_model({"RS_H16_PANEL": "64", "RS_H16_RING": "0"}, synth.make_state_dict(1), "f16", dev)
-    assert np.array_equal(half, mw.classify_raw(sig, off, ln, lens).cpu().numpy())
-    mw.close()
-    mw = hooked_model({"RS_H16_RING": "0"}, synth.make_state_dict(1), "f16", dev)
-    wide = mw.classify_raw(sig, off, ln, lens).cpu().numpy()
-    mw.close()
-    # (activations are re-rounded to 16 bits after every layer, so round-off differences are amplified to the 16-bit
-    # path's own distance from fp32, ~7e-3)
-    assert np.abs(wide - half).max() < 1e-2
-    assert np.abs(wide - full).max() < 2e-2 and np.abs(half - full).max() < 2e-2
+    # (f) the 16-bit path against fp32 and the oracle (the ring kernel's bit-for-bit cross-check against the round-1
+    # register-staged kernel ran through round 3; that kernel is gone, the weights-resident kernel is checked against the
+    # ring kernel in test_gpu_packed.py)
+    assert np.abs(half - full).max() < 2e-2
     assert np.abs(half[pick] - want).max() < 2e-2
     mh.close()

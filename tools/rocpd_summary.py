@@ -46,7 +46,7 @@ def pmc(fdb, wdb, steps):
         hbm = (2.0 * fk + wk) * 1024.0 * per_step
         out["kernels"][k] = {"launches_per_step": round(per_step, 2), "fetch_kb_raw": round(fk, 1),
                              "write_kb": round(wk, 1), "hbm_bytes_per_step": int(hbm)}
-        if k.startswith(("conv_wino_kernel", "conv_wino4_kernel", "conv_f32_kernel", "conv_h16_kernel", "conv_stream_")):
+        if k.startswith(("conv_wino_kernel", "conv_wino4_kernel", "conv_f32_kernel", "conv_ring_h16_kernel", "conv_wres_h16_kernel", "conv_small_f32_kernel", "conv_stream_")):
             total += hbm
     out["conv_stack_hbm_bytes_per_step"] = int(total)
     print(json.dumps(out, indent=1))

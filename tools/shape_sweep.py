@@ -21,7 +21,7 @@ dev = torch.device("cuda", 0)
 sig, off, ln, lens = pack_reads(list(sigs), dev)
 m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=DT)
 RING = [(8,1,2,2),(8,1,2,3),(8,1,2,5),(8,1,2,7),(8,1,4,2),(8,1,4,3),(8,1,4,4),(4,2,4,3),(4,2,4,4),(4,2,4,5),(4,2,4,6),(4,2,2,4),(4,2,2,6),(2,4,4,4),(2,4,2,4),(2,4,4,3)]
-IS_RING = DT in ("bf16x3", "f16x3") or os.environ.get("RS_H16_RING")
+IS_RING = DT in ("bf16x3", "f16x3", "f16", "bf16")     # every tiled 16-bit layer runs the ring kernel
 if DT == "f32w": shapes = WINO4 if W4 else WINO
 if IS_RING: shapes = RING
 ROWMUL = 4 if W4 else 2 if DT == "f32w" else 1
@@ -37,7 +37,7 @@ def run():
 base, info = run()
 print("B", B, "default:", " ".join("L%d[%dx%d]=%.3f" % (i, info[i]["bm"], info[i]["bn"], base[1 + i]) for i in layers))
 for sh in shapes:
-    os.environ["RS_FORCE_SHAPE_RING" if IS_RING else "RS_FORCE_SHAPE_WINO4" if W4 else "RS_FORCE_SHAPE_WINO" if DT == "f32w" else "RS_FORCE_SHAPE_H16" if DT in ("f16", "bf16") else "RS_FORCE_SHAPE_F32"] = ";".join("%d:%d,%d,%d,%d" % ((l,) + sh) for l in layers)
+    os.environ["RS_FORCE_SHAPE_RING" if IS_RING else "RS_FORCE_SHAPE_WINO4" if W4 else "RS_FORCE_SHAPE_WINO" if DT == "f32w" else "RS_FORCE_SHAPE_F32"] = ";".join("%d:%d,%d,%d,%d" % ((l,) + sh) for l in layers)
     ms, info = run()
     bm, bn = sh[0]*16*sh[2]*ROWMUL, sh[1]*16*sh[3]
     print("%-12s %4dx%-4d" % (sh, bm, bn), " ".join(("L%d=%.3f" % (i, ms[1 + i])) if (info[i]["bm"], info[i]["bn"]) == (bm, bn) else ("L%d=  -  " % i) for i in layers))
