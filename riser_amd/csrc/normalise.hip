@@ -36,6 +36,7 @@ constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int kBins = 4096;            // 8 bins per thread
 constexpr int kSubBins = 32;           // refinement pass: keys < 2^17 -> shift <= 5
+constexpr int kHeadCap = 1024;         // outlier-run heads listed in LDS per read (more: the walk scans the read instead)
 
 struct Scratch {
     int wave_tot[kWaves];
@@ -47,7 +48,7 @@ struct Scratch {
     int result[2];
     unsigned sub[2][kSubBins];
     int dthr;
-    int pad_;
+    int n_heads;                       // outlier runs found by the output pass
     double denom;
 };
 
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
             while (!(((double)d * 0.5) / denom > 3.5)) ++d;
             sc->denom = denom;
             sc->dthr = (int)(d > 0x7fffffffLL ? 0x7fffffffLL : d);
+            sc->n_heads = 0;
         }
         __syncthreads();
         const double denom = sc->denom;
@@ -394,16 +396,14 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
             __syncthreads();
         }
         RS_K1_STAMP(6);
-        for (int i = tid; i < n; i += kThreads) {
-            const int t = dev2(i);
-            if (abs(t) < dthr) {
-                if (use_lut)
-                    o32[i] = lut[t + dthr];
-                else
-                    put(i, ((double)t * 0.5) / denom);
-                continue;
-            }
-            if (i > 0 && abs(dev2(i - 1)) >= dthr) continue;     // inside a run: its head writes it
+        // Pass 1, every sample: non-outliers are written (look-up or division), the FIRST sample of each run of
+        // consecutive outliers is listed in LDS.  Pass 2, one lane per listed run: the sequential recurrence of
+        // riser/preprocess.py:128-147 along the run.  (Through round 3 the run walk sat inside the sample loop: a
+        // wave paid for it on every iteration in which one of its 64 samples opened a run - a quarter of the
+        // iterations on nanopore-like data - and the loop could not be pipelined around the divergent walk.)
+        int* heads = reinterpret_cast<int*>(sx0 + ((lmax + 15) & ~7));
+        auto is_head = [&](int i) { return i == 0 || abs(dev2(i - 1)) < dthr; };
+        auto walk = [&](int i) {
             double prev = i > 0 ? yv(i - 1) : 0.0;
             int j = i;
             do {
@@ -420,6 +420,55 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
                 prev = nv;
                 ++j;
             } while (j < n && abs(dev2(j)) >= dthr);
+        };
+        auto list_head = [&](int i) {
+            if (is_head(i)) {
+                const int slot = atomicAdd(&sc->n_heads, 1);
+                if (slot < kHeadCap) heads[slot] = i;
+            }
+        };
+        if (use_lut) {
+            const int top = 2 * dthr - 1;
+            int i = tid;
+            for (; i + 3 * kThreads < n; i += 4 * kThreads) {    // four samples in flight per lane
+                int t[4];
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = dev2(i + u * kThreads);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = lut[min(max(t[u] + dthr, 0), top)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (abs(t[u]) < dthr)
+                        o32[i + u * kThreads] = v[u];
+                    else
+                        list_head(i + u * kThreads);
+                }
+            }
+            for (; i < n; i += kThreads) {
+                const int t = dev2(i);
+                if (abs(t) < dthr)
+                    o32[i] = lut[t + dthr];
+                else
+                    list_head(i);
+            }
+        } else {
+            for (int i = tid; i < n; i += kThreads) {
+                const int t = dev2(i);
+                if (abs(t) < dthr)
+                    put(i, ((double)t * 0.5) / denom);
+                else
+                    list_head(i);
+            }
+        }
+        __syncthreads();
+        RS_K1_STAMP(9);
+        const int nh = sc->n_heads;
+        if (nh <= kHeadCap) {
+            for (int k = tid; k < nh; k += kThreads) walk(heads[k]);
+        } else {                                                 // more runs than the list holds: find them again
+            for (int i = tid; i < n; i += kThreads)
+                if (abs(dev2(i)) >= dthr && is_head(i)) walk(i);
         }
     }
     RS_K1_STAMP(7);
@@ -445,7 +494,7 @@ int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* 
         set_error("rs_normalise: read length %d outside [1, %d]", Lmax, kMaxNormLen);
         return RS_ERR_LENGTH;
     }
-    const size_t lds = (size_t)kBins * 4 + 512 + (size_t)round_up(Lmax + 8, 8) * 2;
+    const size_t lds = (size_t)kBins * 4 + 512 + (size_t)round_up(Lmax + 8, 8) * 2 + (size_t)kHeadCap * 4;
     // the > 64 KiB dynamic-LDS limit is a per-DEVICE function attribute: raise it once on every device that
     // launches the kernel (a process may hold models on several GPUs)
     static std::atomic<bool> attr_set[kMaxDevices];
@@ -465,8 +514,8 @@ int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* 
         unsigned long long h[16];
         RS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_k1_stamps), sizeof(h)));
         fprintf(stderr, "[k1-stamps] B %d Lmax %d cycles: plan %llu | stage+minmax %llu | median %llu | mad %llu | thr %llu | lut %llu | "
-                "normalise+smooth %llu | pad %llu | total %llu\n", B, Lmax, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3],
-                h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[8] - h[0]);
+                "normalise %llu + run walk %llu | pad %llu | total %llu\n", B, Lmax, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3],
+                h[5] - h[4], h[6] - h[5], h[9] - h[6], h[7] - h[9], h[8] - h[7], h[8] - h[0]);
     }
 #endif
     return RS_OK;
