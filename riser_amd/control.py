@@ -189,6 +189,7 @@ class _SignalStore:
         self.mismatches = 0                                      # candidates whose overlap did not match (uploaded whole)
         self.auto_off = False
         self._bad_streak = 0
+        self._uploaded = None                                    # event: the last slice's staging has been read by its copy
 
     def reserve(self, rows: int, samples: int):
         """device rows / pinned staging for batches of up to `rows` reads carrying up to `samples` new samples"""
@@ -269,19 +270,23 @@ class _SignalStore:
 
     def update(self, channels: np.ndarray, batch: _Batch, pinned: _Pinned) -> np.ndarray:
         """One slice of a batch (the whole batch, for all but PromethION-scale ones) -> int64 [B]: offset of every read's
-        first sample in self.buf.  Copies and launches go to the CURRENT stream, which is synchronised first: the staging
-        buffers are re-used from slice to slice."""
+        first sample in self.buf.  Copies and launches go to the CURRENT stream.  The pinned staging is re-used from slice to
+        slice: the host waits for the previous slice's transfer (an event, not the stream - the stream may hold that slice's
+        poly(A) scan, which the caller wants to overlap with this staging)."""
         lens = batch.lens
         B = lens.shape[0]
         presented = int(lens.sum())
         self.samples_presented += presented
-        torch.cuda.current_stream(self.device).synchronize()
+        if self._uploaded is None:
+            self._uploaded = torch.cuda.Event()
+        self._uploaded.synchronize()
         if not self.resident:
             offs = np.zeros(B, dtype=np.int64)
             np.cumsum(lens[:-1], out=offs[1:])
             offs += self._spill_at
             total = batch.stage(np.zeros(B, dtype=np.int64), self._stage(presented))
             self.buf[self._spill_at: self._spill_at + total].copy_(self.stage[:total], non_blocking=True)
+            self._uploaded.record(torch.cuda.current_stream(self.device))
             self._spill_at += total
             self.samples_uploaded += total
             return offs
@@ -330,6 +335,7 @@ class _SignalStore:
         self.samples_uploaded += total
         if total:
             self.stage_dev[:total].copy_(self.stage[:total], non_blocking=True)
+            self._uploaded.record(torch.cuda.current_stream(self.device))
             live = np.flatnonzero(seg_len > 0)
             d_src = pinned.to_device(np.ascontiguousarray(src[live]))
             d_dst = pinned.to_device(np.ascontiguousarray(dst[live]))
@@ -374,7 +380,8 @@ class SequencerControl:
         self.batch_phases = deque(maxlen=4096)
         self._store = _SignalStore(processor.device, resident=signal_cache, logger=logger)
         self._pinned = _Pinned(processor.device)
-        self._res_probs = self._res_dec = None
+        self._res_probs = self._res_dec = self._polya_host = None
+        self._pa_events = []                      # one per slice: the poly(A) scan's result is in pinned memory
         self._side, self._events = None, []       # PromethION-scale batches: the upload / poly(A) stream of the slice pipeline
         self._channels_seen = 0
         self._reserved_for = 0
@@ -404,6 +411,7 @@ class SequencerControl:
                                     torch.empty((n_models, cap, 2), dtype=torch.float32).pin_memory())
             self._res_dec = _Pair(torch.empty(cap, dtype=torch.uint8, device=dev),
                                   torch.empty(cap, dtype=torch.uint8).pin_memory())
+            self._polya_host = torch.empty(cap, dtype=torch.int32).pin_memory()
 
     SLICE_READS = 4096          # a batch of more than 1.5 x this many reads is assessed in slices of about this size
 
@@ -448,58 +456,83 @@ class SequencerControl:
         n_models = len(self.models)
         self._result_buffers(B)
         flat_p, flat_d = self._res_probs.dev.view(-1), self._res_dec.dev
-        parts, keep, n_total = [], [], 0
-        for k in range(n_slices):
+        parts, n_total = [], 0
+        pa_host = self._polya_host
+        while len(self._pa_events) < n_slices:
+            self._pa_events.append(torch.cuda.Event())
+
+        def upload_and_scan(k):
+            """slice k: its new samples to the device rows, the poly(A) scan of its reads not in the cache launched, the
+            scan's result on its way to pinned memory - nothing here waits for the device"""
+            nonlocal t
             lo, hi = bounds[k], bounds[k + 1]
             part = batch.view(lo, hi)
-            ids, lens = part.ids, part.lens
             with torch.cuda.stream(side):
                 offs = store.update(channels[lo:hi], part, self._pinned)
-                sig = store.buf
+                if side is not caller:
+                    self._events[k].record(side)            # the slice's samples are in the rows behind this point
                 t, dt = self._tick(t, 1)
                 ph[1] += dt
-                # -- poly(A) end for reads not in the cache: one launch -------------------------------
                 if polyA_cache:
                     cget = polyA_cache.get
-                    end = np.fromiter((cget(i, 0) for i in ids), dtype=np.int64, count=hi - lo)
+                    end = np.fromiter((cget(i, 0) for i in part.ids), dtype=np.int64, count=hi - lo)
                 else:
                     end = np.zeros(hi - lo, dtype=np.int64)
                 need = np.flatnonzero(end == 0)
-                if need.size:
+                found_h = found_d = None
+                if need.size:                                   # one launch for every read without a known end
                     d_off = self._pinned.to_device(np.ascontiguousarray(offs[need]))
-                    d_len = self._pinned.to_device(lens[need].astype(np.int32))
-                    found = proc.polyA_end_device(sig, d_off, d_len, int(need.size)).cpu().numpy().astype(np.int64)
-                    hit = np.flatnonzero(found > 0)
-                    end[need[hit]] = found[hit]
-                    polyA_cache.update(zip(ids[need[hit]].tolist(), found[hit].tolist()))
-                t, dt = self._tick(t, 2)
-                ph[2] += dt
-                # -- gating (riser/control.py:36-60) as offsets / lengths ------------------------------
-                has = end > 0
-                start = np.where(has, end + 1, fixed)
-                length = lens - start
-                ok = np.where(has, length >= min_len, lens > fixed + max_len)   # :53-56 / should_trim_fixed_length :39-50
-                sel = np.flatnonzero(ok)
-                if sel.size == 0:
-                    continue
-                lens_a = np.minimum(length[sel], max_len).astype(np.int32)
-                off_d = self._pinned.to_device(np.ascontiguousarray(offs[sel] + start[sel]))
-                len_d = self._pinned.to_device(lens_a)
-                if side is not caller:
-                    self._events[k].record(side)
+                    d_len = self._pinned.to_device(part.lens[need].astype(np.int32))
+                    found_d = proc.polyA_end_device(store.buf, d_off, d_len, int(need.size))
+                    found_h = pa_host[lo: lo + need.size]
+                    found_h.copy_(found_d, non_blocking=True)
+                    self._pa_events[k].record(side)
+            return part, offs, end, need, found_h, found_d
+
+        def gate_and_classify(k, staged):
+            nonlocal t, n_total
+            lo = bounds[k]
+            part, offs, end, need, found_h, _found_d = staged
+            ids, lens = part.ids, part.lens
+            if need.size:
+                self._pa_events[k].synchronize()
+                found = found_h.numpy().astype(np.int64)
+                hit = np.flatnonzero(found > 0)
+                end[need[hit]] = found[hit]
+                polyA_cache.update(zip(ids[need[hit]].tolist(), found[hit].tolist()))
+            t, dt = self._tick(t, 2)
+            ph[2] += dt
+            # -- gating (riser/control.py:36-60) as offsets / lengths ------------------------------
+            has = end > 0
+            start = np.where(has, end + 1, fixed)
+            length = lens - start
+            ok = np.where(has, length >= min_len, lens > fixed + max_len)   # :53-56 / should_trim_fixed_length :39-50
+            sel = np.flatnonzero(ok)
+            if sel.size == 0:
+                return
+            lens_a = np.minimum(length[sel], max_len).astype(np.int32)
+            off_d = self._pinned.to_device(np.ascontiguousarray(offs[sel] + start[sel]))
+            len_d = self._pinned.to_device(lens_a)
             if side is not caller:
                 caller.wait_event(self._events[k])
             # -- normalise once, one batched forward per model, decision on the device -------------
             n_sel = int(sel.size)
             probs_d = flat_p[n_models * 2 * n_total: n_models * 2 * (n_total + n_sel)].view(n_models, n_sel, 2)
             dec_d = flat_d[n_total: n_total + n_sel]
-            classify_raw_ensemble(self.models, sig, off_d, len_d, lens_a, out=probs_d, decision=dec_d, max_len=max_len,
+            classify_raw_ensemble(self.models, store.buf, off_d, len_d, lens_a, out=probs_d, decision=dec_d, max_len=max_len,
                                   threshold=threshold, mode=_MODE[mode])
-            keep.append((off_d, len_d))                 # allocated on the side stream, read on the caller's: alive until the end
             parts.append((lo + sel, lens_a, n_total, n_sel))
             n_total += n_sel
             t, dt = self._tick(t, 3)
             ph[3] += dt
+
+        # slice k + 1 is staged, uploaded and scanned BEFORE the host waits for slice k's scan: the wait has the next
+        # slice's host work in front of it, and the classification of slice k runs under the staging of slice k + 2
+        staged = upload_and_scan(0)
+        for k in range(n_slices):
+            ahead = upload_and_scan(k + 1) if k + 1 < n_slices else None
+            gate_and_classify(k, staged)
+            staged = ahead
         store.end_batch()
         if n_total == 0:
             if side is not caller:
@@ -512,7 +545,6 @@ class SequencerControl:
         caller.synchronize()
         if side is not caller:
             side.synchronize()
-        del keep
         pn, dn = probs_h.numpy(), dec_h.numpy()
         p_on = np.empty((n_total, n_models), dtype=np.float64)                              # [read][model]
         for _, _, at, n in parts:

@@ -1,9 +1,14 @@
 // poly(A) end detector (riser/preprocess.py:42-79) for a batch of raw reads.
-// One 256-thread workgroup per read.  Each wave takes every 4th 500-sample window, sorts
-// it (bitonic, 512 int keys in LDS, padded with +inf) to get the exact median, sorts the
-// integer deviations |2x - 2med| to get the exact MAD, and records the window sum; one
-// lane then replays the reference's sequential start/end rule over the window table in
-// fp64 with the reference's operation order.  No length limit: the table is filled in passes.
+// One 256-thread workgroup per read.  Each wave takes every 4th 500-sample window and needs its exact median and MAD:
+//   * the window is sorted IN REGISTERS: 512 keys (500 samples + 12 x +inf), 8 per lane, a bitonic network whose
+//     exchanges at distance < 8 stay inside the lane and whose 21 longer ones are lane permutes - no LDS traffic and no
+//     barrier inside the sort (round 1-3 sorted 512 keys in LDS with a workgroup barrier per stage, twice per window);
+//   * the MAD needs no second sort: the deviations |x - med| along the SORTED window fall to the median and rise again,
+//     so "at least k + 1 deviations <= d" holds exactly when some run of k + 1 consecutive sorted samples has both of its
+//     END points within d:  D_k = min_i max(dev(K[i]), dev(K[i + k])) - 251 candidates, four per lane, one wave minimum;
+//   * the window sum rides along.
+// One lane then replays the reference's sequential start/end rule over the window table in fp64 with the reference's
+// operation order.  No length limit: the table is filled in passes.
 #include "common.hpp"
 
 namespace rs {
@@ -13,23 +18,56 @@ constexpr int kWin = 500;                          // _TRIM_RESOLUTION
 constexpr int kChunkWin = 128;                     // windows per pass over the table (64000 samples)
 constexpr int kPad = 0x7fffffff;
 
-__device__ __forceinline__ void bitonic512(int* keys, int lane) {
-    for (int k = 2; k <= 512; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+__device__ __forceinline__ void cmpx(int& lo, int& hi) {        // ascending compare-exchange of two registers
+    const int a = lo, b = hi;
+    lo = min(a, b);
+    hi = max(a, b);
+}
+
+// the sub-steps of a merge that stay inside a lane: partners at element distance J = 4, 2, 1
+template <int J>
+__device__ __forceinline__ void lane_steps(int (&v)[8]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int p = lane + 64 * u;
-                const int i = 2 * p - (p & (j - 1));
-                const int q = i + j;
-                const int a = keys[i], b = keys[q];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    keys[i] = b;
-                    keys[q] = a;
-                }
-            }
-            __syncthreads();
+    for (int r = 0; r < 8; ++r)
+        if ((r & J) == 0) cmpx(v[r], v[r ^ J]);
+    if constexpr (J > 1) lane_steps<J / 2>(v);
+}
+
+// Ascending bitonic sort of 512 keys held as element e = 8 * lane + r.  Every merge of block size k starts with the
+// "flip" (e <-> e ^ (k - 1): the block's second half reversed), then halves the distance; all exchanges are ascending
+// (the lower element keeps the minimum), so no per-block direction is needed.
+__device__ __forceinline__ void sort512(int (&v)[8], int lane) {
+    // k = 2, 4, 8: inside the lane
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) cmpx(v[r], v[r + 1]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if ((r & 2) == 0) cmpx(v[r], v[r ^ 3]);
+    lane_steps<1>(v);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cmpx(v[r], v[7 - r]);
+    lane_steps<2>(v);
+    // k = 16 ... 512: d = k / 8 lanes per block
+#pragma unroll
+    for (int d = 2; d <= 64; d <<= 1) {
+        {   // flip: partner lane ^ (d - 1), its register 7 - r
+            const bool lower = (lane & (d >> 1)) == 0;
+            int p[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) p[r] = __shfl_xor(v[7 - r], d - 1, 64);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = lower ? min(v[r], p[r]) : max(v[r], p[r]);
         }
+#pragma unroll
+        for (int dl = d >> 2; dl >= 1; dl >>= 1) {            // partner lane ^ dl, same register
+            const bool lower = (lane & dl) == 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int q = __shfl_xor(v[r], dl, 64);
+                v[r] = lower ? min(v[r], q) : max(v[r], q);
+            }
+        }
+        lane_steps<4>(v);
     }
 }
 
@@ -60,37 +98,47 @@ __global__ __launch_bounds__(256) void polya_kernel(const int16_t* __restrict__ 
             const int wl = w0 + wave;                              // window of this wave inside the pass
             const bool act = wl < cn;
             const int16_t* wsrc = src + (int64_t)(c0 + wl) * kWin;
+            int v[8];
             int s = 0;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = lane + 64 * u;
-                int v = kPad;
+                const int i = 8 * lane + u;
+                v[u] = kPad;
                 if (act && i < kWin) {
-                    v = wsrc[i];
-                    s += v;
+                    v[u] = wsrc[i];
+                    s += v[u];
                 }
-                K[i] = v;
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-            __syncthreads();
-            bitonic512(K, lane);
-            const int sum2 = K[kWin / 2 - 1] + K[kWin / 2];            // 2 * median
-            __syncthreads();
+            sort512(v, lane);
+            // K is this wave's own array: its LDS accesses execute in program order, no barrier between the store of the
+            // sorted keys and the look-ups below (or the previous window's look-ups and this store)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 8; ++u) K[8 * lane + u] = v[u];
+            __builtin_amdgcn_wave_barrier();
+            const int sum2 = K[kWin / 2 - 1] + K[kWin / 2];                // 2 * median
+            int d_lo = kPad, d_hi = kPad;                                  // order statistics kWin/2 - 1 and kWin/2 of |2x - 2 med|
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
                 const int i = lane + 64 * u;
-                const int v = K[i];
-                K[i] = (v == kPad) ? kPad : abs(2 * v - sum2);
+                if (i + kWin / 2 - 1 < kWin) {
+                    const int a = abs(2 * K[i] - sum2);
+                    d_lo = min(d_lo, max(a, abs(2 * K[i + kWin / 2 - 1] - sum2)));
+                    if (i + kWin / 2 < kWin) d_hi = min(d_hi, max(a, abs(2 * K[i + kWin / 2] - sum2)));
+                }
             }
-            __syncthreads();
-            bitonic512(K, lane);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                d_lo = min(d_lo, __shfl_xor(d_lo, d, 64));
+                d_hi = min(d_hi, __shfl_xor(d_hi, d, 64));
+            }
             if (act && lane == 0) {
                 wsum[2 + wl] = s;
-                wmad4[wl] = K[kWin / 2 - 1] + K[kWin / 2];              // 4 * MAD
+                wmad4[wl] = d_lo + d_hi;                                   // 4 * MAD
             }
-            __syncthreads();
         }
+        __syncthreads();
         if (tid == 0) {
             int start = state[0], end = state[1];
             for (int wl = 0; wl < cn && end <= 0; ++wl) {
