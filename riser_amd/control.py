@@ -108,6 +108,17 @@ class _Pinned:
         return host.to(self.device, non_blocking=True)
 
 
+def _object_array(items: list) -> np.ndarray:
+    """list -> 1-D object array (np.array would make a 2-D array of a list of equal-length tuples)"""
+    out = np.empty(len(items), dtype=object)
+    if items and type(items[0]) is str:
+        out[:] = items
+    else:
+        for i, v in enumerate(items):
+            out[i] = v
+    return out
+
+
 class _Batch:
     """The reads of one ReadUntil batch, as the store sees them: ids, lengths and a way to stage `raw[start:]` of every
     read back to back.  Two implementations of the per-read walk: the client's own get_raw_signal (the eight-method duck
@@ -116,7 +127,8 @@ class _Batch:
     def __init__(self, client, reads):
         self.reads = reads
         B = len(reads)
-        self.ids = np.fromiter((r.id for r in reads), dtype=object, count=B)
+        self.ids = _object_array(_hp.attrs(reads, "id")) if _hp is not None and type(reads) is list else \
+            np.fromiter((r.id for r in reads), dtype=object, count=B)
         declared = getattr(client, "raw_data_dtype", None)
         self.native = _hp is not None and declared is not None and np.dtype(declared) == np.int16
         if self.native:
@@ -299,7 +311,7 @@ class _SignalStore:
         reseen = fits & (self.row_id[rows] == batch.ids) & (have > 0)
         cand = reseen & (have <= lens) & (have >= T)
         stage = self._stage(presented)
-        tail_ix = np.arange(T, dtype=np.int64)
+        windows = np.lib.stride_tricks.sliding_window_view(stage, T)      # windows[i] = stage[i: i + T], no copy
         while True:
             start = np.where(cand, have - T, 0)
             seg_len = lens - start
@@ -309,7 +321,7 @@ class _SignalStore:
             ci = np.flatnonzero(cand)
             if ci.size == 0:
                 break
-            ok = (stage[src[ci][:, None] + tail_ix] == self.row_tail[rows[ci]]).all(axis=1)
+            ok = (windows[src[ci]] == self.row_tail[rows[ci]]).all(axis=1)
             if ok.all():
                 break
             cand[ci[~ok]] = False                                   # not the prefix the row holds: whole, and staged again
@@ -330,7 +342,7 @@ class _SignalStore:
         self.row_have[rows[~fits]] = 0
         keep = fi[lens[fi] >= T]                                    # the new tails: the last T staged samples of each read
         if keep.size:
-            self.row_tail[rows[keep]] = stage[(src[keep] + seg_len[keep] - T)[:, None] + tail_ix]
+            self.row_tail[rows[keep]] = windows[src[keep] + seg_len[keep] - T]
         # ---- the new samples, compacted: one transfer, one scatter ------------------------------------------------
         self.samples_uploaded += total
         if total:
@@ -473,11 +485,13 @@ class SequencerControl:
                     self._events[k].record(side)            # the slice's samples are in the rows behind this point
                 t, dt = self._tick(t, 1)
                 ph[1] += dt
+                end = np.zeros(hi - lo, dtype=np.int64)
                 if polyA_cache:
-                    cget = polyA_cache.get
-                    end = np.fromiter((cget(i, 0) for i in part.ids), dtype=np.int64, count=hi - lo)
-                else:
-                    end = np.zeros(hi - lo, dtype=np.int64)
+                    if _hp is not None and type(polyA_cache) is dict:
+                        _hp.lookup(polyA_cache, part.ids, end)
+                    else:
+                        cget = polyA_cache.get
+                        end = np.fromiter((cget(i, 0) for i in part.ids), dtype=np.int64, count=hi - lo)
                 need = np.flatnonzero(end == 0)
                 found_h = found_d = None
                 if need.size:                                   # one launch for every read without a known end

@@ -10,6 +10,8 @@
  *   gather(reads, start_i64, out_i16) -> total   out = concat(raw[start[i]:]) in batch order (the staging buffer of the
  *                                                upload: whole reads, or only the samples the device does not hold yet)
  *   format_rows(...) -> str                      the CSV rows of riser/control.py:145-153, floats printed as repr() does
+ *   attrs(reads, name) -> list                   [getattr(r, name) for r in reads] (the read ids of a batch)
+ *   lookup(dict, keys, out_i64)                  out[i] = dict.get(keys[i], 0) for integer values (the poly(A) cache)
  *
  * Clients without the flag go through the eight-method duck type unchanged (get_raw_signal per read).
  */
@@ -315,10 +317,88 @@ static PyObject* hp_format_rows(PyObject* self, PyObject* args) {
     return res;
 }
 
+static PyObject* hp_attrs(PyObject* self, PyObject* args) {
+    PyObject *reads, *name;
+    if (!PyArg_ParseTuple(args, "OU", &reads, &name)) return NULL;
+    if (!PyList_Check(reads)) {
+        PyErr_SetString(PyExc_TypeError, "attrs: reads must be a list");
+        return NULL;
+    }
+    const Py_ssize_t n = PyList_GET_SIZE(reads);
+    PyObject* out = PyList_New(n);
+    if (!out) return NULL;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* v = PyObject_GetAttr(PyList_GET_ITEM(reads, i), name);
+        if (!v) {
+            Py_DECREF(out);
+            return NULL;
+        }
+        PyList_SET_ITEM(out, i, v);
+    }
+    return out;
+}
+
+static PyObject* hp_lookup(PyObject* self, PyObject* args) {
+    PyObject *dict, *keys, *out;
+    if (!PyArg_ParseTuple(args, "O!OO", &PyDict_Type, &dict, &keys, &out)) return NULL;
+    /* a contiguous numpy object array exports its PyObject* items (format "O"): read them in place; anything else
+     * is walked as a sequence */
+    PyObject* seq = NULL;
+    Py_buffer kv;
+    int have_kv = 0;
+    if (PyObject_GetBuffer(keys, &kv, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS) == 0) {
+        if (kv.format && strcmp(kv.format, "O") == 0 && kv.itemsize == (Py_ssize_t)sizeof(PyObject*))
+            have_kv = 1;
+        else
+            PyBuffer_Release(&kv);
+    } else {
+        PyErr_Clear();
+    }
+    if (!have_kv) {
+        seq = PySequence_Fast(keys, "lookup: keys must be a sequence");
+        if (!seq) return NULL;
+    }
+    Py_buffer ov;
+    if (get_wbuf(out, &ov, "lookup(out)") != 0) {
+        if (have_kv) PyBuffer_Release(&kv);
+        Py_XDECREF(seq);
+        return NULL;
+    }
+    const Py_ssize_t n = have_kv ? kv.len / (Py_ssize_t)sizeof(PyObject*) : PySequence_Fast_GET_SIZE(seq);
+    if (ov.len < (Py_ssize_t)(n * sizeof(int64_t))) {
+        PyBuffer_Release(&ov);
+        if (have_kv) PyBuffer_Release(&kv);
+        Py_XDECREF(seq);
+        PyErr_SetString(PyExc_ValueError, "lookup: output buffer too small");
+        return NULL;
+    }
+    int64_t* o = (int64_t*)ov.buf;
+    PyObject** items = have_kv ? (PyObject**)kv.buf : PySequence_Fast_ITEMS(seq);
+    int bad = 0;
+    for (Py_ssize_t i = 0; i < n && !bad; ++i) {
+        PyObject* v = PyDict_GetItemWithError(dict, items[i]);        /* borrowed */
+        if (!v) {
+            if (PyErr_Occurred()) bad = 1;
+            o[i] = 0;
+            continue;
+        }
+        const long long x = PyLong_AsLongLong(v);
+        if (x == -1 && PyErr_Occurred()) bad = 1;
+        o[i] = (int64_t)x;
+    }
+    PyBuffer_Release(&ov);
+    if (have_kv) PyBuffer_Release(&kv);
+    Py_XDECREF(seq);
+    if (bad) return NULL;
+    Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
     {"lengths", hp_lengths, METH_VARARGS, "lengths(reads, out_int64): samples of every read's raw_data"},
     {"gather", hp_gather, METH_VARARGS, "gather(reads, start_int64, out_int16) -> samples written"},
     {"format_rows", hp_format_rows, METH_VARARGS, "CSV rows of one batch as one string"},
+    {"attrs", hp_attrs, METH_VARARGS, "attrs(reads, name) -> [getattr(r, name) for r in reads]"},
+    {"lookup", hp_lookup, METH_VARARGS, "lookup(dict, keys, out_int64): out[i] = dict.get(keys[i], 0)"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_hostpack", "per-read host loops of a ReadUntil batch", -1, methods};

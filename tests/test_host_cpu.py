@@ -89,6 +89,28 @@ def test_hostpack_csv_rows_match_the_reference_format(hp):
         hp.format_rows("h,", reads, np.array([40], dtype=np.int64), chan[:1], ns[:1], ",m,", p[:1], 3, ",t,", dec[:1], NAMES)
 
 
+def test_hostpack_attrs_and_cache_lookup(hp):
+    """the read ids of a batch and the poly(A) cache's look-ups as C loops: same values as the comprehensions"""
+    rng = np.random.default_rng(11)
+    reads = _reads(50, rng)
+    assert hp.attrs(reads, "id") == [r.id for r in reads]
+    with pytest.raises(AttributeError):
+        hp.attrs(reads, "no_such_attribute")
+    ids = np.empty(len(reads), dtype=object)
+    ids[:] = [r.id for r in reads]
+    cache = {r.id: int(rng.integers(1, 9000)) for r in reads[::3]}
+    want = np.array([cache.get(i, 0) for i in ids], dtype=np.int64)
+    for keys in (ids, ids[7:31], list(ids), tuple(ids[:5])):          # object array (read in place), a view, sequences
+        got = np.full(len(keys), -1, dtype=np.int64)
+        hp.lookup(cache, keys, got)
+        lo = 7 if len(keys) == 24 else 0
+        assert got.tolist() == want[lo: lo + len(keys)].tolist()
+    with pytest.raises(ValueError):
+        hp.lookup(cache, ids, np.zeros(3, dtype=np.int64))
+    with pytest.raises(TypeError):
+        hp.lookup({"id-0": "not a number"}, ids[:1], np.zeros(1, dtype=np.int64))
+
+
 def test_fake_client_channel_range_and_flags():
     batches = [[(ch, FakeRead(f"r{ch}", np.zeros(10, dtype=np.int16))) for ch in range(1, 13)] for _ in range(2)]
     c = FakeClient(batches, first_channel=5, last_channel=8)
