@@ -144,11 +144,13 @@ RS_API int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_
                  double* d_out64, int64_t ld64, double* d_stats, void* stream);
 
 /*
- * The same for FLOATING-POINT signals (elem_bytes = 4: float32, 8: float64), the other input
+ * The same for FLOATING-POINT signals (elem_bytes = 2: float16 (since ABI 2.2), 4: float32, 8: float64), the other input
  * SignalProcessor.mad_normalise accepts (riser/preprocess.py:108-115; the retrain path normalises pA-scaled float
  * signals, riser/retrain/preprocess.py:79).  numpy keeps the input's precision end to end (float32 in -> float32
  * arithmetic -> float32 out, the Python constant 1.4826 adopting the array's dtype under NEP 50), and so does this
- * entry: d_out has the element type of d_sig, rows of `ld` elements, bit-identical to the reference's result.
+ * entry: d_out has the element type of d_sig, rows of `ld` elements, bit-identical to the reference's result (float16:
+ * every operation as numpy evaluates it - in float32, rounded to half - and the median's mean of the two middle values
+ * with its float32 accumulator).
  * Every read must have 1 <= len; read b is d_sig[d_off[b] .. d_off[b] + d_len[b]) in elements.  d_stats: fp64 [B, 2]
  * = (median, mad) or NULL.  Off the live path: an exact radix select per read, not tuned.
  */

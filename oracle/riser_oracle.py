@@ -108,7 +108,7 @@ def mad_normalise(signal: np.ndarray) -> np.ndarray:
 
 
 def mad_normalise_float(signal: np.ndarray) -> np.ndarray:
-    """riser/preprocess.py:108-147 for float32 / float64 input (the retrain path's pA-scaled signals,
+    """riser/preprocess.py:108-147 for float16 / float32 / float64 input (the retrain path's pA-scaled signals,
     riser/retrain/preprocess.py:79).  numpy >= 2 (NEP 50) keeps the array's precision: np.median and np.abs(x - med)
     return the input dtype T, the Python float 1.4826 adopts T in `1.4826 * mad`, so y = (x - med) / (T(1.4826) * mad)
     and the smoothing recurrence run entirely in T.  mad == 0 gives the int64 zero array of the integer case."""
@@ -191,7 +191,8 @@ def conv_block(x: np.ndarray, w: np.ndarray, b: np.ndarray, acc=np.float32) -> n
 
 def convnet_forward(sd: dict, x: np.ndarray, acc=np.float32, return_layers: bool = False):
     """ConvNet.forward for the shipped `gap_fc` classifier (riser/nets/cnn.py:43-49,
-    28-33): x [B, L] -> 12 conv blocks -> mean over length -> Linear -> logits [B, 2]."""
+    28-33): x [B, L] -> 12 conv blocks -> mean over length -> Linear -> logits [B, 2]; a state dict with
+    `classifier.0.*` keys is the `gap` classifier (gap_head)."""
     n_layers = sum(1 for k in sd if k.startswith("layers.") and k.endswith(".0.weight"))
     h = np.asarray(x, dtype=acc)[:, None, :]
     layers = []
@@ -201,11 +202,22 @@ def convnet_forward(sd: dict, x: np.ndarray, acc=np.float32, return_layers: bool
             layers.append(h)
     if h.shape[2] == 0:
         raise RuntimeError("input shorter than 2**n_layers samples")     # torch raises in max_pool1d
-    feat = h.mean(axis=2, dtype=acc)
-    logits = feat @ np.asarray(sd["classifier.2.weight"]).astype(acc).T + np.asarray(sd["classifier.2.bias"]).astype(acc)
+    if "classifier.0.weight" in sd:
+        logits = gap_head(h, sd, acc)
+    else:
+        feat = h.mean(axis=2, dtype=acc)
+        logits = feat @ np.asarray(sd["classifier.2.weight"]).astype(acc).T + np.asarray(sd["classifier.2.bias"]).astype(acc)
     if return_layers:
         return logits, layers
     return logits
+
+
+def gap_head(h: np.ndarray, sd: dict, acc=np.float32) -> np.ndarray:
+    """The `gap` classifier (riser/nets/cnn.py:34-38): Conv1d(C, n_classes, 1) at every position, then the mean over
+    positions (AdaptiveAvgPool1d(1)) - in that order, as the reference computes it.  h [B, C, P] -> logits [B, n_classes]."""
+    w = np.asarray(sd["classifier.0.weight"]).astype(acc)[:, :, 0]
+    y = np.matmul(w, h) + np.asarray(sd["classifier.0.bias"]).astype(acc)[None, :, None]
+    return y.mean(axis=2, dtype=acc)
 
 
 def convnet_forward_general(sd: dict, x: np.ndarray, depth: int, acc=np.float32) -> np.ndarray:
@@ -229,6 +241,8 @@ def convnet_forward_general(sd: dict, x: np.ndarray, depth: int, acc=np.float32)
         h = np.maximum(h[:, :, 0:2 * Lo:2], h[:, :, 1:2 * Lo:2])
     if h.shape[2] == 0:
         raise RuntimeError("input shorter than 2**n_layers samples")
+    if "classifier.0.weight" in sd:
+        return gap_head(h, sd, acc)
     feat = h.mean(axis=2, dtype=acc)
     return feat @ np.asarray(sd["classifier.2.weight"]).astype(acc).T + np.asarray(sd["classifier.2.bias"]).astype(acc)
 

@@ -386,7 +386,7 @@ extern "C" {
 
 const char* rs_last_error(void) { return g_err; }
 
-int rs_version(void) { return (2 << 16) | 1; }
+int rs_version(void) { return (2 << 16) | 2; }
 
 int rs_device_count(void) {
     int n = 0;
@@ -669,8 +669,8 @@ int rs_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
 
 int rs_normalise_float(const void* d_sig, int elem_bytes, const int64_t* d_off, const int32_t* d_len, int B, void* d_out,
                        int64_t ld, double* d_stats, void* stream) {
-    if (B < 0 || (B > 0 && (!d_sig || !d_off || !d_len || !d_out)) || (elem_bytes != 4 && elem_bytes != 8)) {
-        set_error("rs_normalise_float: null argument or element size %d not 4 / 8", elem_bytes);
+    if (B < 0 || (B > 0 && (!d_sig || !d_off || !d_len || !d_out)) || (elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8)) {
+        set_error("rs_normalise_float: null argument or element size %d not 2 / 4 / 8", elem_bytes);
         return RS_ERR_ARG;
     }
     return launch_normalise_float(d_sig, elem_bytes, d_off, d_len, B, d_out, ld, d_stats, static_cast<hipStream_t>(stream));

@@ -1,4 +1,4 @@
-// K1f: MAD normalisation + outlier smoothing of FLOATING-POINT signals (float32 or float64), one 256-thread workgroup
+// K1f: MAD normalisation + outlier smoothing of FLOATING-POINT signals (float16, float32 or float64), one 256-thread workgroup
 // per read.  The live path feeds raw int16 ADC counts (normalise.hip); this kernel covers the other input the
 // reference's SignalProcessor.mad_normalise accepts (riser/preprocess.py:108-147): the retrain path normalises
 // pA-scaled float signals (riser/retrain/preprocess.py:79).  numpy keeps the input's precision end to end (NEP 50:
@@ -7,6 +7,8 @@
 //   mad = np.median(np.abs(x - med))         |x - med| rounded in T, then the same select
 //   y   = (x - med) / (T(1.4826) * mad)      one rounding per operation (-ffp-contract=off, IEEE division)
 //   the sequential in-place smoothing of {|y| > 3.5} of normalise.hip, in T.
+// float16: numpy evaluates every half-precision operation as float32(a) op float32(b) rounded to half, and np.median's
+// mean of the two middle values with a float32 accumulator rounded once - Arith<_Float16> spells exactly that.
 // Order statistics of floats: MSB-first radix select (8 bits per pass) on the order-preserving integer image of the
 // value, over the read in global memory (it is a few tens of KB: L2-resident after the first pass).
 // Off the hot path: clarity over speed.
@@ -17,7 +19,36 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// one operation of numpy on scalars / arrays of dtype T
+template <class T> struct Arith {
+    __device__ static T add(T a, T b) { return a + b; }
+    __device__ static T sub(T a, T b) { return a - b; }
+    __device__ static T mul(T a, T b) { return a * b; }
+    __device__ static T div(T a, T b) { return a / b; }
+    __device__ static T mean2(T a, T b) { return (T)((T)(a + b) / (T)2); }     // np.mean([a, b]) in T
+};
+template <> struct Arith<_Float16> {
+    typedef _Float16 H;
+    __device__ static H add(H a, H b) { return (H)((float)a + (float)b); }
+    __device__ static H sub(H a, H b) { return (H)((float)a - (float)b); }
+    __device__ static H mul(H a, H b) { return (H)((float)a * (float)b); }
+    __device__ static H div(H a, H b) { return (H)((float)a / (float)b); }
+    __device__ static H mean2(H a, H b) { return (H)(((float)a + (float)b) / 2.0f); }   // float32 accumulator, one rounding
+};
+
 template <class T> struct Bits;
+template <> struct Bits<_Float16> {
+    typedef unsigned type;
+    static constexpr int kPasses = 2;
+    __device__ static unsigned key(_Float16 v) {
+        const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, v);
+        return (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
+    }
+    __device__ static _Float16 value(unsigned k) {
+        const unsigned u = (k & 0x8000u) ? (k & 0x7fffu) : (~k & 0xffffu);
+        return __builtin_bit_cast(_Float16, (unsigned short)u);
+    }
+};
 template <> struct Bits<float> {
     typedef unsigned type;
     static constexpr int kPasses = 4;
@@ -90,11 +121,11 @@ __global__ __launch_bounds__(kThreads) void normalise_float_kernel(const T* __re
     auto median_of = [&](auto f) -> T {
         const T lo = block_select<T>(f, n, k_lo, hist, sel, tid);
         const T hi = k_hi == k_lo ? lo : block_select<T>(f, n, k_hi, hist, sel, tid);
-        return k_hi == k_lo ? lo : (T)((T)(lo + hi) / (T)2);       // np.mean of the two middle values, in T
+        return k_hi == k_lo ? lo : Arith<T>::mean2(lo, hi);         // np.mean of the two middle values
     };
     const T med = median_of([&](int i) { return x[i]; });
     const T mad = median_of([&](int i) {
-        const T d = x[i] - med;
+        const T d = Arith<T>::sub(x[i], med);
         return d < (T)0 ? -d : d;
     });
     if (stats && tid == 0) {
@@ -105,9 +136,9 @@ __global__ __launch_bounds__(kThreads) void normalise_float_kernel(const T* __re
         for (int i = tid; i < n; i += kThreads) o[i] = (T)0;
         return;
     }
-    const T denom = (T)1.4826 * mad;                                 // the Python float adopts the array's dtype
+    const T denom = Arith<T>::mul((T)1.4826, mad);                   // the Python float adopts the array's dtype
     const T lim = (T)3.5;
-    auto yv = [&](int j) -> T { return (T)(x[j] - med) / denom; };
+    auto yv = [&](int j) -> T { return Arith<T>::div(Arith<T>::sub(x[j], med), denom); };
     auto is_out = [&](int j) {
         const T y = yv(j);
         return (y < (T)0 ? -y : y) > lim;
@@ -127,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void normalise_float_kernel(const T* __re
             } else if (j == n - 1) {
                 nv = prev;                                           // :134 (not clipped)
             } else {
-                nv = (T)(prev + yv(j + 1)) / (T)2;                   // :136
+                nv = Arith<T>::div(Arith<T>::add(prev, yv(j + 1)), (T)2);    // :136
                 nv = nv > lim ? lim : (nv < -lim ? -lim : nv);       // :141-147
             }
             o[j] = nv;
@@ -142,7 +173,10 @@ __global__ __launch_bounds__(kThreads) void normalise_float_kernel(const T* __re
 int launch_normalise_float(const void* d_sig, int elem_bytes, const int64_t* d_off, const int32_t* d_len, int B, void* d_out,
                            int64_t ld, double* d_stats, hipStream_t st) {
     if (B <= 0) return RS_OK;
-    if (elem_bytes == 4)
+    if (elem_bytes == 2)
+        hipLaunchKernelGGL(normalise_float_kernel<_Float16>, dim3(B), dim3(kThreads), 0, st,
+                           static_cast<const _Float16*>(d_sig), d_off, d_len, static_cast<_Float16*>(d_out), ld, d_stats);
+    else if (elem_bytes == 4)
         hipLaunchKernelGGL(normalise_float_kernel<float>, dim3(B), dim3(kThreads), 0, st, static_cast<const float*>(d_sig),
                            d_off, d_len, static_cast<float*>(d_out), ld, d_stats);
     else

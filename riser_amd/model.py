@@ -66,16 +66,25 @@ class Model:
         if logger is not None:
             logger.info('Using %s device', self.device)
         cnn = config.cnn
-        if getattr(cnn, "classifier", "gap_fc") != "gap_fc":
-            # 'fc' hard-codes Linear(67 * 753, 4096) for one input length of one 4-layer net (riser/nets/cnn.py:22-27,
-            # "TODO: Hardcoded"); 'gap' cannot pass Model.classify at all: x.squeeze() (cnn.py:48-49) drops the batch
-            # dimension at batch 1 and softmax(dim=1) (riser/model.py:27) then raises
-            raise ValueError("riser_amd supports the `gap_fc` classifier (every shipped config, riser/model/*.yaml)")
+        self.classifier = getattr(cnn, "classifier", "gap_fc")
+        if self.classifier not in ("gap_fc", "gap"):
+            # 'fc' hard-codes Linear(67 * 753, 4096) for ONE input length (12048 .. 12063 samples) of one 4-layer net
+            # (riser/nets/cnn.py:22-27, "TODO: Hardcoded"): no shipped config, no read of another length can pass it
+            raise ValueError("riser_amd supports the `gap_fc` (every shipped config, riser/model/*.yaml) and `gap` classifiers")
         if isinstance(state, dict):
             sd = state
         else:
             sd = torch.load(state, map_location="cpu")              # riser/model.py:19
         sd = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
+        if self.classifier == "gap":
+            # Conv1d(C, n_classes, 1) then the mean over positions (riser/nets/cnn.py:34-38) = the mean, then the same
+            # matrix: W mean_p(x_p) + b.  Runs as the gap_fc head with the 1 x 1 kernel read as a matrix (fp32 summation
+            # order differs from the reference's, ~1e-7 on a probability).
+            w0 = np.asarray(sd["classifier.0.weight"])
+            if w0.ndim != 3 or w0.shape[2] != 1:
+                raise ValueError("classifier.0.weight: expected [n_classes, channels, 1] for the `gap` classifier")
+            sd["classifier.2.weight"] = np.ascontiguousarray(w0[:, :, 0])
+            sd["classifier.2.bias"] = np.asarray(sd["classifier.0.bias"])
         self.channels = [int(c) for c in cnn.channels][: int(cnn.n_layers)]
         self.n_layers = len(self.channels)
         self.min_length = 1 << self.n_layers
@@ -231,6 +240,10 @@ class Model:
     # ------------------------------------------------------------------------------------
     def classify(self, signal):
         """riser/model.py:22-28: normalised signal [L] -> fp32 Tensor[2] on the device."""
+        if self.classifier == "gap":
+            # the reference cannot classify ONE read with this head: x.squeeze() (riser/nets/cnn.py:48-49) drops the batch
+            # dimension and softmax(dim=1) (riser/model.py:27) raises this; the batched entry points below run it
+            raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1)")
         x = torch.from_numpy(np.ascontiguousarray(signal)).unsqueeze(0)
         x = x.to(self.device, dtype=torch.float)
         lens = np.array([x.shape[1]], dtype=np.int32)

@@ -162,19 +162,19 @@ class SignalProcessor:
         return (res, stats.cpu().numpy()) if return_stats else res
 
     def mad_normalise_float_batch(self, signals, return_stats: bool = False):
-        """List of float32 (or float64) signals of one dtype -> list of arrays of that dtype, bit-identical to the
+        """List of float16 / float32 / float64 signals of one dtype -> list of arrays of that dtype, bit-identical to the
         reference's mad_normalise on the same input (rs_normalise_float)."""
         arrs = [np.ascontiguousarray(s) for s in signals]
         dt = arrs[0].dtype
-        if dt not in (np.float32, np.float64) or any(a.dtype != dt for a in arrs):
-            raise TypeError("riser_amd normalises float32 or float64 signals (one dtype per batch); "
+        if dt not in (np.float16, np.float32, np.float64) or any(a.dtype != dt for a in arrs):
+            raise TypeError("riser_amd normalises float16, float32 or float64 signals (one dtype per batch); "
                             f"got {sorted({str(a.dtype) for a in arrs})}")
         if any(a.shape[0] == 0 for a in arrs):
             raise ValueError("Signal must not be empty")
         lens = np.array([a.shape[0] for a in arrs], dtype=np.int32)
         offs = np.zeros(len(arrs), dtype=np.int64)
         offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
-        tdt = torch.float32 if dt == np.float32 else torch.float64
+        tdt = {2: torch.float16, 4: torch.float32, 8: torch.float64}[dt.itemsize]
         dev = self.device
         sig = torch.from_numpy(np.concatenate(arrs)).to(dev)
         B, lmax = len(arrs), int(lens.max())

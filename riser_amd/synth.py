@@ -231,7 +231,7 @@ def polya_edge_cases(seed: int = 77):
 
 
 def normalise_float_cases(seed: int = 20260103):
-    """[(name, float32 / float64 signal)]: pA-scaled versions (x * scale + offset, the form the retrain path feeds to
+    """[(name, float16 / float32 / float64 signal)]: pA-scaled versions (x * scale + offset, the form the retrain path feeds to
     mad_normalise, riser/retrain/preprocess.py:79) of integer cases with outliers at both ends, runs, half-integer
     medians and MAD = 0; tests/golden/normalise_float.npz holds the reference's outputs for them."""
     base = make_signals(seed, 1, 5000, first_read=3, spikes=False)[0]
@@ -254,6 +254,8 @@ def normalise_float_cases(seed: int = 20260103):
     for name, s in ints.items():
         for dt in (np.float32, np.float64):
             out.append((f"{name}.{np.dtype(dt).name}", (s.astype(np.float64) * 0.17548 + 3.25).astype(dt)))
+    for name, s in ints.items():                     # half precision (round 4): 11-bit values, medians between ties
+        out.append((f"{name}.float16", (s.astype(np.float64) * 0.17548 + 3.25).astype(np.float16)))
     return out
 
 

@@ -39,6 +39,8 @@ def test_model_loads_pth_like_the_reference(dev, tmp_path):
     with pytest.raises(ValueError):
         Model(bad, synth.Config(), log, "mRNA", device=dev)
     with pytest.raises(ValueError):
+        Model(sd, synth.Config(synth.CnnConfig(classifier="fc")), log, "mRNA", device=dev)
+    with pytest.raises(KeyError):                     # a `gap` config needs the 1 x 1 convolution's keys (classifier.0.*)
         Model(sd, synth.Config(synth.CnnConfig(classifier="gap")), log, "mRNA", device=dev)
     m.close()
 
@@ -371,6 +373,29 @@ def test_oversized_batches_are_split(dev, monkeypatch):
     m.close()
 
 
+def test_gap_classifier_against_reference(dev, golden_dir):
+    """`gap` head (riser/nets/cnn.py:34-38): batches of 3 reads against the reference's ConvNet.forward + softmax, on the
+    shipped architecture (every dtype mode that claims 1e-3) and on a depth-2 net (generic conv program); Model.classify
+    of ONE read raises what the reference raises."""
+    from test_oracle_golden import _gap_cases
+    from riser_amd.model import Model
+    for name, cfg, sd, want, err in _gap_cases(golden_dir):
+        config = synth.Config(synth.CnnConfig(channels=cfg["channels"], kernels=cfg["kernels"], depth=cfg["depth"],
+                                              classifier="gap"))
+        for dt in (("f32w", "f32", "bf16x3", "f16x3") if cfg["depth"] == 1 else ("f32w",)):
+            m = Model(sd, config, None, "x", dtype=dt, device=dev)
+            for j, (L, probs) in enumerate(want.items()):
+                sigs = synth.make_signals(SIG_SEED, 3, L, first_read=90 + 3 * j)
+                got = m.classify_batch([ro.mad_normalise(s) for s in sigs]).cpu().numpy()
+                assert np.abs(got - probs).max() < 1e-3, (name, dt, L)
+                assert np.array_equal(got[:, 1] > 0.9, probs[:, 1] > 0.9)
+            with pytest.raises(IndexError):
+                m.classify(ro.mad_normalise(sigs[0]))
+            m.close()
+    with pytest.raises(ValueError):
+        Model(synth.make_state_dict(1), synth.Config(synth.CnnConfig(classifier="fc")), None, "x", device=dev)
+
+
 def test_convnet_variants_against_reference(dev, golden_dir):
     """ConvNet configurations outside the shipped class - depth 2 / 3, kernels 5 and 7 (riser/nets/cnn.py:17,52-65) -
     run the generic MFMA conv program (csrc/seqnet.hip) behind the same Model surface: classify(signal), batched
@@ -406,9 +431,8 @@ def test_convnet_variants_against_reference(dev, golden_dir):
         assert np.abs(ms.classify_batch(xs).cpu().numpy() - got[: len(xs)]).max() < 1e-5
         ms.close()
         m.close()
-    for clf in ("gap", "fc"):
-        with pytest.raises(ValueError):
-            Model(synth.make_state_dict(1), synth.Config(synth.CnnConfig(classifier=clf)), None, "x", device=dev)
+    with pytest.raises(ValueError):
+        Model(synth.make_state_dict(1), synth.Config(synth.CnnConfig(classifier="fc")), None, "x", device=dev)
     with pytest.raises(ValueError):                                           # even kernels: 'same' pads asymmetrically
         Model({}, synth.Config(synth.CnnConfig(channels=[4, 4], kernels=[4, 3])), None, "x", device=dev)
 

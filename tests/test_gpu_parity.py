@@ -146,22 +146,22 @@ def test_normalise_fp32_device_output(proc, dev):
 
 
 def test_normalise_float_inputs_golden(proc, golden_dir):
-    """SignalProcessor.mad_normalise on float32 / float64 signals (riser/preprocess.py:108-115 accepts any numeric
-    array; the retrain path feeds pA-scaled floats): dtype and bits of the reference, singly and batched; float16 and
-    mixed batches are refused"""
+    """SignalProcessor.mad_normalise on float16 / float32 / float64 signals (riser/preprocess.py:108-115 accepts any
+    numeric array; the retrain path feeds pA-scaled floats): dtype and bits of the reference, singly and batched; long
+    doubles and mixed batches are refused"""
     g = np.load(os.path.join(golden_dir, "normalise_float.npz"))
     cases = synth.normalise_float_cases()
     for name, x in cases:
         want = g[f"{name}.out"]
         got = proc.mad_normalise(x.copy())
         assert got.dtype == want.dtype and np.array_equal(got, want), name
-    for dt in ("float32", "float64"):
+    for dt in ("float16", "float32", "float64"):
         pick = [(n, x) for n, x in cases if n.endswith(dt) and "mad0" not in n]
         outs = proc.mad_normalise_float_batch([x for _, x in pick])
         for (n, _), o in zip(pick, outs):
             assert np.array_equal(o, g[f"{n}.out"]), n
     with pytest.raises(TypeError):
-        proc.mad_normalise(np.ones(100, dtype=np.float16))
+        proc.mad_normalise(np.ones(100, dtype=np.longdouble))
     with pytest.raises(TypeError):
         proc.mad_normalise_float_batch([np.ones(10, np.float32), np.ones(10, np.float64)])
     with pytest.raises(ValueError):

@@ -104,6 +104,31 @@ def test_convnet_variants_oracle_vs_reference(golden_dir):
             assert np.abs(got - want[j]).max() < 2e-5, (name, int(L))
 
 
+def _gap_cases(golden_dir):
+    import json
+    g = np.load(os.path.join(golden_dir, "gap_head.npz"))
+    for name in ("shipped_gap", "depth2_gap"):
+        cfg = json.loads(str(g[f"{name}.cfg"]))
+        if cfg["depth"] == 1:                        # the shipped architecture: seed-1 weights, Linear head as a 1 x 1 conv
+            sd = dict(synth.make_state_dict(1))
+            sd["classifier.0.weight"] = sd.pop("classifier.2.weight")[:, :, None].copy()
+            sd["classifier.0.bias"] = sd.pop("classifier.2.bias")
+        else:
+            sd = {k[len(name) + 4:]: g[k] for k in g.files if k.startswith(name + ".sd.")}
+        yield name, cfg, sd, {int(L): g[f"{name}.L{L}.probs"] for L in cfg["lens"]}, str(g[f"{name}.classify_error"])
+
+
+def test_gap_classifier_oracle_vs_reference(golden_dir):
+    """the `gap` head (riser/nets/cnn.py:34-38) through the reference's ConvNet.forward on batches of 3 reads"""
+    for name, cfg, sd, want, err in _gap_cases(golden_dir):
+        assert err == "IndexError"                   # the reference's Model.classify cannot run this head at batch 1
+        for j, (L, probs) in enumerate(want.items()):
+            sigs = synth.make_signals(20260103, 3, L, first_read=90 + 3 * j)
+            x = np.stack([ro.mad_normalise(s) for s in sigs]).astype(np.float32)
+            logits = ro.convnet_forward(sd, x) if cfg["depth"] == 1 else ro.convnet_forward_general(sd, x, cfg["depth"])
+            assert np.abs(ro.softmax(logits) - probs).max() < 2e-5, (name, L)
+
+
 @pytest.fixture(scope="module")
 def net(golden_dir):
     return np.load(os.path.join(golden_dir, "network.npz"))
