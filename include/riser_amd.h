@@ -109,6 +109,21 @@ RS_API int rs_model_create(int n_layers, const int32_t* channels, int n_classes,
 
 RS_API int rs_model_destroy(rs_model* m);
 
+/*
+ * ABI 2.2.  Replace the model's gap_fc head by the reference's `fc` classifier (riser/nets/cnn.py:22-27):
+ *     Flatten(1) -> Linear(C * positions, hidden) -> ReLU -> Linear(hidden, 2),
+ * C = the last conv layer's channels.  w1 [hidden][C * positions] (row-major, features channel-major as Flatten orders
+ * them: f = c * positions + p), b1 [hidden], w2 [2][hidden], b2 [2]: host pointers, copied.  The reference hard-codes
+ * C * positions = 67 * 753 and hidden = 4096 (one input length, 12048 .. 12063 samples, of one 4-layer net); here any
+ * positions >= 1 and any hidden that is a multiple of 64.  fp32 models only (RS_F32 / RS_F32W).  After this call a read
+ * whose len >> n_layers differs from `positions` cannot be classified - the reference's matmul raises for it
+ * (riser/nets/cnn.py:47) - and gets NaN probabilities (decision RS_NO_DECISION); rs_workspace_bytes() grows by the
+ * partial sums of the first Linear.  The fc model runs in rs_forward / rs_classify / rs_classify_ensemble like any other
+ * (ensemble members must agree on `hidden`).  Call once, before the first forward.
+ */
+RS_API int rs_model_set_fc_classifier(rs_model* m, int positions, int hidden, const float* w1, const float* b1,
+                               const float* w2, const float* b2);
+
 /* Bytes of device workspace rs_forward / rs_classify need for a batch of B reads of at
  * most Lmax samples (0 on bad arguments): the block table, the normalised signals and two activation buffers. */
 RS_API size_t rs_workspace_bytes(const rs_model* m, int B, int Lmax);

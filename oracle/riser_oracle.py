@@ -192,7 +192,7 @@ def conv_block(x: np.ndarray, w: np.ndarray, b: np.ndarray, acc=np.float32) -> n
 def convnet_forward(sd: dict, x: np.ndarray, acc=np.float32, return_layers: bool = False):
     """ConvNet.forward for the shipped `gap_fc` classifier (riser/nets/cnn.py:43-49,
     28-33): x [B, L] -> 12 conv blocks -> mean over length -> Linear -> logits [B, 2]; a state dict with
-    `classifier.0.*` keys is the `gap` classifier (gap_head)."""
+    `classifier.0.*` keys is the `gap` classifier (gap_head), one with `classifier.1.*` / `classifier.3.*` the `fc` one (fc_head)."""
     n_layers = sum(1 for k in sd if k.startswith("layers.") and k.endswith(".0.weight"))
     h = np.asarray(x, dtype=acc)[:, None, :]
     layers = []
@@ -204,6 +204,8 @@ def convnet_forward(sd: dict, x: np.ndarray, acc=np.float32, return_layers: bool
         raise RuntimeError("input shorter than 2**n_layers samples")     # torch raises in max_pool1d
     if "classifier.0.weight" in sd:
         logits = gap_head(h, sd, acc)
+    elif "classifier.1.weight" in sd:
+        logits = fc_head(h, sd, acc)
     else:
         feat = h.mean(axis=2, dtype=acc)
         logits = feat @ np.asarray(sd["classifier.2.weight"]).astype(acc).T + np.asarray(sd["classifier.2.bias"]).astype(acc)
@@ -218,6 +220,18 @@ def gap_head(h: np.ndarray, sd: dict, acc=np.float32) -> np.ndarray:
     w = np.asarray(sd["classifier.0.weight"]).astype(acc)[:, :, 0]
     y = np.matmul(w, h) + np.asarray(sd["classifier.0.bias"]).astype(acc)[None, :, None]
     return y.mean(axis=2, dtype=acc)
+
+
+def fc_head(h: np.ndarray, sd: dict, acc=np.float32) -> np.ndarray:
+    """The `fc` classifier (riser/nets/cnn.py:22-27): Flatten(1) (channel-major: f = c * P + p) -> Linear -> ReLU ->
+    Linear.  h [B, C, P] -> logits [B, n_classes]; torch raises in the first Linear when C * P is not its in_features."""
+    w1 = np.asarray(sd["classifier.1.weight"])
+    flat = h.reshape(h.shape[0], -1).astype(acc)
+    if flat.shape[1] != w1.shape[1]:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({flat.shape[0]}x{flat.shape[1]} and "
+                           f"{w1.shape[1]}x{w1.shape[0]})")
+    hid = np.maximum(flat @ w1.astype(acc).T + np.asarray(sd["classifier.1.bias"]).astype(acc), 0)
+    return hid @ np.asarray(sd["classifier.3.weight"]).astype(acc).T + np.asarray(sd["classifier.3.bias"]).astype(acc)
 
 
 def convnet_forward_general(sd: dict, x: np.ndarray, depth: int, acc=np.float32) -> np.ndarray:

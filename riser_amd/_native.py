@@ -19,7 +19,7 @@ DECISION_NAMES = ("try_again", "accept", "reject", "no_decision")
 
 # every symbol include/riser_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = (
-    "rs_last_error", "rs_version", "rs_device_count", "rs_model_create", "rs_model_destroy",
+    "rs_last_error", "rs_version", "rs_device_count", "rs_model_create", "rs_model_destroy", "rs_model_set_fc_classifier",
     "rs_workspace_bytes", "rs_max_batch", "rs_block_samples", "rs_normalise", "rs_normalise_float", "rs_forward", "rs_padded_length", "rs_classify",
     "rs_classify_ensemble", "rs_ensemble_workspace_bytes", "rs_autotune", "rs_decide", "rs_polya_end", "rs_copy_segments", "rs_model_layer_info", "rs_profile_enable", "rs_profile_read",
     "rs_debug_capture_layer",
@@ -66,6 +66,8 @@ def lib():
                                   i32, i32, C.POINTER(vp)]
     L.rs_model_destroy.restype = i32
     L.rs_model_destroy.argtypes = [vp]
+    L.rs_model_set_fc_classifier.restype = i32
+    L.rs_model_set_fc_classifier.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     L.rs_workspace_bytes.restype = sz
     L.rs_workspace_bytes.argtypes = [vp, i32, i32]
     L.rs_padded_length.restype = i32

@@ -85,6 +85,7 @@ struct rs_model {
     ConvLayerDev layers[kMaxLayers];      // i >= 1
     float* d_fcw = nullptr;               // [2][c_last]
     float* d_fcb = nullptr;
+    FcHead fc;                            // fc.H > 0: the `fc` classifier replaces the gap_fc head (rs_model_set_fc_classifier)
     float* d_zero = nullptr;              // 256 zero bytes: target of masked-off staging loads
     int num_cu = 256;
     int last_bm[kMaxLayers] = {0};
@@ -231,7 +232,7 @@ bool use_wino4(int layer, int n_layers, int c_in, int c_out) {
 struct WsLayout {
     size_t rbase_off, blen_off, bread_off;          // coarse table
     size_t rbase_f_off, blen_f_off, bread_f_off;    // fine table (== coarse when the model has one level)
-    size_t xnorm_off, bufa_off, bufb_off, total;
+    size_t xnorm_off, bufa_off, bufb_off, fc_part_off, total;
     int U, Uf;              // block sizes in samples (1 << pad_shift, 1 << fine_shift)
     int nblk_max, nblk_f_max;   // blocks of a read of Lmax samples
     int64_t nb_max, nb_f_max;   // B * nblk_max
@@ -277,7 +278,8 @@ WsLayout ws_layout(const rs_model* m, int B, int Lmax) {
     w.xnorm_off = at + kAlign;                                    // the last 16 bytes before the rows are a zero prefix
     w.bufa_off = align_up(w.xnorm_off + (size_t)w.nb_f_max * w.Uf * sizeof(float));
     w.bufb_off = w.bufa_off + buf;
-    w.total = w.bufb_off + buf;
+    w.fc_part_off = w.bufb_off + buf;
+    w.total = w.fc_part_off + (m->fc.H ? align_up(fc_head_workspace_bytes(B, m->fc.H)) : 0);
     return w;
 }
 
@@ -609,6 +611,61 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
     return RS_OK;
 }
 
+int rs_model_set_fc_classifier(rs_model* m, int positions, int hidden, const float* w1, const float* b1, const float* w2,
+                               const float* b2) {
+    if (!m || !w1 || !b1 || !w2 || !b2) {
+        set_error("rs_model_set_fc_classifier: null argument");
+        return RS_ERR_ARG;
+    }
+    if (m->dtype != RS_F32 && m->dtype != RS_F32W) {
+        set_error("rs_model_set_fc_classifier: fp32 models only (RS_F32 / RS_F32W)");
+        return RS_ERR_ARG;
+    }
+    if (m->fc.H) {
+        set_error("rs_model_set_fc_classifier: already set");
+        return RS_ERR_ARG;
+    }
+    const int C = m->channels[m->n_layers - 1], C4 = round_up(C, 4);
+    if (positions < 1 || hidden < 64 || hidden % 64 != 0 || C4 > m->cp[m->n_layers - 1] ||
+        (int64_t)positions << m->n_layers > kMaxNormLen) {
+        set_error("rs_model_set_fc_classifier: positions %d / hidden %d not supported (hidden: a multiple of 64)", positions, hidden);
+        return RS_ERR_ARG;
+    }
+    DeviceGuard guard(m->device);
+    const size_t F = (size_t)C * positions;
+    float* d_raw = nullptr;
+    RS_HIP(hipMalloc(reinterpret_cast<void**>(&d_raw), F * hidden * sizeof(float)));
+    int rc = RS_OK;
+    FcHead fc;
+    fc.C = C;
+    fc.C4 = C4;
+    fc.P = positions;
+    auto fail = [&](hipError_t e) {
+        set_error("rs_model_set_fc_classifier: %s", hipGetErrorString(e));
+        rc = RS_ERR_HIP;
+    };
+    hipError_t e = hipMemcpy(d_raw, w1, F * hidden * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) fail(e);
+    if (rc == RS_OK && (e = hipMalloc(reinterpret_cast<void**>(&fc.d_w1p), (size_t)positions * C4 * hidden * sizeof(float))) != hipSuccess)
+        fail(e);
+    if (rc == RS_OK) rc = launch_fc_pack(d_raw, fc.d_w1p, C, C4, positions, hidden, nullptr);
+    if (rc == RS_OK && (e = hipDeviceSynchronize()) != hipSuccess) fail(e);
+    (void)hipFree(d_raw);
+    if (rc == RS_OK) rc = upload(&fc.d_b1, std::vector<float>(b1, b1 + hidden));
+    if (rc == RS_OK) rc = upload(&fc.d_w2, std::vector<float>(w2, w2 + 2 * (size_t)hidden));
+    if (rc == RS_OK) rc = upload(&fc.d_b2, std::vector<float>(b2, b2 + 2));
+    if (rc != RS_OK) {
+        if (fc.d_w1p) (void)hipFree(fc.d_w1p);
+        if (fc.d_b1) (void)hipFree(fc.d_b1);
+        if (fc.d_w2) (void)hipFree(fc.d_w2);
+        if (fc.d_b2) (void)hipFree(fc.d_b2);
+        return rc;
+    }
+    fc.H = hidden;
+    m->fc = fc;
+    return RS_OK;
+}
+
 int rs_model_destroy(rs_model* m) {
     if (!m) return RS_OK;
     DeviceGuard guard(m->device);
@@ -621,6 +678,10 @@ int rs_model_destroy(rs_model* m) {
     if (m->d_fcw) (void)hipFree(m->d_fcw);
     if (m->d_fcb) (void)hipFree(m->d_fcb);
     if (m->d_zero) (void)hipFree(m->d_zero);
+    if (m->fc.d_w1p) (void)hipFree(m->fc.d_w1p);
+    if (m->fc.d_b1) (void)hipFree(m->fc.d_b1);
+    if (m->fc.d_w2) (void)hipFree(m->fc.d_w2);
+    if (m->fc.d_b2) (void)hipFree(m->fc.d_b2);
     if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
@@ -918,9 +979,14 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         }
         cur ^= 1;
     }
-    rc = launch_head(buf[cur], act_dtype(m), m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
-                     w.U >> m->n_layers, m->n_layers, d_len, B, bt.plan, two ? &bt.fine : nullptr, m->d_fcw, m->d_fcb, d_probs,
-                     d_logits, st);
+    if (m->fc.H)
+        rc = launch_fc_head(static_cast<const float*>(buf[cur]), m->cp[m->n_layers - 1], w.U >> m->n_layers, m->n_layers, d_len,
+                            B, bt.plan, m->fc, reinterpret_cast<float*>(static_cast<char*>(d_ws) + w.fc_part_off), d_probs,
+                            d_logits, st);
+    else
+        rc = launch_head(buf[cur], act_dtype(m), m->cp[m->n_layers - 1], m->channels[m->n_layers - 1],
+                         w.U >> m->n_layers, m->n_layers, d_len, B, bt.plan, two ? &bt.fine : nullptr, m->d_fcw, m->d_fcb,
+                         d_probs, d_logits, st);
     if (rc == RS_OK) prof_mark(m, m->n_layers + 1, st);
     return rc;
 }
@@ -994,13 +1060,13 @@ static bool ensemble_compatible(rs_model* const* models, int n_models) {
     for (int k = 0; k < n_models; ++k)
         if (!models[k] || models[k]->n_layers != m0->n_layers || models[k]->device != m0->device ||
             esize(models[k]) != esize(m0) || models[k]->pad_shift != m0->pad_shift || models[k]->fine_shift != m0->fine_shift ||
-            models[k]->split != m0->split)
+            models[k]->split != m0->split || models[k]->fc.H != m0->fc.H)
             return false;
     return true;
 }
 
 size_t rs_ensemble_workspace_bytes(rs_model* const* models, int n_models, int B, int Lmax) {
-    if (!ensemble_compatible(models, n_models) || B < 1 || Lmax < 1) return 0;
+    if (!ensemble_compatible(models, n_models) || B < 1 || Lmax < 1 || models[0]->fc.H) return 0;
     const WsLayout w = ensemble_layout(models, n_models, B, Lmax);
     return w.bufa_off + (size_t)n_models * 2 * (w.bufb_off - w.bufa_off);
 }
@@ -1050,7 +1116,7 @@ int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d
     // launches leave nothing for another's to use, and the fork / join is pure overhead
     constexpr int64_t kConcurrentBelowSamples = 1800LL * 4096;
     bool concurrent = n_models > 1 && ws_bytes >= w.bufa_off + (size_t)n_models * 2 * buf_bytes &&
-                      !m0->hooks.ensemble_serial && (int64_t)bt.NB * w.U < kConcurrentBelowSamples;
+                      !m0->hooks.ensemble_serial && !m0->fc.H && (int64_t)bt.NB * w.U < kConcurrentBelowSamples;
     for (int k = 0; k < n_models; ++k)
         if (models[k]->prof_on || models[k]->tuning || models[k]->dbg_dst) concurrent = false;
     for (int k = 1; k < n_models && concurrent; ++k)

@@ -209,6 +209,20 @@ int launch_head(const void* d_y, int dtype, int cp, int c, int P_last, int n_lay
 int launch_repack_rows(const void* d_src, void* d_dst, const BlockPlan& fine, const BlockPlan& coarse, int NB_coarse, int Pf,
                        int Pc, size_t row_bytes, hipStream_t st);
 
+// the `fc` classifier (fc_head.hip): weights on the device, first Linear re-ordered to [P][C4][H]
+struct FcHead {
+    float* d_w1p = nullptr;
+    float* d_b1 = nullptr;
+    float* d_w2 = nullptr;      // [2][H]
+    float* d_b2 = nullptr;
+    int C = 0, C4 = 0, P = 0, H = 0;
+};
+int fc_head_splits(int B, int H);
+size_t fc_head_workspace_bytes(int B, int H);
+int launch_fc_pack(const float* d_w1, float* d_w1p, int C, int C4, int P, int H, hipStream_t st);
+int launch_fc_head(const float* d_act, int cp, int P_last, int n_layers, const int32_t* d_len, int B, const BlockPlan& plan,
+                   const FcHead& fc, float* d_part, float* d_probs, float* d_logits, hipStream_t st);
+
 int launch_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len,
                   float thr, int mode, uint8_t* d_out, hipStream_t st);
 

@@ -67,10 +67,10 @@ class Model:
             logger.info('Using %s device', self.device)
         cnn = config.cnn
         self.classifier = getattr(cnn, "classifier", "gap_fc")
-        if self.classifier not in ("gap_fc", "gap"):
-            # 'fc' hard-codes Linear(67 * 753, 4096) for ONE input length (12048 .. 12063 samples) of one 4-layer net
-            # (riser/nets/cnn.py:22-27, "TODO: Hardcoded"): no shipped config, no read of another length can pass it
-            raise ValueError("riser_amd supports the `gap_fc` (every shipped config, riser/model/*.yaml) and `gap` classifiers")
+        if self.classifier not in ("gap_fc", "gap", "fc"):
+            raise ValueError(f"classifier {self.classifier!r}: the reference knows `fc`, `gap_fc` and `gap` "
+                             "(riser/nets/cnn.py:21-41)")
+        self._fc_positions = 0
         if isinstance(state, dict):
             sd = state
         else:
@@ -87,6 +87,26 @@ class Model:
             sd["classifier.2.bias"] = np.asarray(sd["classifier.0.bias"])
         self.channels = [int(c) for c in cnn.channels][: int(cnn.n_layers)]
         self.n_layers = len(self.channels)
+        fc = None
+        if self.classifier == "fc":
+            # Flatten -> Linear(C * P, H) -> ReLU -> Linear(H, n_classes) (riser/nets/cnn.py:22-27; the reference hard-codes
+            # C * P = 67 * 753 and H = 4096: one input length of one 4-layer net).  Runs behind the conv stack as two extra
+            # kernels (csrc/fc_head.hip); the gap_fc weights the library is created with are placeholders.
+            if int(getattr(cnn, "depth", 1)) != 1 or any(int(k) != 3 for k in list(cnn.kernels)[: self.n_layers]) \
+                    or dtype not in ("f32w", "f32"):
+                raise ValueError("the `fc` classifier runs behind the depth-1, kernel-3 conv stack in fp32 (dtype f32w / f32)")
+            w1 = np.ascontiguousarray(sd["classifier.1.weight"], dtype=np.float32)
+            c_last = self.channels[-1]
+            if w1.ndim != 2 or w1.shape[1] % c_last != 0:
+                raise ValueError(f"classifier.1.weight {w1.shape}: in_features is not a multiple of the last layer's "
+                                 f"{c_last} channels")
+            fc = (w1, np.ascontiguousarray(sd["classifier.1.bias"], dtype=np.float32),
+                  np.ascontiguousarray(sd["classifier.3.weight"], dtype=np.float32),
+                  np.ascontiguousarray(sd["classifier.3.bias"], dtype=np.float32))
+            if fc[1].shape != (w1.shape[0],) or fc[2].shape != (int(cnn.n_classes), w1.shape[0]) or fc[3].shape != (int(cnn.n_classes),):
+                raise ValueError("classifier.1 / classifier.3 shapes do not match each other or n_classes")
+            sd["classifier.2.weight"] = np.zeros((int(cnn.n_classes), c_last), dtype=np.float32)
+            sd["classifier.2.bias"] = np.zeros(int(cnn.n_classes), dtype=np.float32)
         self.min_length = 1 << self.n_layers
         self.dtype = dtype
         self._keep = []
@@ -130,6 +150,12 @@ class Model:
                  "rs_model_create")
         self._h = h
         self._ws = Workspace(self.device)
+        if fc is not None:
+            w1, b1, w2, b2 = fc
+            positions = w1.shape[1] // self.channels[-1]
+            nv.check(L.rs_model_set_fc_classifier(h, positions, int(w1.shape[0]), w1.ctypes.data, b1.ctypes.data,
+                                                  w2.ctypes.data, b2.ctypes.data), "rs_model_set_fc_classifier")
+            self._fc_positions, self._fc_hidden = positions, int(w1.shape[0])
 
     # ------------------------------------------------------------------------------------
     def _get_device(self, device=None):
@@ -232,6 +258,14 @@ class Model:
     def _check_lengths(self, lens_host: np.ndarray):
         if lens_host.size == 0:
             raise ValueError("empty batch")
+        if self._fc_positions:
+            rows = np.asarray(lens_host, dtype=np.int64) >> self.n_layers
+            bad = np.flatnonzero(rows != self._fc_positions)
+            if bad.size and int(np.asarray(lens_host).min()) >= self.min_length:
+                # what torch raises in the reference's first Linear (riser/nets/cnn.py:24,47) for a read of another length
+                c = self.channels[-1]
+                raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied (1x{c * int(rows[bad[0]])} and "
+                                   f"{c * self._fc_positions}x{self._fc_hidden})")
         if int(lens_host.min()) < self.min_length:
             # torch raises "max_pool1d() Invalid computed output size: 0" in the reference
             raise ValueError(f"signal of {int(lens_host.min())} samples is shorter than the network "
@@ -372,7 +406,10 @@ def _ensemble_bytes(models, B: int, lmax: int) -> int:
     """workspace of one rs_classify_ensemble call: a pair of activation buffers per model, so that the forwards of the
     models run concurrently (include/riser_amd.h)"""
     hs = (C.c_void_p * len(models))(*[m._h for m in models])
-    return nv.lib().rs_ensemble_workspace_bytes(hs, len(models), int(B), int(lmax))
+    need = nv.lib().rs_ensemble_workspace_bytes(hs, len(models), int(B), int(lmax))
+    if need == 0:          # models that cannot run concurrently (an `fc` classifier): the widest single-model workspace
+        need = max(nv.lib().rs_workspace_bytes(m._h, int(B), int(lmax)) for m in models)
+    return need
 
 
 def reserve_ensemble(models, B: int, lmax: int):

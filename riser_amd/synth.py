@@ -259,6 +259,32 @@ def normalise_float_cases(seed: int = 20260103):
     return out
 
 
+FC_CHANNELS = CHANNELS[:4]          # the 4-layer net the reference's `fc` classifier is hard-coded for (riser/nets/cnn.py:24)
+FC_POSITIONS, FC_HIDDEN = 753, 4096  # Linear(67 * 753, 4096): reads of 12048 .. 12063 samples
+
+
+def make_fc_state_dict(seed: int, positions: int = FC_POSITIONS, hidden: int = FC_HIDDEN) -> dict:
+    """Reference-format state dict of the 4-layer ConvNet with the `fc` classifier (riser/nets/cnn.py:22-27): the first
+    four conv layers of make_state_dict(seed) and Flatten -> Linear(67 * positions, hidden) -> ReLU -> Linear(hidden, 2).
+    The 206 M weights of the first Linear are a 4 M-entry hash table read through an index pattern (rebuilt in seconds,
+    never stored)."""
+    full = make_state_dict(seed)
+    sd = {k: v for k, v in full.items() if k.startswith("layers.") and int(k.split(".")[1]) < len(FC_CHANNELS)}
+    F = FC_CHANNELS[-1] * positions
+    n = 1 << 22
+    base = uniform_pm1(seed, 7001, n) * np.float32(np.sqrt(3.0 / F) * 1.6)
+    w1 = np.empty((hidden, F), dtype=np.float32)
+    f7 = np.arange(F, dtype=np.int64) * 7
+    for o0 in range(0, hidden, 256):
+        o = np.arange(o0, min(hidden, o0 + 256), dtype=np.int64)
+        w1[o0: o0 + o.size] = base[(f7[None, :] + o[:, None] * 131071) & (n - 1)]
+    sd["classifier.1.weight"] = w1
+    sd["classifier.1.bias"] = uniform_pm1(seed, 7002, hidden) * np.float32(0.05)
+    sd["classifier.3.weight"] = (uniform_pm1(seed, 7003, N_CLASSES * hidden) * np.float32(np.sqrt(3.0 / hidden) * 2.0)).reshape(N_CLASSES, hidden)
+    sd["classifier.3.bias"] = uniform_pm1(seed, 7004, N_CLASSES) * np.float32(0.1)
+    return sd
+
+
 RESNET_BENCH_CFG = dict(channels=[20, 30, 45, 67], kernel=19, padding=5, stride=3, block="basic", n_layers=4,
                         blocks=[2, 2, 2, 2], n_classes=2)
 

@@ -38,10 +38,11 @@ def test_model_loads_pth_like_the_reference(dev, tmp_path):
     bad["layers.3.0.weight"] = bad["layers.3.0.weight"][:, :10]
     with pytest.raises(ValueError):
         Model(bad, synth.Config(), log, "mRNA", device=dev)
-    with pytest.raises(ValueError):
-        Model(sd, synth.Config(synth.CnnConfig(classifier="fc")), log, "mRNA", device=dev)
-    with pytest.raises(KeyError):                     # a `gap` config needs the 1 x 1 convolution's keys (classifier.0.*)
-        Model(sd, synth.Config(synth.CnnConfig(classifier="gap")), log, "mRNA", device=dev)
+    with pytest.raises(ValueError):                   # the reference exits on a classifier it does not know (cnn.py:39-41)
+        Model(sd, synth.Config(synth.CnnConfig(classifier="softmax")), log, "mRNA", device=dev)
+    for clf in ("gap", "fc"):                         # their configs need their own keys (classifier.0.* / classifier.1.*, .3.*)
+        with pytest.raises(KeyError):
+            Model(sd, synth.Config(synth.CnnConfig(classifier=clf)), log, "mRNA", device=dev)
     m.close()
 
 
@@ -392,8 +393,56 @@ def test_gap_classifier_against_reference(dev, golden_dir):
             with pytest.raises(IndexError):
                 m.classify(ro.mad_normalise(sigs[0]))
             m.close()
+
+
+def test_fc_classifier_against_reference(dev, golden_dir):
+    """`fc` head (riser/nets/cnn.py:22-27: Flatten -> Linear(67 * 753, 4096) -> ReLU -> Linear(4096, 2)) behind the 4-layer
+    conv stack: Model.classify per read against the reference's own probabilities, the same reads batched (normalised
+    and raw entry points, with a batch large enough to leave the split-K regime), both fp32 lowerings; a read of another
+    length raises what the reference raises; through the C ABI without host lengths such a read comes back as NaN."""
+    import json
+    from riser_amd.model import Model, classify_raw_ensemble
+    from riser_amd.preprocess import pack_reads
+    g = np.load(os.path.join(golden_dir, "fc_head.npz"))
+    sd = synth.make_fc_state_dict(1)
+    config = synth.Config(synth.CnnConfig(channels=list(synth.FC_CHANNELS), kernels=[3] * 4, classifier="fc"))
+    lens, want = g["lens"], g["probs"]
+    sigs = [synth.make_signals(SIG_SEED, 1, int(L), first_read=120 + j)[0] for j, L in enumerate(lens)]
+    xs = [ro.mad_normalise(s) for s in sigs]
+    for dt in ("f32w", "f32"):
+        m = Model(sd, config, None, "x", dtype=dt, device=dev)
+        for j, x in enumerate(xs):
+            one = m.classify(x).cpu().numpy()
+            assert one.shape == (2,) and np.abs(one - want[j]).max() < 1e-3, (dt, j)
+        got = m.classify_batch(xs).cpu().numpy()
+        assert np.abs(got - want).max() < 1e-3 and np.array_equal(got[:, 1] > 0.9, want[:, 1] > 0.9)
+        sig, off, ln, lh = pack_reads(sigs * 8, dev)                         # 40 reads: three 16-read tiles, fewer K splits
+        raw = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+        assert np.abs(raw - np.tile(want, (8, 1))).max() < 1e-3
+        assert np.array_equal(raw[:5], raw[35:])                             # the same read gives the same bits in any tile
+        dec = torch.empty(len(lh), dtype=torch.uint8, device=dev)
+        ens = classify_raw_ensemble([m], sig, off, ln, lh, decision=dec, max_len=12048).cpu().numpy()
+        assert np.array_equal(ens[0], raw)
+        for L, err in json.loads(str(g["errors"])).items():
+            assert err == "RuntimeError"
+            with pytest.raises(RuntimeError):
+                m.classify(ro.mad_normalise(synth.make_signals(SIG_SEED, 1, int(L), first_read=130)[0]))
+        # a caller of the C ABI that passes no host lengths: the odd read is NaN, its neighbours are untouched
+        odd = sigs[:2] + [synth.make_signals(SIG_SEED, 1, 12064, first_read=130)[0]] + sigs[2:]
+        sig, off, ln, lh = pack_reads(odd, dev)
+        from riser_amd import _native as nv
+        import ctypes as C
+        Lb = nv.lib()
+        ws = torch.empty(Lb.rs_workspace_bytes(m._h, len(odd), 12064), dtype=torch.uint8, device=dev)
+        probs = torch.empty((len(odd), 2), dtype=torch.float32, device=dev)
+        nv.check(Lb.rs_classify(m._h, sig.data_ptr(), off.data_ptr(), ln.data_ptr(), None, len(odd), 12048, 12064,
+                                ws.data_ptr(), ws.numel(), probs.data_ptr(), None, None), "rs_classify")
+        torch.cuda.synchronize()
+        p = probs.cpu().numpy()
+        assert np.isnan(p[2]).all() and np.abs(np.delete(p, 2, axis=0) - want).max() < 1e-3
+        m.close()
     with pytest.raises(ValueError):
-        Model(synth.make_state_dict(1), synth.Config(synth.CnnConfig(classifier="fc")), None, "x", device=dev)
+        Model(sd, config, None, "x", dtype="bf16x3", device=dev)
 
 
 def test_convnet_variants_against_reference(dev, golden_dir):
@@ -431,8 +480,6 @@ def test_convnet_variants_against_reference(dev, golden_dir):
         assert np.abs(ms.classify_batch(xs).cpu().numpy() - got[: len(xs)]).max() < 1e-5
         ms.close()
         m.close()
-    with pytest.raises(ValueError):
-        Model(synth.make_state_dict(1), synth.Config(synth.CnnConfig(classifier="fc")), None, "x", device=dev)
     with pytest.raises(ValueError):                                           # even kernels: 'same' pads asymmetrically
         Model({}, synth.Config(synth.CnnConfig(channels=[4, 4], kernels=[4, 3])), None, "x", device=dev)
 

@@ -129,6 +129,21 @@ def test_gap_classifier_oracle_vs_reference(golden_dir):
             assert np.abs(ro.softmax(logits) - probs).max() < 2e-5, (name, L)
 
 
+def test_fc_classifier_oracle_vs_reference(golden_dir):
+    """the `fc` head (riser/nets/cnn.py:22-27) on the 4-layer net it is hard-coded for, against the reference's
+    Model.classify on reads of 12048 .. 12063 samples; another length fails in the first Linear, as in the reference"""
+    import json
+    g = np.load(os.path.join(golden_dir, "fc_head.npz"))
+    sd = synth.make_fc_state_dict(1)
+    for j, L in enumerate(g["lens"]):
+        sig = synth.make_signals(20260103, 1, int(L), first_read=120 + j)[0]
+        got = ro.softmax(ro.convnet_forward(sd, ro.mad_normalise(sig).astype(np.float32)[None, :]))[0]
+        assert np.abs(got - g["probs"][j]).max() < 2e-5, int(L)
+    assert set(json.loads(str(g["errors"])).values()) == {"RuntimeError"}
+    with pytest.raises(RuntimeError):
+        ro.convnet_forward(sd, np.zeros((1, 12064), dtype=np.float32))
+
+
 @pytest.fixture(scope="module")
 def net(golden_dir):
     return np.load(os.path.join(golden_dir, "network.npz"))

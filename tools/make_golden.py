@@ -10,7 +10,7 @@ own code returned for them.
 
 Reference entry points exercised:
   F1  SignalProcessor.mad_normalise          riser/preprocess.py:108-147  (F1b: float32 / float64 inputs)
-  F2  Model.classify / ConvNet.forward        riser/model.py:22-28, riser/nets/cnn.py:43-65  (F2b: depth > 1 / odd kernels; F2c: `gap` head)
+  F2  Model.classify / ConvNet.forward        riser/model.py:22-28, riser/nets/cnn.py:43-65  (F2b: depth > 1 / odd kernels; F2c: `gap` head; F2d: `fc` head)
   F3  SequencerControl.target                 riser/control.py:11-124 (fake client)
   F4  SignalProcessor.get_polyA_end           riser/preprocess.py:42-79
 """
@@ -329,6 +329,39 @@ def f2c_gap_head():
 
 
 # --------------------------------------------------------------------------------------
+def f2d_fc_head():
+    """The `fc` classifier (riser/nets/cnn.py:22-27: Flatten -> Linear(67 * 753, 4096) -> ReLU -> Linear(4096, 2)) on the
+    4-layer net it is hard-coded for, through the reference's Model.classify: reads of 12048 .. 12063 samples (753
+    positions after four pools); any other length fails in the first Linear - the error type is recorded.  Weights:
+    riser_amd.synth.make_fc_state_dict(1), rebuilt from the seed (826 MB, never stored)."""
+    sd = synth.make_fc_state_dict(1)
+    cnn = synth.CnnConfig(channels=list(synth.FC_CHANNELS), kernels=[3] * len(synth.FC_CHANNELS), classifier="fc")
+    with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as f:
+        torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, f.name)
+        path = f.name
+    try:
+        m = Model(path, synth.Config(cnn), LOG, "x")
+    finally:
+        os.unlink(path)
+    proc = SignalProcessor(Kit.create_from_version("RNA002"))
+    lens = [12048, 12048, 12050, 12063, 12048]
+    probs = []
+    for j, L in enumerate(lens):
+        sig = synth.make_signals(SIG_SEED, 1, L, first_read=120 + j)[0]
+        probs.append(m.classify(proc.mad_normalise(sig.copy())).numpy())
+    errors = {}
+    for L in (12047, 12064, 6024):
+        try:
+            m.classify(proc.mad_normalise(synth.make_signals(SIG_SEED, 1, L, first_read=130)[0].copy()))
+            errors[str(L)] = ""
+        except Exception as e:                                    # noqa: BLE001 - the type is the datum
+            errors[str(L)] = type(e).__name__
+    np.savez_compressed(os.path.join(OUT, "fc_head.npz"), lens=np.array(lens), probs=np.stack(probs),
+                        errors=np.array(json.dumps(errors)))
+    print("F2d:", np.stack(probs)[:, 1], errors)
+
+
+# --------------------------------------------------------------------------------------
 def f4_polya():
     proc = SignalProcessor(Kit.create_from_version("RNA004"))
     cases = []
@@ -419,6 +452,8 @@ if __name__ == "__main__":
         f2b_convnet_variants()
     if "f2c" in which or "f2" in which:
         f2c_gap_head()
+    if "f2d" in which or "f2" in which:
+        f2d_fc_head()
     if "f3" in which:
         f3_control()
     if "f5" in which:
