@@ -444,8 +444,12 @@ class SequencerControl:
         self._channels_seen = max(self._channels_seen, B)
         if B > self._reserved_for:                 # first batch (a flow cell's channel count), or a larger one than ever seen
             self.reserve(max(512, B))
-        reads = [e[1] for e in entries]
-        channels = np.fromiter((e[0] for e in entries), dtype=np.int64, count=B)
+        if _hp is not None and type(entries) is list:
+            channels = np.empty(B, dtype=np.int64)
+            reads = _hp.unpack(entries, channels)
+        else:
+            reads = [e[1] for e in entries]
+            channels = np.fromiter((e[0] for e in entries), dtype=np.int64, count=B)
         batch = _Batch(self.client, reads)
         t, ph[0] = self._tick(t, 0)
         self._pinned.reset(96 * B + (1 << 12))

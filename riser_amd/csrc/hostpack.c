@@ -10,6 +10,7 @@
  *   gather(reads, start_i64, out_i16) -> total   out = concat(raw[start[i]:]) in batch order (the staging buffer of the
  *                                                upload: whole reads, or only the samples the device does not hold yet)
  *   format_rows(...) -> str                      the CSV rows of riser/control.py:145-153, floats printed as repr() does
+ *   unpack(entries, channels_i64) -> list        entries = [(channel, read), ...]: the channels, and the reads as a list
  *   attrs(reads, name) -> list                   [getattr(r, name) for r in reads] (the read ids of a batch)
  *   lookup(dict, keys, out_i64)                  out[i] = dict.get(keys[i], 0) for integer values (the poly(A) cache)
  *
@@ -93,7 +94,7 @@ static void* copy_job(void* arg) {
     return NULL;
 }
 
-#define HP_MAX_THREADS 4
+#define HP_MAX_THREADS 8
 
 static PyObject* hp_gather(PyObject* self, PyObject* args) {
     PyObject *reads, *start, *out;
@@ -150,7 +151,7 @@ static PyObject* hp_gather(PyObject* self, PyObject* args) {
     if (!bad) {
         /* the views pin the exporters: the copies need no interpreter state */
         Py_BEGIN_ALLOW_THREADS
-        int nt = at > (8 << 20) ? HP_MAX_THREADS : 1;
+        int nt = at > (8 << 20) ? HP_MAX_THREADS : at > (3 << 20) ? 4 : 1;
         if (nt > n) nt = (int)(n ? n : 1);
         job_t jobs[HP_MAX_THREADS];
         pthread_t th[HP_MAX_THREADS];
@@ -317,6 +318,54 @@ static PyObject* hp_format_rows(PyObject* self, PyObject* args) {
     return res;
 }
 
+static PyObject* hp_unpack(PyObject* self, PyObject* args) {
+    PyObject *entries, *out;
+    if (!PyArg_ParseTuple(args, "OO", &entries, &out)) return NULL;
+    if (!PyList_Check(entries)) {
+        PyErr_SetString(PyExc_TypeError, "unpack: entries must be a list");
+        return NULL;
+    }
+    Py_buffer ov;
+    if (get_wbuf(out, &ov, "unpack(channels)") != 0) return NULL;
+    const Py_ssize_t n = PyList_GET_SIZE(entries);
+    PyObject* reads = NULL;
+    if (ov.len < (Py_ssize_t)(n * sizeof(int64_t))) {
+        PyErr_SetString(PyExc_ValueError, "unpack: output buffer too small");
+        goto done;
+    }
+    reads = PyList_New(n);
+    if (!reads) goto done;
+    {
+        int64_t* ch = (int64_t*)ov.buf;
+        for (Py_ssize_t i = 0; i < n; ++i) {
+            PyObject* e = PyList_GET_ITEM(entries, i);
+            PyObject *c, *r;
+            if (PyTuple_Check(e) && PyTuple_GET_SIZE(e) == 2) {
+                c = PyTuple_GET_ITEM(e, 0);
+                r = PyTuple_GET_ITEM(e, 1);
+            } else if (PyList_Check(e) && PyList_GET_SIZE(e) == 2) {
+                c = PyList_GET_ITEM(e, 0);
+                r = PyList_GET_ITEM(e, 1);
+            } else {
+                PyErr_SetString(PyExc_TypeError, "unpack: every entry must be a (channel, read) pair");
+                Py_CLEAR(reads);
+                goto done;
+            }
+            const long long v = PyLong_AsLongLong(c);
+            if (v == -1 && PyErr_Occurred()) {
+                Py_CLEAR(reads);
+                goto done;
+            }
+            ch[i] = (int64_t)v;
+            Py_INCREF(r);
+            PyList_SET_ITEM(reads, i, r);
+        }
+    }
+done:
+    PyBuffer_Release(&ov);
+    return reads;
+}
+
 static PyObject* hp_attrs(PyObject* self, PyObject* args) {
     PyObject *reads, *name;
     if (!PyArg_ParseTuple(args, "OU", &reads, &name)) return NULL;
@@ -397,6 +446,7 @@ static PyMethodDef methods[] = {
     {"lengths", hp_lengths, METH_VARARGS, "lengths(reads, out_int64): samples of every read's raw_data"},
     {"gather", hp_gather, METH_VARARGS, "gather(reads, start_int64, out_int16) -> samples written"},
     {"format_rows", hp_format_rows, METH_VARARGS, "CSV rows of one batch as one string"},
+    {"unpack", hp_unpack, METH_VARARGS, "unpack(entries, channels_int64) -> reads: splits [(channel, read), ...]"},
     {"attrs", hp_attrs, METH_VARARGS, "attrs(reads, name) -> [getattr(r, name) for r in reads]"},
     {"lookup", hp_lookup, METH_VARARGS, "lookup(dict, keys, out_int64): out[i] = dict.get(keys[i], 0)"},
     {NULL, NULL, 0, NULL}};

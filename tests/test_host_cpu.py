@@ -96,6 +96,15 @@ def test_hostpack_attrs_and_cache_lookup(hp):
     assert hp.attrs(reads, "id") == [r.id for r in reads]
     with pytest.raises(AttributeError):
         hp.attrs(reads, "no_such_attribute")
+    entries = [(7 + 3 * i, r) for i, r in enumerate(reads)]
+    channels = np.empty(len(entries), dtype=np.int64)
+    got = hp.unpack(entries, channels)
+    assert channels.tolist() == [e[0] for e in entries] and all(a is b for a, b in zip(got, reads))
+    assert hp.unpack([[1, reads[0]]], channels[:1])[0] is reads[0]
+    with pytest.raises(TypeError):
+        hp.unpack([(1, reads[0], 2)], channels)
+    with pytest.raises(ValueError):
+        hp.unpack(entries, np.empty(3, dtype=np.int64))
     ids = np.empty(len(reads), dtype=object)
     ids[:] = [r.id for r in reads]
     cache = {r.id: int(rng.integers(1, 9000)) for r in reads[::3]}
