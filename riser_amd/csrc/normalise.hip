@@ -77,8 +77,10 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot, int tid) {
 // One histogram pass over (key >> shift) with shift chosen so that at most kBins bins are
 // used; when shift > 0 (value range wider than 4096) a second pass resolves the low bits
 // inside the (at most two) selected bins.
-template <class KeyFn>
-__device__ void block_select2(KeyFn key, int n, int R, int k_lo, int k_hi, unsigned* hist, Scratch* sc,
+// KeepPrefix: when the pass was exact (shift == 0: one bin per key value) the histogram is left behind as its INCLUSIVE
+// PREFIX SUM (hist[v] = number of keys <= v) and the function returns true; the caller reads rank counts from it.
+template <bool KeepPrefix = false, class KeyFn>
+__device__ bool block_select2(KeyFn key, int n, int R, int k_lo, int k_hi, unsigned* hist, Scratch* sc,
                               int tid, int& out_lo, int& out_hi) {
     const int bits = 32 - __clz(R | 1);
     const int shift = bits > 12 ? bits - 12 : 0;
@@ -128,7 +130,16 @@ __device__ void block_select2(KeyFn key, int n, int R, int k_lo, int k_hi, unsig
     if (shift == 0) {
         out_lo = bin_lo;
         out_hi = bin_hi;
-        return;
+        if constexpr (KeepPrefix) {
+            int c = excl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                c += loc[j];
+                hist[tid * 8 + j] = (unsigned)c;
+            }
+            __syncthreads();
+        }
+        return true;
     }
     const int mask = (1 << shift) - 1;
     for (int k = 0, i = tid * chunk; k < chunk; ++k, ++i) {
@@ -153,6 +164,7 @@ __device__ void block_select2(KeyFn key, int n, int R, int k_lo, int k_hi, unsig
     out_lo = sc->result[0];
     out_hi = sc->result[1];
     __syncthreads();
+    return false;
 }
 
 // Block plan of the packed activation layout (common.hpp: BlockPlan).  Read b takes nblk(b) = len / U + 1 blocks of
@@ -340,14 +352,38 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
     // ---- median: the two middle order statistics -------------------------------------------
     const int k_lo = (n - 1) >> 1, k_hi = n >> 1;
     int m_lo, m_hi;
-    block_select2([&](int i) { return (int)sx[i] - mn; }, n, mx - mn, k_lo, k_hi, hist, sc, tid, m_lo, m_hi);
+    const bool exact_hist = block_select2<true>([&](int i) { return (int)sx[i] - mn; }, n, mx - mn, k_lo, k_hi, hist, sc, tid,
+                                                m_lo, m_hi);
     const int sum2 = m_lo + m_hi + 2 * mn;                       // 2 * median, exact
 
     RS_K1_STAMP(3);
     // ---- MAD: middle order statistics of |2x - 2 med| (integers < 2^17) --------------------
-    const int rd = max(abs(2 * mn - sum2), abs(2 * mx - sum2));
     int d_lo, d_hi;
-    block_select2([&](int i) { return abs(2 * (int)sx[i] - sum2); }, n, rd, k_lo, k_hi, hist, sc, tid, d_lo, d_hi);
+    if (exact_hist) {
+        // No second pass over the read: hist[v] = #{x - mn <= v}, and the samples within d of the median are a RANGE of
+        // values, so  #{|2x - 2 med| <= d} = hist[hi(d)] - hist[lo(d) - 1].  All deviations have the parity q of
+        // sp = m_lo + m_hi; for d = 2 e + q the range is [b - e, a + e] with a = (sp + q) / 2, b = (sp - q) / 2.  The k-th
+        // smallest deviation is the smallest d whose count exceeds k: every thread tests 8 consecutive e.
+        const int R = mx - mn, sp = m_lo + m_hi, q = sp & 1, a = (sp + q) >> 1, b2 = (sp - q) >> 1;
+        auto upto = [&](int v) { return v < 0 ? 0 : (int)hist[min(v, R)]; };
+        auto within = [&](int e) { return upto(a + e) - upto(b2 - e - 1); };
+        const int e0 = tid * 8;
+        int prev = e0 == 0 ? 0 : within(e0 - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = within(e0 + j);
+            if (c > k_lo && prev <= k_lo) sc->result[0] = 2 * (e0 + j) + q;
+            if (c > k_hi && prev <= k_hi) sc->result[1] = 2 * (e0 + j) + q;
+            prev = c;
+        }
+        __syncthreads();
+        d_lo = sc->result[0];
+        d_hi = sc->result[1];
+        __syncthreads();
+    } else {
+        const int rd = max(abs(2 * mn - sum2), abs(2 * mx - sum2));
+        block_select2([&](int i) { return abs(2 * (int)sx[i] - sum2); }, n, rd, k_lo, k_hi, hist, sc, tid, d_lo, d_hi);
+    }
     const int mad4 = d_lo + d_hi;                                // 4 * mad, exact
 
     RS_K1_STAMP(4);
