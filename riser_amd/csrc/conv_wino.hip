@@ -535,6 +535,9 @@ const Shape kShapes[] = {
     RS_SHAPE(4, 2, 2, 3), RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 1, 5), RS_SHAPE(4, 2, 1, 7), RS_SHAPE(4, 2, 1, 8),
     // 2 x 4 waves (few rows)
     RS_SHAPE(2, 4, 2, 2), RS_SHAPE(2, 4, 2, 3), RS_SHAPE(2, 4, 1, 4),
+    // small tiles (round 4): a batch of 32 ... 200 reads leaves the late layers a few dozen tiles of the shapes above
+    RS_SHAPE(8, 1, 1, 2), RS_SHAPE(8, 1, 1, 3), RS_SHAPE(8, 1, 1, 4), RS_SHAPE(4, 2, 1, 2), RS_SHAPE(4, 2, 1, 3),
+    RS_SHAPE(4, 2, 1, 4), RS_SHAPE(2, 4, 1, 2), RS_SHAPE(2, 4, 1, 1),
 };
 #undef RS_SHAPE
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);

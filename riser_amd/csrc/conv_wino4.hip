@@ -438,6 +438,8 @@ const Shape kShapes[] = {
     RS_SHAPE(8, 1, 1, 2), RS_SHAPE(8, 1, 1, 3), RS_SHAPE(8, 1, 1, 4), RS_SHAPE(8, 1, 1, 5),
     RS_SHAPE(4, 2, 1, 2), RS_SHAPE(4, 2, 1, 3), RS_SHAPE(4, 2, 1, 4), RS_SHAPE(4, 2, 2, 2),
     RS_SHAPE(2, 4, 1, 2), RS_SHAPE(2, 4, 1, 3), RS_SHAPE(2, 4, 1, 4), RS_SHAPE(2, 4, 2, 2),
+    // small tiles (round 4): a batch of 32 ... 200 reads leaves the late layers a few dozen tiles of the shapes above
+    RS_SHAPE(4, 2, 1, 1), RS_SHAPE(2, 4, 1, 1),
 };
 #undef RS_SHAPE
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);

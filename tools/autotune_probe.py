@@ -18,10 +18,13 @@ for dt in (sys.argv[1:] or ["f32w", "f16"]):
     m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dt)
     ref = m.classify_raw(sig, off, ln, lens).cpu().numpy()
     t0 = timeit(m)
+    before = m.layer_info()
     t = time.perf_counter(); changed = m.autotune(sig, off, ln, lens); torch.cuda.synchronize(); tt = time.perf_counter() - t
     got = m.classify_raw(sig, off, ln, lens).cpu().numpy()
     t1 = timeit(m); t0b = None
     info = m.layer_info()
     print(f"{dt}: {t0:.4f} ms -> {t1:.4f} ms after autotune ({changed} layers changed, tuning took {tt*1e3:.0f} ms); "
-          f"max |dp| vs before {np.abs(got - ref).max():.2e}; tiles " + " ".join(f"L{i}[{info[i]['bm']}x{info[i]['bn']}]" for i in range(1, 12)))
+          f"max |dp| vs before {np.abs(got - ref).max():.2e}; tiles " + " ".join(
+              f"L{i}[{info[i]['bm']}x{info[i]['bn']}]" + ("" if (before[i]['bm'], before[i]['bn']) == (info[i]['bm'], info[i]['bn'])
+                                                         else f"(planner {before[i]['bm']}x{before[i]['bn']})") for i in range(1, 12)))
     m.close()

@@ -6,7 +6,7 @@ import numpy as np, torch
 from riser_amd import synth
 from riser_amd.model import Model
 from riser_amd.preprocess import pack_reads
-B = int(os.environ.get("RS_B", 512)); L = 16000
+B = int(os.environ.get("RS_B", 512)); L = int(os.environ.get("RS_L", 16000))
 layers = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "4,7,9,10,11").split(",")]
 DT = sys.argv[2] if len(sys.argv) > 2 else "f32"
 W4 = DT == "f32w4"                       # F(4,3) on the listed layers (RS_WINO4), swept with RS_FORCE_SHAPE_WINO4
@@ -16,7 +16,7 @@ if W4:
 WINO4 = [(8,1,1,2),(8,1,1,3),(8,1,1,4),(8,1,1,5),(4,2,1,2),(4,2,1,3),(4,2,1,4),(4,2,2,2),(2,4,1,2),(2,4,1,3),(2,4,1,4),(2,4,2,2)]
 WINO = [(8,1,2,2),(8,1,2,3),(8,1,2,4),(8,1,1,5),(8,1,1,6),(8,1,1,7),(8,1,1,8),(4,2,2,3),(4,2,2,4),(4,2,1,5),(4,2,1,7),(4,2,1,8),(2,4,2,2),(2,4,2,3),(2,4,1,4)]
 shapes = [(8,1,4,2),(8,1,4,3),(8,1,2,5),(8,1,4,5),(8,1,2,7),(8,1,4,7),(4,2,4,2),(4,2,4,3),(4,2,2,4),(4,2,4,4),(4,2,4,5),(4,2,2,6),(4,2,4,6),(4,2,4,7),(4,2,2,8),(2,4,2,2),(2,4,2,4),(2,4,1,4),(4,2,2,5),(2,4,4,2),(8,1,2,6),(4,2,2,3)]
-sigs = synth.make_signals(20260103, 64, L); sigs = np.tile(sigs, (B // 64, 1))
+sigs = synth.make_signals(20260103, 64, L); sigs = np.tile(sigs, ((B + 63) // 64, 1))[:B]
 dev = torch.device("cuda", 0)
 sig, off, ln, lens = pack_reads(list(sigs), dev)
 m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=DT)
