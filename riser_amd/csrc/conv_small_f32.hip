@@ -336,14 +336,18 @@ int64_t conv_small_f32_waves(const ConvLayerDev& L, int64_t rows_in) {
     return ((units + 15) / 16) * (int64_t)(round_up(L.c_out, 16) / 16);
 }
 
-// Estimate in shader cycles, fitted to tools/layer_times.py at 1 / 8 / 32 reads: a wave's chain is C_in / 4 k-steps of ~200
+// Estimate in shader cycles, fitted to tools/layer_times.py at 1 ... 48 reads: a wave's chain is C_in / 4 k-steps of ~200
 // cycles (F(2,3): four waves on four SIMDs; fragment reads, transform and MFMA of a k-step are one dependent sequence) or
-// ~350 (F(4,3): six waves on four SIMDs); workgroups beyond one per CU overlap only partly (x 0.8 per further workgroup).
+// ~350 (F(4,3): six waves on four SIMDs).  A launch lasts as long as its most loaded CU: ceil(workgroups / CUs) chains,
+// of which the second and later overlap with the first only where they find an idle SIMD - not at all for the six waves
+// of F(4,3) (layer 10: 28 / 58 / 87 / 114 us at 71 / 284 / 568 / 852 workgroups), by a third for the four of F(2,3)
+// (layer 11: 24 / 39 / 56 / 72 us at 107 / 428 / 642 / 856).
 double conv_small_f32_cost(const ConvLayerDev& L, int64_t rows_in, int num_cu) {
     const double ksteps = (L.cp_in + 3) / 4;
     const double per_step = L.wino_m == 4 ? 350.0 : 200.0;
-    const double share = 0.8 * (double)conv_small_f32_waves(L, rows_in) / num_cu;
-    return ksteps * per_step * (share > 1.0 ? share : 1.0) + 6000.0;
+    const int64_t per_cu = (conv_small_f32_waves(L, rows_in) + num_cu - 1) / num_cu;
+    const double chains = 1.0 + (L.wino_m == 4 ? 1.0 : 0.65) * (double)(per_cu > 1 ? per_cu - 1 : 0);
+    return ksteps * per_step * chains + 6000.0;
 }
 
 bool conv_small_f32_ok(const ConvLayerDev& L) { return pick(L.wino_m == 4 ? 6 : 4, L.plan.kc) != nullptr; }
