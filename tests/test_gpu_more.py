@@ -445,6 +445,36 @@ def test_fc_classifier_against_reference(dev, golden_dir):
         Model(sd, config, None, "x", dtype="bf16x3", device=dev)
 
 
+def test_fc_classifier_other_shapes_against_oracle(dev):
+    """the `fc` head is not tied to 67 x 753 -> 4096 here: small nets, 1 ... 7 positions, hidden 64 / 192, batches of 1 ... 37
+    reads (one to three 16-read tiles, 16 to 5 K splits) against the oracle's Flatten -> Linear -> ReLU -> Linear"""
+    from riser_amd.model import Model
+    rng = np.random.default_rng(20260106)
+    for channels, positions, hidden in (([4, 6, 8, 10], 3, 64), ([20, 30, 45], 7, 192), ([5, 9], 1, 64)):
+        n = len(channels)
+        sd, c_in = {}, 1
+        for i, co in enumerate(channels):
+            sd[f"layers.{i}.0.weight"] = (rng.standard_normal((co, c_in, 3)) * np.sqrt(2.0 / (3 * c_in))).astype(np.float32)
+            sd[f"layers.{i}.0.bias"] = (rng.standard_normal(co) * 0.1).astype(np.float32)
+            c_in = co
+        F = c_in * positions
+        sd["classifier.1.weight"] = (rng.standard_normal((hidden, F)) * np.sqrt(2.0 / F)).astype(np.float32)
+        sd["classifier.1.bias"] = (rng.standard_normal(hidden) * 0.1).astype(np.float32)
+        sd["classifier.3.weight"] = (rng.standard_normal((2, hidden)) * np.sqrt(2.0 / hidden)).astype(np.float32)
+        sd["classifier.3.bias"] = (rng.standard_normal(2) * 0.1).astype(np.float32)
+        config = synth.Config(synth.CnnConfig(channels=channels, kernels=[3] * n, classifier="fc"))
+        m = Model(sd, config, None, "x", device=dev)
+        for B in (1, 16, 17, 37):
+            lens = rng.integers(positions << n, (positions + 1) << n, size=B)
+            xs = [rng.standard_normal(int(L)).astype(np.float32) for L in lens]
+            want = np.stack([ro.softmax(ro.convnet_forward(sd, x[None, :]))[0] for x in xs])
+            got = m.classify_batch(xs).cpu().numpy()
+            assert np.abs(got - want).max() < 1e-4, (channels, B)
+        with pytest.raises(RuntimeError):
+            m.classify(rng.standard_normal((positions + 1) << n).astype(np.float32))
+        m.close()
+
+
 def test_convnet_variants_against_reference(dev, golden_dir):
     """ConvNet configurations outside the shipped class - depth 2 / 3, kernels 5 and 7 (riser/nets/cnn.py:17,52-65) -
     run the generic MFMA conv program (csrc/seqnet.hip) behind the same Model surface: classify(signal), batched
