@@ -37,6 +37,8 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kBins = 4096;            // 8 bins per thread
 constexpr int kSubBins = 32;           // refinement pass: keys < 2^17 -> shift <= 5
 constexpr int kHeadCap = 1024;         // outlier-run heads listed in LDS per read (more: the walk scans the read instead)
+constexpr int kLongCap = 64;           // runs handed from a lane to a whole wave (longer than kLaneSteps samples)
+constexpr int kLaneSteps = 16;
 
 struct Scratch {
     int wave_tot[kWaves];
@@ -49,6 +51,8 @@ struct Scratch {
     unsigned sub[2][kSubBins];
     int dthr;
     int n_heads;                       // outlier runs found by the output pass
+    int n_long;                        // ... of which handed to a wave
+    int pad_;
     double denom;
 };
 
@@ -410,6 +414,7 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
             sc->denom = denom;
             sc->dthr = (int)(d > 0x7fffffffLL ? 0x7fffffffLL : d);
             sc->n_heads = 0;
+            sc->n_long = 0;
         }
         __syncthreads();
         const double denom = sc->denom;
@@ -439,23 +444,68 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
         // iterations on nanopore-like data - and the loop could not be pipelined around the divergent walk.)
         int* heads = reinterpret_cast<int*>(sx0 + ((lmax + 15) & ~7));
         auto is_head = [&](int i) { return i == 0 || abs(dev2(i - 1)) < dthr; };
+        // one step of riser/preprocess.py:128-147 at sample j of a run, the smoothed value of j - 1 in `prev`
+        auto step = [&](int j, double prev) -> double {
+            double nv;
+            if (j == 0) {
+                nv = yv(1);                                      // :132 (not clipped)
+            } else if (j == n - 1) {
+                nv = prev;                                       // :134 (not clipped)
+            } else {
+                nv = (prev + yv(j + 1)) * 0.5;                   // :136
+                nv = nv > 3.5 ? 3.5 : (nv < -3.5 ? -3.5 : nv);   // :141-147
+            }
+            return nv;
+        };
+        // A run LONGER than kLaneSteps (a stall, an open pore, what a fixed trim leaves of the adapter: thousands of
+        // consecutive outliers) is handed to a whole wave (below): one lane walking it was the slowest workgroup of the
+        // launch by a factor of ten (0.8 ms for a 3000-sample plateau).
+        int* long_at = heads + kHeadCap;
+        double* long_prev = reinterpret_cast<double*>(long_at + kLongCap);
         auto walk = [&](int i) {
             double prev = i > 0 ? yv(i - 1) : 0.0;
             int j = i;
+            int steps = 0;
             do {
-                double nv;
-                if (j == 0) {
-                    nv = yv(1);                                  // :132 (not clipped)
-                } else if (j == n - 1) {
-                    nv = prev;                                   // :134 (not clipped)
-                } else {
-                    nv = (prev + yv(j + 1)) * 0.5;               // :136
-                    nv = nv > 3.5 ? 3.5 : (nv < -3.5 ? -3.5 : nv);   // :141-147
+                if (++steps > kLaneSteps) {
+                    const int slot = atomicAdd(&sc->n_long, 1);
+                    if (slot < kLongCap) {
+                        long_at[slot] = j;
+                        long_prev[slot] = prev;
+                        return;
+                    }
+                    steps = -0x40000000;                         // list full: this lane walks its run to the end
                 }
+                const double nv = step(j, prev);
                 put(j, nv);
                 prev = nv;
                 ++j;
             } while (j < n && abs(dev2(j)) >= dthr);
+        };
+        // The same recurrence by a wave, every lane holding the same (j, prev).  Once the smoothed value sits AT the clip
+        // limit, it stays there for as long as the NEXT sample is an outlier of the same sign: (3.5 + y) / 2 >= 3.5 for every
+        // y > 3.5 in fp64 (the sum is >= 7 after rounding, halving is exact), clipped back to 3.5 - so such a stretch needs no
+        // arithmetic: 64 samples are tested and written per step.  Everything else is the sequential step, unchanged.
+        auto wave_walk = [&](int j, double prev) {
+            while (j < n && abs(dev2(j)) >= dthr) {
+                if (prev == 3.5 || prev == -3.5) {
+                    const int sgn = prev > 0.0 ? 1 : -1;
+                    int took;
+                    do {
+                        const int idx = j + lane;
+                        const bool ok = idx >= 1 && idx < n - 1 && sgn * dev2(min(idx + 1, n - 1)) >= dthr;
+                        const unsigned long long m = __ballot(ok);
+                        took = m == ~0ull ? 64 : __builtin_ctzll(~m);
+                        if (lane < took) put(idx, prev);
+                        j += took;
+                    } while (took == 64);
+                    if (!(j < n && abs(dev2(j)) >= dthr)) break;   // (cannot happen: sample j is still the run's, see above)
+                }
+                const double nv = step(j, prev);
+                if (lane == 0) put(j, nv);
+                prev = nv;
+                ++j;
+            }
         };
         auto list_head = [&](int i) {
             if (is_head(i)) {
@@ -506,6 +556,9 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
             for (int i = tid; i < n; i += kThreads)
                 if (abs(dev2(i)) >= dthr && is_head(i)) walk(i);
         }
+        __syncthreads();
+        const int nl = min(sc->n_long, kLongCap);
+        for (int k = w; k < nl; k += kWaves) wave_walk(long_at[k], long_prev[k]);
     }
     RS_K1_STAMP(7);
     if (o32)
@@ -530,7 +583,7 @@ int launch_normalise(const int16_t* d_sig, const int64_t* d_off, const int32_t* 
         set_error("rs_normalise: read length %d outside [1, %d]", Lmax, kMaxNormLen);
         return RS_ERR_LENGTH;
     }
-    const size_t lds = (size_t)kBins * 4 + 512 + (size_t)round_up(Lmax + 8, 8) * 2 + (size_t)kHeadCap * 4;
+    const size_t lds = (size_t)kBins * 4 + 512 + (size_t)round_up(Lmax + 8, 8) * 2 + (size_t)kHeadCap * 4 + (size_t)kLongCap * 12;
     // the > 64 KiB dynamic-LDS limit is a per-DEVICE function attribute: raise it once on every device that
     // launches the kernel (a process may hold models on several GPUs)
     static std::atomic<bool> attr_set[kMaxDevices];

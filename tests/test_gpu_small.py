@@ -146,3 +146,52 @@ def test_normalise_selects_on_hostile_long_reads(dev):
             assert not g.any()
         else:
             assert np.array_equal(g, want), (k, len(s))
+
+
+def test_normalise_long_outlier_runs(dev):
+    """Runs of hundreds to thousands of consecutive outliers (a stall, an open pore, what a fixed trim leaves of the adapter)
+    are walked by a whole wave, which skips stretches that sit at the clip limit 64 samples at a time (normalise.hip:
+    wave_walk).  Bit-exact float64 AND the fp32 rows the conv stack reads against the oracle's sequential loop: plateaus of
+    17 ... 5000 samples at 4 ... 30 MADs on either side, plateaus that change sign inside, that start the read, that end it,
+    that are interrupted by single in-range samples, two plateaus back to back, a plateau longer than half the read (it moves
+    the median) and a read with more long runs than the hand-over list holds."""
+    from riser_amd import Kit, SignalProcessor
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    rng = np.random.default_rng(31)
+
+    def base(n):
+        return np.round(rng.normal(500, 40, n))
+
+    reads = []
+    for n in (4096, 8615, 16000):
+        for length in (17, 63, 64, 65, 128, 129, 1000, 3000):
+            for level in (200, 330, 700, 1700):                       # ~ -7.5, -4.2, +5, +30 MADs of the squiggle
+                x = base(n)
+                at = int(rng.integers(10, n - length - 10))
+                x[at: at + length] = level + rng.integers(-3, 4, length)
+                reads.append(x)
+        x = base(n); x[:700] = 720; reads.append(x)                   # starts the read
+        x = base(n); x[-900:] = 310; reads.append(x)                  # ends it
+        x = base(n); x[-1:] = 900; x[-400:-1] = 705; reads.append(x)
+        x = base(n); x[1000:1500] = 700; x[1500:2100] = 300; reads.append(x)        # changes sign inside
+        x = base(n); x[1000:3000] = np.where(np.arange(2000) % 2 == 0, 700, 300); reads.append(x)   # alternates: no stretch at all
+        x = base(n); x[2000:2600] = 690; x[2100] = 500; x[2300:2302] = 505; reads.append(x)         # interrupted
+        x = base(n); x[500:900] = 700; x[901:1400] = 710; reads.append(x)           # back to back, one sample between
+        x = base(n); x[100: 100 + n // 2 + 50] = 900; reads.append(x)               # the plateau IS the median
+        x = base(n)
+        for k in range(80):                                                          # 80 runs of 20: more than the list holds
+            x[40 * k + 5: 40 * k + 25] = 700 if k % 3 else 290
+        reads.append(x)
+        x = base(n); x[300:2300] = 660 + (np.arange(2000) % 90); reads.append(x)     # a ramp across the clip region
+    sigs = [np.clip(r, -32768, 32767).astype(np.int16) for r in reads]
+    got = proc.mad_normalise_batch(sigs)
+    for k, (g, sgn) in enumerate(zip(got, sigs)):
+        assert np.array_equal(g, ro.mad_normalise(sgn)), (k, len(sgn))
+    from riser_amd.preprocess import pack_reads
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    lmax = int(lh.max())
+    rows = proc.normalise_device(sig, off, ln, len(sigs), lmax).cpu().numpy()
+    for k, sgn in enumerate(sigs):
+        assert np.array_equal(rows[k, : len(sgn)], ro.mad_normalise(sgn).astype(np.float32)), k
+        assert not rows[k, len(sgn):].any()
+
