@@ -343,6 +343,18 @@ def roofline_object(args, model, wl, conv_ms_total, conv_calls, stage_ms, detail
             "layers": per_layer}
 
 
+def _longest_run(sig: np.ndarray) -> int:
+    """longest run of consecutive |y| > 3.5 samples of a raw read after MAD normalisation (numpy; a statistic for the JSON)"""
+    x = sig.astype(np.float64)
+    med = np.median(x)
+    mad = np.median(np.abs(x - med))
+    if mad == 0:
+        return 0
+    o = np.abs((x - med) / (1.4826 * mad)) > 3.5
+    edges = np.flatnonzero(np.diff(np.concatenate([[0], o.astype(np.int8), [0]])))
+    return int((edges[1::2] - edges[0::2]).max()) if edges.size else 0
+
+
 def side_variants(args, device, wl, ref):
     """The same 512-read batch through the other arithmetic modes, the 3-model ensemble (config 3) and the mixed-length
     batch (config 5): throughput, and distance of the probabilities from the fp32 result of this run."""
@@ -451,6 +463,24 @@ def side_variants(args, device, wl, ref):
     dtl = timed(lambda: ml.classify_raw(sig, live_off, live_len, live_lens, out=pl))
     variants["live_357x8615_f32"] = {"reads_per_s": round(lb / dtl, 1), "ms_per_step": round(dtl * 1e3, 4), "batch": lb,
                                      "samples_per_read": ll}
+    # the same shape on the signals the control-loop replay carries (synth.make_raw_read: adapter + poly(A) plateau + squiggle,
+    # trimmed as riser/control.py:36-60 trims: behind the poly(A) end, or at the fixed offset when none is found - which leaves a
+    # plateau of ~3000 consecutive outliers in front of the squiggle).  Data-dependent only through the normalise kernel's walk
+    # of outlier runs (one lane per run cost such a batch 0.8 ms until round 4)
+    from riser_amd.preprocess import pack_reads
+    from riser_amd import Kit, SignalProcessor
+    whole = [synth.make_raw_read(4242, rid, 18000 + 11 * (rid % 97), polya=(rid % 5 != 0)) for rid in range(lb)]
+    kit = SignalProcessor(Kit.create_from_version("RNA004"), device=device)
+    ends = kit.get_polyA_end_batch(whole)                     # the GPU detector; -1 where the reference returns None
+    raw = []
+    for s, end in zip(whole, ends.tolist()):
+        start = min(end + 1 if end > 0 else kit.get_fixed_trim_length(), s.shape[0] - ll)
+        raw.append(np.ascontiguousarray(s[start: start + ll]))
+    rsig, roff, rln, rlh = pack_reads(raw, device)
+    dtp = timed(lambda: ml.classify_raw(rsig, roff, rln, rlh, out=pl))
+    variants["live_357x8615_f32_replay_signals"] = {"reads_per_s": round(lb / dtp, 1), "ms_per_step": round(dtp * 1e3, 4),
+                                                    "batch": lb, "samples_per_read": ll,
+                                                    "reads_with_a_run_over_1000_outliers": int(sum(_longest_run(r) > 1000 for r in raw))}
     ml.close()
     # the reference's secondary architecture (riser/nets/resnet.py; no shipped config or weights): a SquiggleNet-like
     # basic-block ResNet through the generic conv program (csrc/seqnet.hip: f32-input MFMA, weights resident in LDS)
