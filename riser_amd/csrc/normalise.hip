@@ -356,35 +356,68 @@ __global__ __launch_bounds__(kThreads) void normalise_kernel(
     // ---- median: the two middle order statistics -------------------------------------------
     const int k_lo = (n - 1) >> 1, k_hi = n >> 1;
     int m_lo, m_hi;
-    const bool exact_hist = block_select2<true>([&](int i) { return (int)sx[i] - mn; }, n, mx - mn, k_lo, k_hi, hist, sc, tid,
-                                                m_lo, m_hi);
-    const int sum2 = m_lo + m_hi + 2 * mn;                       // 2 * median, exact
+    // One bin per sample value needs a value range <= kBins.  A read with ONE spike beyond that (an open pore, a glitch) would
+    // pay the two-pass select twice over (+17 us on the launch, measured) - so such a read is histogrammed over a WINDOW of
+    // kBins values around a typical sample (the median of three), values outside clamped to the window's edge bins.  The
+    // prefix sums stay exact for every interior value (a clamped-low sample IS <= it, a clamped-high one is not), so the
+    // median and the MAD read off them are exact as long as they are found in the interior - checked, with the full-range
+    // select as the fall-back.
+    int w0 = mn, top = mx - mn;                                  // bin 0's value; the last bin whose prefix sum is exact
+    bool windowed = false;
+    bool exact_hist;
+    if (mx - mn >= kBins) {
+        const int s0 = sx[n >> 2], s1 = sx[n >> 1], s2 = sx[n - 1 - (n >> 2)];
+        const int mid = max(min(s0, s1), min(max(s0, s1), s2));
+        w0 = mid - kBins / 2;
+        windowed = true;
+        exact_hist = block_select2<true>([&](int i) { return min(max((int)sx[i] - w0, 0), kBins - 1); }, n, kBins - 1, k_lo, k_hi,
+                                         hist, sc, tid, m_lo, m_hi);
+        top = kBins - 2;
+        if (m_lo < 1 || m_hi > top) {                            // the median is not inside the window (block-uniform)
+            w0 = mn;
+            top = mx - mn;
+            windowed = false;
+            exact_hist = block_select2<true>([&](int i) { return (int)sx[i] - mn; }, n, mx - mn, k_lo, k_hi, hist, sc, tid,
+                                             m_lo, m_hi);
+        }
+    } else {
+        exact_hist = block_select2<true>([&](int i) { return (int)sx[i] - mn; }, n, mx - mn, k_lo, k_hi, hist, sc, tid, m_lo,
+                                         m_hi);
+    }
+    const int sum2 = m_lo + m_hi + 2 * w0;                       // 2 * median, exact
 
     RS_K1_STAMP(3);
     // ---- MAD: middle order statistics of |2x - 2 med| (integers < 2^17) --------------------
     int d_lo, d_hi;
+    bool mad_done = false;
     if (exact_hist) {
-        // No second pass over the read: hist[v] = #{x - mn <= v}, and the samples within d of the median are a RANGE of
+        // No second pass over the read: hist[v] = #{x - w0 <= v}, and the samples within d of the median are a RANGE of
         // values, so  #{|2x - 2 med| <= d} = hist[hi(d)] - hist[lo(d) - 1].  All deviations have the parity q of
         // sp = m_lo + m_hi; for d = 2 e + q the range is [b - e, a + e] with a = (sp + q) / 2, b = (sp - q) / 2.  The k-th
         // smallest deviation is the smallest d whose count exceeds k: every thread tests 8 consecutive e.
-        const int R = mx - mn, sp = m_lo + m_hi, q = sp & 1, a = (sp + q) >> 1, b2 = (sp - q) >> 1;
-        auto upto = [&](int v) { return v < 0 ? 0 : (int)hist[min(v, R)]; };
+        // (Windowed: a count that reaches outside the exact prefix sums can only be too LARGE, so the smallest e found is
+        // the true one whenever it lies inside; if it does not, the full-range select below takes over.)
+        const int sp = m_lo + m_hi, q = sp & 1, a = (sp + q) >> 1, b2 = (sp - q) >> 1;
+        const int last = windowed ? kBins - 1 : top;
+        auto upto = [&](int v) { return v < 0 ? 0 : (int)hist[min(v, last)]; };
         auto within = [&](int e) { return upto(a + e) - upto(b2 - e - 1); };
         const int e0 = tid * 8;
         int prev = e0 == 0 ? 0 : within(e0 - 1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = within(e0 + j);
-            if (c > k_lo && prev <= k_lo) sc->result[0] = 2 * (e0 + j) + q;
-            if (c > k_hi && prev <= k_hi) sc->result[1] = 2 * (e0 + j) + q;
+            if (c > k_lo && prev <= k_lo) sc->result[0] = e0 + j;
+            if (c > k_hi && prev <= k_hi) sc->result[1] = e0 + j;
             prev = c;
         }
         __syncthreads();
-        d_lo = sc->result[0];
-        d_hi = sc->result[1];
+        const int e_lo = sc->result[0], e_hi = sc->result[1];
         __syncthreads();
-    } else {
+        d_lo = 2 * e_lo + q;
+        d_hi = 2 * e_hi + q;
+        mad_done = !windowed || (a + e_hi <= top && b2 - e_hi - 1 >= 0);
+    }
+    if (!mad_done) {
         const int rd = max(abs(2 * mn - sum2), abs(2 * mx - sum2));
         block_select2([&](int i) { return abs(2 * (int)sx[i] - sum2); }, n, rd, k_lo, k_hi, hist, sc, tid, d_lo, d_hi);
     }

@@ -183,6 +183,13 @@ def test_normalise_long_outlier_runs(dev):
             x[40 * k + 5: 40 * k + 25] = 700 if k % 3 else 290
         reads.append(x)
         x = base(n); x[300:2300] = 660 + (np.arange(2000) % 90); reads.append(x)     # a ramp across the clip region
+        # value range > 4096 (the windowed exact histogram of the normalise kernel, and its fall-backs)
+        x = base(n); x[777] = 9000; reads.append(x)                                  # one spike
+        x = base(n); x[n >> 1] = 9000; reads.append(x)                               # ... at one of the three probe samples
+        x = base(n); x[n >> 1] = 9000; x[n >> 2] = 9100; reads.append(x)             # two probes on spikes: window misses the median
+        x = base(n); x[5] = -9000; x[9] = 12000; x[1000:1800] = 700; reads.append(x)   # spikes on both sides and a plateau
+        x = base(n); x[: n // 2 + 10] = 6000 + (np.arange(n // 2 + 10) % 5); reads.append(x)   # bulk far from the probes' window edge
+        x = base(n); x[::2] = 5000 + rng.integers(-40, 41, x[::2].shape[0]); reads.append(x)   # bimodal 4500 apart: median between the modes
     sigs = [np.clip(r, -32768, 32767).astype(np.int16) for r in reads]
     got = proc.mad_normalise_batch(sigs)
     for k, (g, sgn) in enumerate(zip(got, sigs)):
