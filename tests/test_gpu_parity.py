@@ -206,6 +206,40 @@ def test_polya_random_vs_oracle(proc):
         assert e == (-1 if w is None else w)
 
 
+def test_polya_fuzz_threshold_windows(proc):
+    """400 reads built so that the detector's decisions hang on the EXACT window statistics: every 500-sample window has a
+    MAD within a few percent of the rule's threshold (20) and a mean within a few percent of the +20 % step the start rule
+    looks for - heavy ties (values quantised to 1 ... 8 counts), constant windows, windows with int16 extremes.  A window
+    median or MAD off by one half count (the in-register sort, the sorted-window MAD formula of csrc/polya.hip) moves the
+    end index of many of them."""
+    rng = np.random.default_rng(20260108)
+    sigs = []
+    for k in range(400):
+        nw = int(rng.integers(3, 60))
+        level = float(rng.integers(300, 700))
+        parts = []
+        for w in range(nw):
+            level *= float(rng.choice([1.0, 1.0, 1.19, 1.21, 1.25, 0.8, 0.9]))
+            level = min(max(level, 150.0), 6000.0)
+            sd = 29.65 * float(rng.uniform(0.93, 1.07))                       # MAD = 0.6745 sd: 18.6 ... 21.4
+            q = int(rng.choice([1, 1, 2, 4, 8]))
+            x = np.round(rng.normal(level, sd, 500) / q) * q
+            r = rng.random()
+            if r < 0.05:
+                x[:] = np.round(level)                                        # constant window: MAD 0
+            elif r < 0.10:
+                x[rng.integers(0, 500, size=3)] = rng.choice([-32768, 32767])
+            elif r < 0.15:
+                x[:251] = np.round(level) - 20; x[251:] = np.round(level) + 21   # MAD exactly at / next to the threshold
+            parts.append(x)
+        tail = rng.normal(level, 30, int(rng.integers(0, 500)))               # a last partial window (ignored by the rule)
+        sigs.append(np.clip(np.concatenate(parts + [tail]), -32768, 32767).astype(np.int16))
+    got = proc.get_polyA_end_batch(sigs)
+    want = np.array([-1 if (e := ro.polya_end(s)) is None else e for s in sigs])
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+    assert (want > 0).sum() > 100 and (want < 0).sum() > 20                   # both outcomes are exercised
+
+
 # ------------------------------------------------------------------------------------------
 # network
 # ------------------------------------------------------------------------------------------

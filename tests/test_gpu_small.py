@@ -202,3 +202,39 @@ def test_normalise_long_outlier_runs(dev):
         assert np.array_equal(rows[k, : len(sgn)], ro.mad_normalise(sgn).astype(np.float32)), k
         assert not rows[k, len(sgn):].any()
 
+
+def test_normalise_fuzz_structured_reads(dev):
+    """600 reads with random STRUCTURE - a squiggle plus any mix of plateaus (10 ... 6000 samples, 3 ... 40 MADs off, either side),
+    spikes (in and far beyond the 4096-count window), level shifts and constant stretches - bit-exact float64 against the oracle's
+    sequential loop.  What the fixed cases of the tests above cannot enumerate: how the pieces of the normalise kernel (windowed
+    histogram and its fall-backs, run list, lane walk, wave walk and its hand-over) meet."""
+    from riser_amd import Kit, SignalProcessor
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    rng = np.random.default_rng(20260107)
+    sigs = []
+    for k in range(600):
+        n = int(rng.integers(4096, 20001))
+        sd = float(rng.choice([8, 25, 40, 90]))
+        x = np.round(rng.normal(rng.integers(300, 900), sd, n))
+        for _ in range(int(rng.integers(0, 5))):                              # plateaus
+            length = int(min(n - 2, rng.choice([10, 17, 40, 64, 65, 300, 1500, 6000])))
+            at = int(rng.integers(0, n - length))
+            x[at: at + length] = x[at: at + length].mean() + rng.choice([-1, 1]) * rng.uniform(3, 40) * sd + rng.integers(-2, 3, length)
+        for _ in range(int(rng.integers(0, 4))):                              # spikes
+            x[rng.integers(0, n, size=int(rng.integers(1, 6)))] = rng.choice([-20000, -3000, 2500, 6000, 15000, 32000])
+        if rng.random() < 0.2:                                                # a level shift for the rest of the read
+            at = int(rng.integers(1, n))
+            x[at:] += rng.choice([-1, 1]) * rng.uniform(1, 12) * sd
+        if rng.random() < 0.1:                                                # a constant stretch (ties)
+            at = int(rng.integers(0, n - 50))
+            x[at: at + int(rng.integers(50, n - at))] = np.round(x[at])
+        sigs.append(np.clip(x, -32768, 32767).astype(np.int16))
+    got, stats = proc.mad_normalise_batch(sigs, return_stats=True)
+    for k, (g, sgn) in enumerate(zip(got, sigs)):
+        med, mad = ro.median_mad(sgn)
+        assert (stats[k, 0], stats[k, 1]) == (med, mad), (k, len(sgn))
+        if mad == 0:
+            assert not g.any()
+        else:
+            assert np.array_equal(g, ro.mad_normalise(sgn)), (k, len(sgn))
+
