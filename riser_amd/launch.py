@@ -69,7 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--seeds", default="1", help="synthetic weights for the replay modes: comma list of riser_amd.synth seeds")
     ap.add_argument("--replay-script", default=None)
     ap.add_argument("--replay-synthetic", type=int, default=0, metavar="BATCHES")
-    ap.add_argument("--share-gpus", action="store_true", help="allow more ranks than visible devices (rehearsal on one GPU)")
+    ap.add_argument("--share-gpus", action="store_true", help="allow more ranks than visible devices: rank r runs on device r mod devices (2-3 channel ranges per GPU fill the device while each rank's host code runs; also: rehearsal on one GPU)")
     ap.add_argument("--no-signal-cache", action="store_true")
     ap.add_argument("--stub", action="store_true", help="no GPU: every received read becomes a 'try_again' CSV row")
     return ap.parse_args(argv)
