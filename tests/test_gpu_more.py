@@ -445,6 +445,35 @@ def test_fc_classifier_against_reference(dev, golden_dir):
         Model(sd, config, None, "x", dtype="bf16x3", device=dev)
 
 
+def test_integration_md_ctypes_stub_runs(dev, tmp_path):
+    """the ctypes stub INTEGRATION.md section 2 shows a RISER maintainer (Model.__init__ / classify and mad_normalise bound straight
+    to the C ABI) is executed as written - only the library path is filled in - and gives the oracle's probabilities and the
+    reference's float64 normalisation"""
+    import re
+    from riser_amd import _native as nv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2. Bind the C ABI directly"):]
+    code = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    assert 'C.CDLL("libriser_amd.so")' in code
+    code = code.replace('C.CDLL("libriser_amd.so")', f'C.CDLL({nv.LIB_PATH!r})')
+    ns = {}
+    torch.cuda.set_device(dev)
+    exec(compile(code, "INTEGRATION.md#2", "exec"), ns)
+    sd = synth.make_state_dict(1)
+    path = str(tmp_path / "mRNA.pth")
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, path)
+    m = ns["Model"](path, synth.Config(), None, "mRNA")
+    for first, L in ((3, 6024), (4, 16000), (5, 4096)):
+        sig = synth.make_signals(SIG_SEED, 1, L, first_read=first)[0]
+        x = ns["mad_normalise"](sig)
+        assert x.dtype == np.float64 and np.array_equal(x, ro.mad_normalise(sig))
+        p = m.classify(x)
+        assert np.abs(p.cpu().numpy() - ro.classify(sd, x)).max() < 1e-3
+    with pytest.raises(ValueError):
+        ns["mad_normalise"](np.zeros(0, dtype=np.int16))
+
+
 def test_fc_classifier_other_shapes_against_oracle(dev):
     """the `fc` head is not tied to 67 x 753 -> 4096 here: small nets, 1 ... 7 positions, hidden 64 / 192, batches of 1 ... 37
     reads (one to three 16-read tiles, 16 to 5 K splits) against the oracle's Flatten -> Linear -> ReLU -> Linear"""
