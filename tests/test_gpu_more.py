@@ -445,6 +445,34 @@ def test_fc_classifier_against_reference(dev, golden_dir):
         Model(sd, config, None, "x", dtype="bf16x3", device=dev)
 
 
+def test_split_precision_and_the_range_of_the_numbers(dev):
+    """ReLU networks are positively homogeneous: scaling layer 5's weights and bias by s and layer 6's weights by 1 / s leaves
+    the function unchanged, but moves layer 5's activations (and layer 6's weights) by s through the number formats.
+    fp32 and bf16x3 (fp32's exponent range) must not care - held to the 1e-3 tolerance at s = 1e3 and 1e5.  f16x3 is only
+    claimed INSIDE half precision's range: here it is merely required to stay finite."""
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    sigs = list(synth.make_signals(SIG_SEED, 24, 8000, first_read=500))
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    base = synth.make_state_dict(1)
+    ref = None
+    for scale in (1.0, 1e3, 1e5):
+        sd = dict(base)
+        sd["layers.5.0.weight"] = base["layers.5.0.weight"] * np.float32(scale)
+        sd["layers.5.0.bias"] = base["layers.5.0.bias"] * np.float32(scale)
+        sd["layers.6.0.weight"] = base["layers.6.0.weight"] / np.float32(scale)
+        for dt in ("f32w", "bf16x3", "f16x3"):
+            m = Model(sd, synth.Config(), None, "m", dtype=dt, device=dev)
+            p = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+            m.close()
+            if ref is None:
+                ref = p
+            assert np.isfinite(p).all(), (dt, scale)
+            if dt != "f16x3" or scale == 1.0:
+                assert np.abs(p - ref).max() < 1e-3, (dt, scale, float(np.abs(p - ref).max()))
+                assert np.array_equal(p[:, 1] > 0.9, ref[:, 1] > 0.9), (dt, scale)
+
+
 def test_integration_md_ctypes_stub_runs(dev, tmp_path):
     """the ctypes stub INTEGRATION.md section 2 shows a RISER maintainer (Model.__init__ / classify and mad_normalise bound straight
     to the C ABI) is executed as written - only the library path is filled in - and gives the oracle's probabilities and the
