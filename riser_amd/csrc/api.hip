@@ -518,6 +518,13 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             // 16-bit: panels of 32 input channels, packed [panel][tap][n_alloc][32] (conv_stream_h16.hip: layers 1-2)
             const int st16 = base16(dtype);
             const bool x3 = is_x3(dtype);
+            float ws = 1.0f;                                          // power-of-two weight scale (half precision only)
+            if (is_f16_family(dtype)) {
+                float wmax = 0.0f;
+                for (size_t k = 0; k < (size_t)L.c_out * L.c_in * 3; ++k) wmax = std::max(wmax, fabsf(conv_w[i][k]));
+                if (wmax > 0.0f && std::isfinite(wmax)) ws = ldexpf(1.0f, std::min(60, std::max(-60, 13 - ilogbf(wmax))));
+            }
+            L.w_unscale = 1.0f / ws;
             ConvPlan& p = L.plan;
             p.kc = 32;
             p.nch = (L.c_in + 31) / 32;
@@ -532,7 +539,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
                         const int pn = ci / 32, cc = ci - pn * 32;
                         for (int kw = 0; kw < 3; ++kw)
                             wp[(((size_t)pn * 3 + kw) * p.n_alloc + n) * 32 + cc] =
-                                to_h16(conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw], st16);
+                                to_h16(conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw] * ws, st16);
                     }
                 unsigned short* dw = nullptr;
                 rc = upload(&dw, wp);
@@ -546,7 +553,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
                 for (int n = 0; n < L.c_out; ++n)
                     for (int ci = 0; ci < L.c_in; ++ci)
                         for (int kw = 0; kw < 3; ++kw) {
-                            const float wv = conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw];
+                            const float wv = conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw] * ws;
                             const unsigned short hi = to_h16(wv, st16);
                             if (x3) {
                                 const int pn = ci / 32, cc = ci - pn * 32;

@@ -131,6 +131,10 @@ struct ConvLayerDev {
     int ring_panels = 0;      // panels of the ring packing: 64 channels each (plain) or 32 channels as hi | lo (x3)
     int x3_terms = 7;         // split precision, -DRS_X3_MASK measurement builds only (RS_X3_TERMS): 1 hi*hi | 2 x lo*w hi | 4 x hi*w lo
     float* d_bias;            // [n_alloc] fp32, zero padded
+    // f16 / f16x3: the packed 16-bit weights are the layer's weights x 2^k (max |w| 2^k in [8192, 16384): the LOW halves of
+    // small weights are then normal half-precision numbers instead of subnormals, and weights far below 6e-5 do not vanish);
+    // the kernels' epilogues multiply the fp32 sums by w_unscale = 2^-k - exactly - before the bias.  1 for every other mode.
+    float w_unscale = 1.0f;
     // rs_autotune: the measured-best entry of the kernel's tile-shape table per launch geometry (GEMM rows of the
     // launch -> shape index), consulted before the cost model; force_shape >= 0 overrides both while tuning
     int force_shape = -1;

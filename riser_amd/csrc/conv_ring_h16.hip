@@ -67,6 +67,7 @@ struct RingArgs {
     const unsigned short* x;     // [rows_in][cpx_in]
     const unsigned short* w;     // ring packing [panel][tap][n_alloc][64]
     const float* bias;           // [n_alloc]
+    float unscale;               // 2^-k of the packed weights' power-of-two scale (ConvLayerDev::w_unscale; 1 outside half precision)
     unsigned short* y;           // [rows_in / 2][cpx_out]
     const int32_t* len;
     unsigned x_bytes, w_bytes, y_bytes;
@@ -423,8 +424,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
             for (int j = 0; j < NT; ++j) {
                 // MaxPool, + bias, ReLU: max(a, b) + c == max(a + c, b + c) bit for bit (rounding is monotonic); the sums
                 // are canonical, so the compiler emits one v_max3_f32 instead of two canonicalising v_max + max + max
-                const float v0 = fmaxf(fmaxf(acc[i][j][0] + bias[j], acc[i][j][1] + bias[j]), 0.0f);
-                const float v1 = fmaxf(fmaxf(acc[i][j][2] + bias[j], acc[i][j][3] + bias[j]), 0.0f);
+                const float us = a.unscale;                  // fmaf(x, 1, b) == x + b bit for bit: nothing changes outside f16
+                const float v0 = fmaxf(fmaxf(fmaf(acc[i][j][0], us, bias[j]), fmaf(acc[i][j][1], us, bias[j])), 0.0f);
+                const float v1 = fmaxf(fmaxf(fmaf(acc[i][j][2], us, bias[j]), fmaf(acc[i][j][3], us, bias[j])), 0.0f);
                 const float got = swap_pair(odd ? v0 : v1);
                 const float ca = odd ? got : v0, cb_ = odd ? v1 : got;          // channels (r & ~1, r | 1) of row 2g + odd
                 const unsigned hi = pack2<F16>(ca, cb_);
@@ -668,6 +670,7 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     a.x = static_cast<const unsigned short*>(d_x);
     a.w = static_cast<const unsigned short*>(L.d_w2);
     a.bias = L.d_bias;
+    a.unscale = L.w_unscale;
     a.y = static_cast<unsigned short*>(d_y);
     a.len = d_len;
     const int64_t xb = rows64 * L.cp_in * 2, wb = (int64_t)n_panels * 3 * L.plan.n_alloc * 64 * 2;

@@ -73,6 +73,7 @@ struct StreamArgs {
     int c0;                   // FUSE0: layer-0 channels (<= 32)
     const unsigned short* w;  // packed [panel = 1][tap][n_alloc][32]; X3: ring packing [tap][n_alloc][64] = hi x 32 | lo x 32
     const float* bias;        // [n_alloc]
+    float unscale;            // 2^-k of the packed weights' power-of-two scale (ConvLayerDev::w_unscale; 1 outside half precision)
     void* y;                  // [rows_in / 2][cp_out] 16-bit
     const int32_t* len;
     unsigned x_bytes, xs_bytes, y_bytes;
@@ -392,8 +393,12 @@ __global__ __launch_bounds__(kWaves * 64, X3 ? 2 : NT == 3 ? 3 : RS_STREAM_WGS) 
             // MaxPool, + bias, ReLU: max(e, o) + b == max(e + b, o + b) bit for bit (rounding is monotonic), which is
             // two v_pk_add_f32 and one v_max3_f32 per channel pair instead of max / add / max per channel
             const f32x2 b01 = {bias[j][0], bias[j][1]}, b23 = {bias[j][2], bias[j][3]};
-            const f32x2 e01 = (f32x2){acc[0][j][0], acc[0][j][1]} + b01, e23 = (f32x2){acc[0][j][2], acc[0][j][3]} + b23;
-            const f32x2 o01 = (f32x2){acc[1][j][0], acc[1][j][1]} + b01, o23 = (f32x2){acc[1][j][2], acc[1][j][3]} + b23;
+            // x * unscale + b in one rounding (v_pk_fma_f32); unscale = 1 outside half precision: the plain sum, bit for bit
+            const f32x2 us = {a.unscale, a.unscale};
+            const f32x2 e01 = __builtin_elementwise_fma((f32x2){acc[0][j][0], acc[0][j][1]}, us, b01),
+                        e23 = __builtin_elementwise_fma((f32x2){acc[0][j][2], acc[0][j][3]}, us, b23);
+            const f32x2 o01 = __builtin_elementwise_fma((f32x2){acc[1][j][0], acc[1][j][1]}, us, b01),
+                        o23 = __builtin_elementwise_fma((f32x2){acc[1][j][2], acc[1][j][3]}, us, b23);
             const float p0 = fmaxf(fmaxf(e01[0], o01[0]), 0.0f), p1 = fmaxf(fmaxf(e01[1], o01[1]), 0.0f);
             const float p2 = fmaxf(fmaxf(e23[0], o23[0]), 0.0f), p3 = fmaxf(fmaxf(e23[1], o23[1]), 0.0f);
             hi[j] = (u32x2){pack2<F16>(p0, p1), pack2<F16>(p2, p3)};
@@ -477,6 +482,7 @@ struct Stream2Args {
     int c0;
     const unsigned short* w1; // layer 1: [tap][n_alloc1][32]; X3: [tap][n_alloc1][64] = hi x 32 | lo x 32
     const float* bias1;
+    float unscale1, unscale2; // as StreamArgs::unscale, layers 1 and 2
     int n_alloc1;
     const unsigned short* w2; // layer 2, same packing
     const float* bias2;
@@ -626,7 +632,7 @@ __global__ __launch_bounds__((X3 ? 8 : 4) * 64, X3 ? 1 : 3) void conv_stream012_
     // ---- a conv block: 16 pooled outputs of block v from the 34 ring rows 32v - 1 .. 32v + 32 ------------
     const unsigned ring_r = (unsigned)(2 * r * ROWP + (kq << 4));
     auto block = [&](const unsigned char* ring, int v, const SubInfo& si, auto MASKED, auto NTc, const auto& whi, const auto& wlo,
-                     const auto& bias, auto&& sink) {
+                     const auto& bias, const float unscale, auto&& sink) {
         constexpr bool masked = decltype(MASKED)::value;
         constexpr int NT = decltype(NTc)::value;
         constexpr int NTP = X3 ? 2 * ((NT + 1) / 2) : NT;
@@ -667,8 +673,11 @@ __global__ __launch_bounds__((X3 ? 8 : 4) * 64, X3 ? 1 : 3) void conv_stream012_
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const f32x2 b01 = {bias[j][0], bias[j][1]}, b23 = {bias[j][2], bias[j][3]};
-            const f32x2 e01 = (f32x2){acc[0][j][0], acc[0][j][1]} + b01, e23 = (f32x2){acc[0][j][2], acc[0][j][3]} + b23;
-            const f32x2 o01 = (f32x2){acc[1][j][0], acc[1][j][1]} + b01, o23 = (f32x2){acc[1][j][2], acc[1][j][3]} + b23;
+            const f32x2 us = {unscale, unscale};
+            const f32x2 e01 = __builtin_elementwise_fma((f32x2){acc[0][j][0], acc[0][j][1]}, us, b01),
+                        e23 = __builtin_elementwise_fma((f32x2){acc[0][j][2], acc[0][j][3]}, us, b23);
+            const f32x2 o01 = __builtin_elementwise_fma((f32x2){acc[1][j][0], acc[1][j][1]}, us, b01),
+                        o23 = __builtin_elementwise_fma((f32x2){acc[1][j][2], acc[1][j][3]}, us, b23);
             const float p0 = fmaxf(fmaxf(e01[0], o01[0]), 0.0f), p1 = fmaxf(fmaxf(e01[1], o01[1]), 0.0f);
             const float p2 = fmaxf(fmaxf(e23[0], o23[0]), 0.0f), p3 = fmaxf(fmaxf(e23[1], o23[1]), 0.0f);
             hi[j] = (u32x2){pack2<F16>(p0, p1), pack2<F16>(p2, p3)};
@@ -684,7 +693,7 @@ __global__ __launch_bounds__((X3 ? 8 : 4) * 64, X3 ? 1 : 3) void conv_stream012_
     auto w1hi = [&](int t, int j) -> const u32x4& { return wf1[0][t][j]; };
     auto w1lo = [&](int t, int j) -> const u32x4& { return wf1[NH - 1][t][j]; };
     auto block1 = [&](int v, const SubInfo& si, auto MASKED) {
-        block(ring1, v, si, MASKED, std::integral_constant<int, NT1>{}, w1hi, w1lo, bias1, [&](const auto& hi, const auto& lo) {
+        block(ring1, v, si, MASKED, std::integral_constant<int, NT1>{}, w1hi, w1lo, bias1, a.unscale1, [&](const auto& hi, const auto& lo) {
             Row row;
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
@@ -724,7 +733,7 @@ __global__ __launch_bounds__((X3 ? 8 : 4) * 64, X3 ? 1 : 3) void conv_stream012_
                 }
         }
         auto w2l = [&](int t, int j) -> const u32x4& { return wl[t][j]; };
-        block(ring2, v, si, MASKED, std::integral_constant<int, NT2>{}, w2hi, w2l, bias2, [&](const auto& hi, const auto& lo) {
+        block(ring2, v, si, MASKED, std::integral_constant<int, NT2>{}, w2hi, w2l, bias2, a.unscale2, [&](const auto& hi, const auto& lo) {
             const unsigned base = v < a.n_sub ? (unsigned)v * blk_bytes : kOob;
 #pragma unroll
             for (int j = 0; j + 1 < NTP2; j += 2) {
@@ -856,6 +865,7 @@ int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, co
         return RS_ERR_ARG;
     }
     a.bias = L.d_bias;
+    a.unscale = L.w_unscale;
     a.y = d_y;
     a.len = d_len;
     a.x_bytes = (unsigned)xb;
@@ -910,6 +920,8 @@ int launch_conv_stream012_h16(const ConvLayerDev& L1, const ConvLayerDev& L2, co
         return RS_ERR_ARG;
     }
     a.bias1 = L1.d_bias;
+    a.unscale1 = L1.w_unscale;
+    a.unscale2 = L2.w_unscale;
     a.bias2 = L2.d_bias;
     a.n_alloc1 = L1.plan.n_alloc;
     a.n_alloc2 = L2.plan.n_alloc;

@@ -42,6 +42,7 @@ struct WresArgs {
     const unsigned short* x;     // [rows_in][cpx_in]
     const unsigned short* w;     // ring packing [panel][tap][n_alloc][64]
     const float* bias;           // [n_alloc]
+    float unscale;               // as RingArgs::unscale
     unsigned short* y;           // [rows_in / 2][cpx_out]
     const int32_t* len;
     unsigned x_bytes, w_bytes, y_bytes;
@@ -234,8 +235,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wres_h16_kernel(const WresAr
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const float v0 = fmaxf(fmaxf(acc[i][j][0] + bias[j], acc[i][j][1] + bias[j]), 0.0f);
-                const float v1 = fmaxf(fmaxf(acc[i][j][2] + bias[j], acc[i][j][3] + bias[j]), 0.0f);
+                const float us = a.unscale;
+                const float v0 = fmaxf(fmaxf(fmaf(acc[i][j][0], us, bias[j]), fmaf(acc[i][j][1], us, bias[j])), 0.0f);
+                const float v1 = fmaxf(fmaxf(fmaf(acc[i][j][2], us, bias[j]), fmaf(acc[i][j][3], us, bias[j])), 0.0f);
                 const float got = swap_pair(odd ? v0 : v1);
                 const float ca = odd ? got : v0, cb_ = odd ? v1 : got;
                 const unsigned hi = pack2<F16>(ca, cb_);
@@ -395,6 +397,7 @@ int launch_conv_wres_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     a.x = static_cast<const unsigned short*>(d_x);
     a.w = static_cast<const unsigned short*>(L.d_w2);
     a.bias = L.d_bias;
+    a.unscale = L.w_unscale;
     a.y = static_cast<unsigned short*>(d_y);
     a.len = d_len;
     a.x_bytes = (unsigned)xb;

@@ -448,8 +448,10 @@ def test_fc_classifier_against_reference(dev, golden_dir):
 def test_split_precision_and_the_range_of_the_numbers(dev):
     """ReLU networks are positively homogeneous: scaling layer 5's weights and bias by s and layer 6's weights by 1 / s leaves
     the function unchanged, but moves layer 5's activations (and layer 6's weights) by s through the number formats.
-    fp32 and bf16x3 (fp32's exponent range) must not care - held to the 1e-3 tolerance at s = 1e3 and 1e5.  f16x3 is only
-    claimed INSIDE half precision's range: here it is merely required to stay finite."""
+    fp32 and bf16x3 (fp32's exponent range) must not care - held to the 1e-3 tolerance at s = 1e3 and 1e5.  f16x3 packs its
+    weights with a power-of-two scale per layer (ConvLayerDev::w_unscale), so SMALL weights cost it nothing: held to 1e-4 at
+    s = 1e3 (1.8e-3 before the scale); its activations must stay below 65504: at s = 1e5 it is merely
+    required to stay finite."""
     from riser_amd.model import Model
     from riser_amd.preprocess import pack_reads
     sigs = list(synth.make_signals(SIG_SEED, 24, 8000, first_read=500))
@@ -468,8 +470,8 @@ def test_split_precision_and_the_range_of_the_numbers(dev):
             if ref is None:
                 ref = p
             assert np.isfinite(p).all(), (dt, scale)
-            if dt != "f16x3" or scale == 1.0:
-                assert np.abs(p - ref).max() < 1e-3, (dt, scale, float(np.abs(p - ref).max()))
+            if dt != "f16x3" or scale <= 1e3:
+                assert np.abs(p - ref).max() < (1e-4 if dt == "f16x3" else 1e-3), (dt, scale, float(np.abs(p - ref).max()))
                 assert np.array_equal(p[:, 1] > 0.9, ref[:, 1] > 0.9), (dt, scale)
 
 
