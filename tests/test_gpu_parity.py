@@ -358,6 +358,9 @@ def test_small_custom_network(dev):
 #                   (measured 7e-3 / 6e-2 worst over 512 reads) and are tested against their own measured envelope.
 # ------------------------------------------------------------------------------------------
 X3_TOL = 1e-3                                # north_star
+# what the split-precision modes achieve on these weights (a regression guard, not the specification): bf16x3 carries 16
+# mantissa bits, f16x3 22 - all of them since its weights are packed with a power-of-two scale (round 4: 3.5e-5 before)
+X3_ACHIEVED = {"bf16x3": 3e-4, "f16x3": 3e-5}
 H16_TOL = {"f16": 2e-2, "bf16": 1.5e-1, "bf16x3": X3_TOL, "f16x3": X3_TOL}
 
 
@@ -388,6 +391,7 @@ def test_split_precision_forward_vs_reference(dev, golden_dir, dtype):
             assert err < X3_TOL, (tag, err)
             assert np.array_equal(got[:, 1] > 0.9, want[:, 1] > 0.9), tag
     print(f"{dtype}: worst |dp| {worst:.2e} over the golden cases, no label differs")
+    assert worst < X3_ACHIEVED[dtype], (dtype, worst)
     for m in models.values():
         m.close()
 
@@ -416,7 +420,7 @@ def test_split_precision_full_size_batch(dev, dtype):
         assert np.abs(got - oracle).max() < X3_TOL, (name, float(np.abs(got - oracle).max()))
         assert np.array_equal(got[:, 1] > 0.9, oracle[:, 1] > 0.9), name
         want = ref.classify_raw(sig, off, ln, lens).cpu().numpy()
-        assert np.abs(got - want).max() < X3_TOL, (name, float(np.abs(got - want).max()))
+        assert np.abs(got - want).max() < X3_ACHIEVED[dtype], (name, float(np.abs(got - want).max()))
         assert np.array_equal(got, m.classify_raw(sig, off, ln, lens).cpu().numpy())
         idx = torch.arange(100, 164, device=dev)
         part = m.classify_raw(sig, off[idx].contiguous(), ln[idx].contiguous(), lens[100:164]).cpu().numpy()
