@@ -475,6 +475,25 @@ def test_split_precision_and_the_range_of_the_numbers(dev):
                 assert np.array_equal(p[:, 1] > 0.9, ref[:, 1] > 0.9), (dt, scale)
 
 
+def test_activation_range_check(dev):
+    """riser_amd.rangecheck: per-layer activation maxima of the fp32 path on sample reads - the evidence for choosing f16x3
+    (half precision's range) or bf16x3.  On the calibrated weights every layer is far inside 65504; with layer 5 scaled by
+    1e5 (the same function: layer 6 undoes it) layer 5's maximum is 1e5 times larger and the verdict says bf16x3."""
+    from riser_amd import rangecheck
+    base = synth.make_state_dict(1)
+    sigs = [synth.make_signals(SIG_SEED, 1, 6000 + 100 * i, first_read=700 + i)[0] for i in range(8)]
+    mx = rangecheck.activation_range(base, signals=sigs, device=dev)
+    assert len(mx) == 11 and all(0 < v < 5000 for v in mx)
+    assert "safe" in rangecheck.verdict(mx)
+    sd = dict(base)
+    sd["layers.5.0.weight"] = base["layers.5.0.weight"] * np.float32(1e5)
+    sd["layers.5.0.bias"] = base["layers.5.0.bias"] * np.float32(1e5)
+    sd["layers.6.0.weight"] = base["layers.6.0.weight"] / np.float32(1e5)
+    big = rangecheck.activation_range(sd, signals=sigs, device=dev)
+    assert abs(big[4] / mx[4] / 1e5 - 1) < 1e-3 and abs(big[5] / mx[5] - 1) < 1e-3      # list index = layer - 1
+    assert "bf16x3" in rangecheck.verdict(big) and big[4] > 65504
+
+
 def test_integration_md_ctypes_stub_runs(dev, tmp_path):
     """the ctypes stub INTEGRATION.md section 2 shows a RISER maintainer (Model.__init__ / classify and mad_normalise bound straight
     to the C ABI) is executed as written - only the library path is filled in - and gives the oracle's probabilities and the
