@@ -259,6 +259,22 @@ RS_API int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_
                  int32_t* d_end, void* stream);
 
 /*
+ * ABI 2.2.  The same detector, RESUMABLE: for a caller that sees a read again, longer, with an unchanged prefix (a read that
+ * stays in its pore between two ReadUntil batches; riser/control.py:53 re-scans it from its first sample each time).
+ * The detector's state after W whole 500-sample windows without an end - W, the `start` index, the sums of the last two
+ * windows - depends on the read's first 500 W samples only:
+ *   d_state_in   int32 [B][4] (windows done, start, sum of window W - 2, sum of window W - 1) as a previous call returned
+ *                it for the SAME read, all zeros for a read seen for the first time, or NULL (= all zeros for every read);
+ *                a state whose window count exceeds the read's is ignored (the read is scanned whole)
+ *   d_state_out  int32 [B][4]: the state after this scan; for a read whose end is found, its input state unchanged
+ *                (resumed from it the scan finds the same end).  Must not be d_state_in.
+ * d_end as rs_polya_end: the results are identical to a scan from the first sample.  The caller answers for the prefix being
+ * unchanged (riser_amd's control loop: the signal store's verified delta path).
+ */
+RS_API int rs_polya_end_resume(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B,
+                        const int32_t* d_state_in, int32_t* d_end, int32_t* d_state_out, void* stream);
+
+/*
  * Scatter n segments of raw samples between device buffers: segment k = d_src[d_src_off[k] .. + d_len[k]) is copied to
  * d_dst[d_dst_off[k] ..) (offsets in samples).  The batched control loop keeps the raw signal of every read in flight
  * resident on the device: an AccumulatingCache client (riser/client.py:29-31) re-sends a read's whole signal with every

@@ -1187,6 +1187,19 @@ int rs_polya_end(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_le
     return launch_polya(d_sig, d_off, d_len, B, d_end, static_cast<hipStream_t>(stream));
 }
 
+int rs_polya_end_resume(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, const int32_t* d_state_in,
+                        int32_t* d_end, int32_t* d_state_out, void* stream) {
+    if (B < 0 || (B > 0 && (!d_sig || !d_off || !d_len || !d_end || !d_state_out))) {
+        set_error("rs_polya_end_resume: null argument");
+        return RS_ERR_ARG;
+    }
+    if (B > 0 && d_state_in == d_state_out) {
+        set_error("rs_polya_end_resume: d_state_in and d_state_out must not be the same buffer");
+        return RS_ERR_ARG;
+    }
+    return launch_polya(d_sig, d_off, d_len, B, d_end, static_cast<hipStream_t>(stream), d_state_in, d_state_out);
+}
+
 int rs_copy_segments(const int16_t* d_src, int16_t* d_dst, const int64_t* d_src_off, const int64_t* d_dst_off,
                      const int32_t* d_len, int n, void* stream) {
     if (n < 0 || (n > 0 && (!d_src || !d_dst || !d_src_off || !d_dst_off || !d_len))) {

@@ -230,8 +230,8 @@ int launch_fc_head(const float* d_act, int cp, int P_last, int n_layers, const i
 int launch_decide(const float* d_probs, int n_models, int B, const int32_t* d_len, int max_len,
                   float thr, int mode, uint8_t* d_out, hipStream_t st);
 
-int launch_polya(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B,
-                 int32_t* d_end, hipStream_t st);
+int launch_polya(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int32_t* d_end, hipStream_t st,
+                 const int32_t* d_state_in = nullptr, int32_t* d_state_out = nullptr);
 int launch_copy_segments(const int16_t* d_src, int16_t* d_dst, const int64_t* d_src_off, const int64_t* d_dst_off,
                          const int32_t* d_len, int n, hipStream_t st);
 

@@ -76,8 +76,16 @@ __device__ __forceinline__ void sort512(int (&v)[8], int lane) {
 // pass, carrying (start, end) and the sums of the last two windows (the 1000-sample rolling mean) into the next one.
 // Once an end is found nothing later can change it (riser/preprocess.py:66 sets it only while it is None), so the
 // scan stops there.
+//
+// RESUMING a scan.  A read that stays in its pore comes back longer with every batch, and as long as no end has been found the
+// reference scans it again from its first sample.  But the detector's state after W whole windows - W, `start`, the sums of
+// the last two windows - is a function of the read's first 500 W samples alone, so a caller that knows the prefix is
+// unchanged hands the state of the previous scan back (st_in, four ints per read: windows done, start, the two sums) and
+// only the new windows are sorted.  st_out receives the state after this scan; a scan that FINDS an end hands its input state
+// back unchanged (resumed again it finds the same end).  Both NULL: every read from its first sample, nothing kept.
 __global__ __launch_bounds__(256) void polya_kernel(const int16_t* __restrict__ sig, const int64_t* __restrict__ off,
-                                                    const int32_t* __restrict__ len, int32_t* __restrict__ out) {
+                                                    const int32_t* __restrict__ len, int32_t* __restrict__ out,
+                                                    const int32_t* __restrict__ st_in, int32_t* __restrict__ st_out) {
     __shared__ int keys[4][512];
     __shared__ int wsum[kChunkWin + 2];            // [0], [1]: the two windows before the pass
     __shared__ int wmad4[kChunkWin];
@@ -87,12 +95,17 @@ __global__ __launch_bounds__(256) void polya_kernel(const int16_t* __restrict__ 
     const int16_t* src = sig + off[b];
     const int nw = n / kWin;
     int* K = keys[wave];
+    // windows already scanned (0 < w0 <= nw, else the state is not this read's: start over)
+    int w0 = st_in ? st_in[4 * b] : 0;
+    if (w0 < 0 || w0 > nw) w0 = 0;
     if (tid == 0) {
-        state[0] = -1;
+        state[0] = w0 > 0 ? st_in[4 * b + 1] : -1;
         state[1] = -1;
+        wsum[0] = w0 > 0 ? st_in[4 * b + 2] : 0;
+        wsum[1] = w0 > 0 ? st_in[4 * b + 3] : 0;
     }
     __syncthreads();
-    for (int c0 = 0; c0 < nw; c0 += kChunkWin) {
+    for (int c0 = w0; c0 < nw; c0 += kChunkWin) {
         const int cn = min(kChunkWin, nw - c0);
         for (int w0 = 0; w0 < cn; w0 += 4) {
             const int wl = w0 + wave;                              // window of this wave inside the pass
@@ -155,15 +168,22 @@ __global__ __launch_bounds__(256) void polya_kernel(const int16_t* __restrict__ 
             }
             state[0] = start;
             state[1] = end;
-            if (cn >= 2) {
-                wsum[0] = wsum[cn];
-                wsum[1] = wsum[cn + 1];
-            }
+            wsum[0] = wsum[cn];                                    // the sums of the last two windows seen so far (cn >= 1)
+            wsum[1] = wsum[cn + 1];
         }
         __syncthreads();
         if (state[1] > 0) break;
     }
-    if (tid == 0) out[b] = state[1] > 0 ? state[1] : -1;
+    if (tid == 0) {
+        out[b] = state[1] > 0 ? state[1] : -1;
+        if (st_out) {
+            const bool found = state[1] > 0;
+            st_out[4 * b + 0] = found ? w0 : nw;
+            st_out[4 * b + 1] = found ? (w0 > 0 ? st_in[4 * b + 1] : -1) : state[0];
+            st_out[4 * b + 2] = found ? (w0 > 0 ? st_in[4 * b + 2] : 0) : wsum[0];
+            st_out[4 * b + 3] = found ? (w0 > 0 ? st_in[4 * b + 3] : 0) : wsum[1];
+        }
+    }
 }
 
 // segment k: src[src_off[k] .. + len[k]) -> dst[dst_off[k] ..); one workgroup per segment, 2-byte elements (the segments
@@ -190,9 +210,9 @@ int launch_copy_segments(const int16_t* d_src, int16_t* d_dst, const int64_t* d_
 }
 
 int launch_polya(const int16_t* d_sig, const int64_t* d_off, const int32_t* d_len, int B, int32_t* d_end,
-                 hipStream_t st) {
+                 hipStream_t st, const int32_t* d_state_in, int32_t* d_state_out) {
     if (B <= 0) return RS_OK;
-    hipLaunchKernelGGL(polya_kernel, dim3(B), dim3(256), 0, st, d_sig, d_off, d_len, d_end);
+    hipLaunchKernelGGL(polya_kernel, dim3(B), dim3(256), 0, st, d_sig, d_off, d_len, d_end, d_state_in, d_state_out);
     RS_HIP(hipGetLastError());
     return RS_OK;
 }

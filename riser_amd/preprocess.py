@@ -110,11 +110,19 @@ class SignalProcessor:
         sig, off, ln, lens = pack_reads(signals, self.device)
         return self.polyA_end_device(sig, off, ln, len(signals)).cpu().numpy()
 
-    def polyA_end_device(self, sig, off, ln, B) -> torch.Tensor:
+    def polyA_end_device(self, sig, off, ln, B, state_in: torch.Tensor = None):
+        """-> int32 [B] ends on the device (-1: none).  With `state_in` (int32 [B, 4] on the device: the state a previous scan
+        of the SAME reads returned, zeros for new ones) only the windows not yet scanned are: -> (ends, state_out)."""
         out = torch.empty(B, dtype=torch.int32, device=self.device)
-        nv.check(nv.lib().rs_polya_end(sig.data_ptr(), off.data_ptr(), ln.data_ptr(), B, out.data_ptr(),
-                                       torch.cuda.current_stream(self.device).cuda_stream), "rs_polya_end")
-        return out
+        if state_in is None:
+            nv.check(nv.lib().rs_polya_end(sig.data_ptr(), off.data_ptr(), ln.data_ptr(), B, out.data_ptr(),
+                                           torch.cuda.current_stream(self.device).cuda_stream), "rs_polya_end")
+            return out
+        state_out = torch.empty((B, 4), dtype=torch.int32, device=self.device)
+        nv.check(nv.lib().rs_polya_end_resume(sig.data_ptr(), off.data_ptr(), ln.data_ptr(), B, state_in.data_ptr(),
+                                              out.data_ptr(), state_out.data_ptr(),
+                                              torch.cuda.current_stream(self.device).cuda_stream), "rs_polya_end_resume")
+        return out, state_out
 
     def trim_polyA(self, signal, read_id, cache):
         """-> (signal without adapter + poly(A), True) when a poly(A) end is known for the read, else (signal, False)

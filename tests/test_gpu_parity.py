@@ -206,6 +206,47 @@ def test_polya_random_vs_oracle(proc):
         assert e == (-1 if w is None else w)
 
 
+def test_polya_resume_equals_full_scan(proc, dev):
+    """rs_polya_end_resume: 160 reads seen again and again, longer each time (300 ... 2600 more samples per visit, as a read
+    that stays in its pore between ReadUntil batches) - scanning only the new windows from the state of the previous visit
+    gives, at EVERY visit, the end the oracle finds on the whole prefix, and the state a scan from the first sample returns.
+    Reads with and without a poly(A), threshold-riding windows (the fuzz generator), visits that add less than one window,
+    a state that belongs to a longer read (ignored), and reads past the kernel's 128-window table."""
+    from riser_amd.preprocess import pack_reads
+    rng = np.random.default_rng(20260109)
+    reads = [synth.make_raw_read(977, i, int(rng.integers(3000, 30000)), bool(i % 4)) for i in range(120)]
+    for k in range(36):                                                       # windows whose MAD / mean ride the thresholds
+        level, parts = float(rng.integers(300, 700)), []
+        for w in range(int(rng.integers(6, 50))):
+            level = min(max(level * float(rng.choice([1.0, 1.0, 1.21, 1.25, 0.8])), 150.0), 6000.0)
+            parts.append(np.round(rng.normal(level, 29.65 * float(rng.uniform(0.93, 1.07)), 500)))
+        reads.append(np.clip(np.concatenate(parts), -32768, 32767).astype(np.int16))
+    reads += [synth.make_raw_read(978, i, 70000 + 777 * i, bool(i % 2)) for i in range(4)]   # > 128 windows
+    B = len(reads)
+    seen = np.array([int(rng.integers(200, 1500)) for _ in reads])
+    state = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+    for visit in range(14):
+        pre = [r[:n] for r, n in zip(reads, seen)]
+        sig, off, ln, _ = pack_reads(pre, dev)
+        ends, state_out = proc.polyA_end_device(sig, off, ln, B, state_in=state)
+        full, state_full = proc.polyA_end_device(sig, off, ln, B, state_in=torch.zeros_like(state))
+        ends = ends.cpu().numpy()
+        want = np.array([-1 if (e := ro.polya_end(p)) is None else e for p in pre])
+        assert np.array_equal(ends, want), (visit, np.flatnonzero(ends != want)[:8])
+        assert np.array_equal(full.cpu().numpy(), want)
+        none = want < 0                                                       # the state is only defined while no end is found
+        assert torch.equal(state_out[torch.from_numpy(none).to(dev)], state_full[torch.from_numpy(none).to(dev)]), visit
+        assert np.array_equal(state_out.cpu().numpy()[none, 0], (seen // 500)[none])
+        state = state_out
+        seen = np.minimum(seen + rng.integers(300, 2600, size=B) * (rng.random(B) < 0.85), [len(r) for r in reads])
+    # a state that claims more windows than the read has is not the read's: scanned whole
+    pre = [r[:1700] for r in reads[:8]]
+    sig, off, ln, _ = pack_reads(pre, dev)
+    bogus = torch.tensor([[40, 1500, 1, 1]] * 8, dtype=torch.int32, device=dev)
+    ends, _ = proc.polyA_end_device(sig, off, ln, 8, state_in=bogus)
+    assert np.array_equal(ends.cpu().numpy(), [-1 if (e := ro.polya_end(p)) is None else e for p in pre])
+
+
 def test_polya_fuzz_threshold_windows(proc):
     """400 reads built so that the detector's decisions hang on the EXACT window statistics: every 500-sample window has a
     MAD within a few percent of the rule's threshold (20) and a mean within a few percent of the +20 % step the start rule
