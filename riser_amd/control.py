@@ -190,6 +190,8 @@ class _SignalStore:
         self.row_id = np.empty(0, dtype=object)                  # id of the read a row holds
         self.row_have = np.zeros(0, dtype=np.int64)              # samples of it on the device
         self.row_tail = np.zeros((0, self.TAIL), dtype=np.int16)  # the last TAIL of them
+        self.row_pa = np.zeros((0, 4), dtype=np.int32)           # poly(A) scan state of the read (rs_polya_end_resume)
+        self.last_rows = self.last_delta = None                  # of the slice update() saw last: rows, delta-path mask
         self.cap_rows = 0
         self.spill_cap = 0
         self.buf = None                                          # int16 [cap_rows * pitch + spill_cap]
@@ -247,6 +249,7 @@ class _SignalStore:
             self.row_id = np.concatenate([self.row_id, np.full(uniq.size, None, dtype=object)])
             self.row_have = np.concatenate([self.row_have, np.zeros(uniq.size, dtype=np.int64)])
             self.row_tail = np.concatenate([self.row_tail, np.zeros((uniq.size, self.TAIL), dtype=np.int16)])
+            self.row_pa = np.concatenate([self.row_pa, np.zeros((uniq.size, 4), dtype=np.int32)])
             rows = self.rowmap[channels]
         return rows
 
@@ -292,6 +295,7 @@ class _SignalStore:
         if self._uploaded is None:
             self._uploaded = torch.cuda.Event()
         self._uploaded.synchronize()
+        self.last_rows = self.last_delta = None
         if not self.resident:
             offs = np.zeros(B, dtype=np.int64)
             np.cumsum(lens[:-1], out=offs[1:])
@@ -328,6 +332,7 @@ class _SignalStore:
             self.mismatches += int((~ok).sum())
         n_reseen, n_delta = int(reseen.sum()), int(cand.sum())
         self.delta_reads += n_delta
+        self.last_rows, self.last_delta = rows, cand             # a delta read's prefix is what the row held: scans may resume
         # reads longer than a row: whole, into the spill area, nothing remembered
         spill_len = np.where(fits, 0, lens)
         spill_off = np.zeros(B, dtype=np.int64)
@@ -392,7 +397,7 @@ class SequencerControl:
         self.batch_phases = deque(maxlen=4096)
         self._store = _SignalStore(processor.device, resident=signal_cache, logger=logger)
         self._pinned = _Pinned(processor.device)
-        self._res_probs = self._res_dec = self._polya_host = None
+        self._res_probs = self._res_dec = self._polya_host = self._polya_state_host = None
         self._pa_events = []                      # one per slice: the poly(A) scan's result is in pinned memory
         self._side, self._events = None, []       # PromethION-scale batches: the upload / poly(A) stream of the slice pipeline
         self._channels_seen = 0
@@ -424,6 +429,7 @@ class SequencerControl:
             self._res_dec = _Pair(torch.empty(cap, dtype=torch.uint8, device=dev),
                                   torch.empty(cap, dtype=torch.uint8).pin_memory())
             self._polya_host = torch.empty(cap, dtype=torch.int32).pin_memory()
+            self._polya_state_host = torch.empty((cap, 4), dtype=torch.int32).pin_memory()
 
     SLICE_READS = 4096          # a batch of more than 1.5 x this many reads is assessed in slices of about this size
 
@@ -497,23 +503,35 @@ class SequencerControl:
                         cget = polyA_cache.get
                         end = np.fromiter((cget(i, 0) for i in part.ids), dtype=np.int64, count=hi - lo)
                 need = np.flatnonzero(end == 0)
-                found_h = found_d = None
+                found_h = found_d = state_h = rows_need = None
                 if need.size:                                   # one launch for every read without a known end
                     d_off = self._pinned.to_device(np.ascontiguousarray(offs[need]))
                     d_len = self._pinned.to_device(part.lens[need].astype(np.int32))
-                    found_d = proc.polyA_end_device(store.buf, d_off, d_len, int(need.size))
+                    if store.last_rows is not None:
+                        # a read that took the delta path is the read the row held, longer: its scan resumes behind the
+                        # windows the previous batches scanned (the state lives with the row); everything else starts over
+                        rows_need = store.last_rows[need]
+                        st_in = np.where(store.last_delta[need][:, None], store.row_pa[rows_need], 0).astype(np.int32)
+                        found_d, state_d = proc.polyA_end_device(store.buf, d_off, d_len, int(need.size),
+                                                                 state_in=self._pinned.to_device(np.ascontiguousarray(st_in).reshape(-1)).view(-1, 4))
+                        state_h = self._polya_state_host[lo: lo + need.size]
+                        state_h.copy_(state_d, non_blocking=True)
+                    else:
+                        found_d = proc.polyA_end_device(store.buf, d_off, d_len, int(need.size))
                     found_h = pa_host[lo: lo + need.size]
                     found_h.copy_(found_d, non_blocking=True)
                     self._pa_events[k].record(side)
-            return part, offs, end, need, found_h, found_d
+            return part, offs, end, need, found_h, (found_d, state_h, rows_need)
 
         def gate_and_classify(k, staged):
             nonlocal t, n_total
             lo = bounds[k]
-            part, offs, end, need, found_h, _found_d = staged
+            part, offs, end, need, found_h, (_found_d, state_h, rows_need) = staged
             ids, lens = part.ids, part.lens
             if need.size:
                 self._pa_events[k].synchronize()
+                if state_h is not None:
+                    store.row_pa[rows_need] = state_h.numpy()
                 found = found_h.numpy().astype(np.int64)
                 hit = np.flatnonzero(found > 0)
                 end[need[hit]] = found[hit]
