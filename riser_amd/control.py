@@ -332,7 +332,8 @@ class _SignalStore:
             self.mismatches += int((~ok).sum())
         n_reseen, n_delta = int(reseen.sum()), int(cand.sum())
         self.delta_reads += n_delta
-        self.last_rows, self.last_delta = rows, cand             # a delta read's prefix is what the row held: scans may resume
+        if not self._dup_channels:                               # (two reads of one channel share a row: no per-row state then)
+            self.last_rows, self.last_delta = rows, cand         # a delta read's prefix is what the row held: scans may resume
         # reads longer than a row: whole, into the spill area, nothing remembered
         spill_len = np.where(fits, 0, lens)
         spill_off = np.zeros(B, dtype=np.int64)
