@@ -290,3 +290,54 @@ def test_sliced_pipeline_equals_one_slice(dev, tmp_path, monkeypatch, traffic):
     assert many[3]._side is not None and one[3]._side is None               # the pipeline really ran / really did not
     for m in models:
         m.close()
+
+
+def test_random_traffic_stateful_paths_equal_the_plain_loop(dev, tmp_path):
+    """Random ReadUntil traffic against the loop's STATE: 48 channels x 150 batches in which a read may grow by 0 ... 3000
+    samples, pause (its channel missing from a batch), end (a new read, new id, takes the channel), come back under its id
+    with OTHER samples (a re-based buffer), or shrink.  The signal store's rows, the verified delta path and the resumed
+    poly(A) scans (control.py: row_have / row_tail / row_pa) must be invisible: same CSV rows and the same reject / finish
+    calls, batch by batch, as the loop that uploads every read whole and scans it from its first sample
+    (signal_cache=False); both also through the plain duck type."""
+    from riser_amd import Kit, Model, SignalProcessor
+    rng = np.random.default_rng(20260110)
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    models = [Model(synth.make_state_dict(1), synth.Config(), None, "t1", dtype="bf16x3", device=dev)]
+    C, NB = 48, 150
+    serial = [0]
+
+    def new_read():
+        serial[0] += 1
+        n = int(rng.integers(3000, 26000))
+        return {"id": f"r{serial[0]}", "sig": synth.make_raw_read(31, serial[0], n, polya=bool(rng.random() < 0.75)),
+                "seen": int(rng.integers(500, 3000))}
+
+    chan = [new_read() for _ in range(C)]
+    batches = []
+    for b in range(NB):
+        reads = []
+        for c in range(C):
+            r = chan[c]
+            u = rng.random()
+            if u < 0.06 or r["seen"] >= len(r["sig"]):
+                chan[c] = r = new_read()                                    # the strand left: a new read in the pore
+            elif u < 0.09:
+                r["sig"] = synth.make_raw_read(37, serial[0] + 1000 + b, len(r["sig"]), polya=True)   # same id, other samples
+            elif u < 0.12:
+                r["seen"] = max(400, r["seen"] - int(rng.integers(1, 900)))  # shorter than last time
+            elif u < 0.80:
+                r["seen"] = min(len(r["sig"]), r["seen"] + int(rng.integers(0, 3000)))
+            if rng.random() < 0.1:
+                continue                                                    # not in this batch
+            reads.append((c + 1, FakeRead(r["id"], r["sig"][: r["seen"]])))
+        batches.append(reads)
+    runs = [_run(batches, models, proc, str(tmp_path / f"f{k}"), cls, cache)
+            for k, (cls, cache) in enumerate(((FakeClient, True), (FakeClient, False), (PlainFakeClient, True)))]
+    assert len(runs[0][0]) > 300
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[1] == runs[0][1] and r[2] == runs[0][2]
+    store = runs[0][3]._store
+    assert store.delta_reads > 1000 and store.mismatches > 20 and store.resident     # every path was taken
+    for m in models:
+        m.close()
+
