@@ -96,6 +96,23 @@ class _Pinned:
             self.buf = torch.empty(max(need, 1 << 16), dtype=torch.uint8).pin_memory()
         self.used = 0
 
+    def to_device_many(self, arrs) -> list:
+        """several small contiguous 1-D arrays -> device tensors of their dtypes, as ONE asynchronous copy (a copy per array
+        costs ~10 us of launch time each, and a batch uploads seven of them)"""
+        at0 = self.used
+        spans = []
+        at = at0
+        for a in arrs:
+            spans.append((at, a.nbytes))
+            at = (at + a.nbytes + 63) & ~63
+        if at > self.buf.numel():                                # not reserved for: one by one (blocking fall-back inside)
+            return [self.to_device(a) for a in arrs]
+        self.used = at
+        for a, (o, nb) in zip(arrs, spans):
+            self.buf[o: o + nb].view(torch.from_numpy(a[:0]).dtype).numpy()[:] = a
+        dev = self.buf[at0: at].to(self.device, non_blocking=True)
+        return [dev[o - at0: o - at0 + nb].view(torch.from_numpy(a[:0]).dtype) for a, (o, nb) in zip(arrs, spans)]
+
     def to_device(self, arr: np.ndarray) -> torch.Tensor:
         """arr (contiguous) -> device tensor of the same dtype, copied asynchronously on the current stream"""
         nb = arr.nbytes
@@ -355,9 +372,8 @@ class _SignalStore:
             self.stage_dev[:total].copy_(self.stage[:total], non_blocking=True)
             self._uploaded.record(torch.cuda.current_stream(self.device))
             live = np.flatnonzero(seg_len > 0)
-            d_src = pinned.to_device(np.ascontiguousarray(src[live]))
-            d_dst = pinned.to_device(np.ascontiguousarray(dst[live]))
-            d_len = pinned.to_device(np.ascontiguousarray(seg_len[live].astype(np.int32)))
+            d_src, d_dst, d_len = pinned.to_device_many([np.ascontiguousarray(src[live]), np.ascontiguousarray(dst[live]),
+                                                         np.ascontiguousarray(seg_len[live].astype(np.int32))])
             nv.check(nv.lib().rs_copy_segments(self.stage_dev.data_ptr(), self.buf.data_ptr(), d_src.data_ptr(),
                                                d_dst.data_ptr(), d_len.data_ptr(), int(live.size),
                                                torch.cuda.current_stream(self.device).cuda_stream), "rs_copy_segments")
@@ -506,18 +522,18 @@ class SequencerControl:
                 need = np.flatnonzero(end == 0)
                 found_h = found_d = state_h = rows_need = None
                 if need.size:                                   # one launch for every read without a known end
-                    d_off = self._pinned.to_device(np.ascontiguousarray(offs[need]))
-                    d_len = self._pinned.to_device(part.lens[need].astype(np.int32))
+                    ups = [np.ascontiguousarray(offs[need]), part.lens[need].astype(np.int32)]
                     if store.last_rows is not None:
                         # a read that took the delta path is the read the row held, longer: its scan resumes behind the
                         # windows the previous batches scanned (the state lives with the row); everything else starts over
                         rows_need = store.last_rows[need]
                         st_in = np.where(store.last_delta[need][:, None], store.row_pa[rows_need], 0).astype(np.int32)
-                        found_d, state_d = proc.polyA_end_device(store.buf, d_off, d_len, int(need.size),
-                                                                 state_in=self._pinned.to_device(np.ascontiguousarray(st_in).reshape(-1)).view(-1, 4))
+                        d_off, d_len, d_st = self._pinned.to_device_many(ups + [np.ascontiguousarray(st_in).reshape(-1)])
+                        found_d, state_d = proc.polyA_end_device(store.buf, d_off, d_len, int(need.size), state_in=d_st.view(-1, 4))
                         state_h = self._polya_state_host[lo: lo + need.size]
                         state_h.copy_(state_d, non_blocking=True)
                     else:
+                        d_off, d_len = self._pinned.to_device_many(ups)
                         found_d = proc.polyA_end_device(store.buf, d_off, d_len, int(need.size))
                     found_h = pa_host[lo: lo + need.size]
                     found_h.copy_(found_d, non_blocking=True)
@@ -548,8 +564,7 @@ class SequencerControl:
             if sel.size == 0:
                 return
             lens_a = np.minimum(length[sel], max_len).astype(np.int32)
-            off_d = self._pinned.to_device(np.ascontiguousarray(offs[sel] + start[sel]))
-            len_d = self._pinned.to_device(lens_a)
+            off_d, len_d = self._pinned.to_device_many([np.ascontiguousarray(offs[sel] + start[sel]), lens_a])
             if side is not caller:
                 caller.wait_event(self._events[k])
             # -- normalise once, one batched forward per model, decision on the device -------------
