@@ -46,14 +46,20 @@ import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from riser_amd import supervise              # noqa: E402  (no torch inside)
+
+supervise.apply_rank_limits()                # a spawned rank pins itself to its core slice BEFORE numpy / torch start pools
+
+import numpy as np                           # noqa: E402
+import torch                                 # noqa: E402
+
 from riser_amd import dist as rdist          # noqa: E402
 from riser_amd import synth                  # noqa: E402
+
+supervise.apply_torch_threads()
 
 SETTLE_STEPS = 25
 BATCH = 512
@@ -63,6 +69,7 @@ READS_PER_GPU = 18000         # BASELINE config 4: 144 k concurrent chunks over 
 LAT_WARMUP, LAT_SAMPLES = 20, 200
 PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md:45
 PEAK_BF16_MFMA_TF = 2500.0    # :46
+PROFILE_ROUND = "r05"         # roofline.traffic comes from profiles/<round>_pmc_fetch_write_<mode>.json of THIS round only
 LIB_DTYPE = {"f32": "f32w", "f32_direct": "f32"}
 MFMA_PASSES = {"bf16x3": 3, "f16x3": 3}       # split-precision modes issue three 16-bit MFMAs per product
 
@@ -95,6 +102,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-variants", action="store_true", help="skip the 16-bit / ensemble side measurements")
     ap.add_argument("--no-control-loop", action="store_true", help="skip the ReadUntil replay")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU rehearsal of the rank plumbing (tests)
+    ap.add_argument("--stub-fail-rank", type=int, default=None, help=argparse.SUPPRESS)   # tests: this rank dies before the rendezvous
     args = ap.parse_args(argv)
     if args.dtype is None:
         args.dtype = "f16x3" if args.config == "progressive" else "f32"   # the fp16 mode that meets the 1e-3 tolerance
@@ -112,7 +120,10 @@ def parse_args(argv=None):
 # ---------------------------------------------------------------------------------------------------------------
 def spawn_ranks(args, argv):
     """Start N fresh child processes, one rank per GPU, and relay rank 0's JSON line.  The parent makes no GPU
-    call (torch.cuda.device_count() does not initialise the runtime on this image)."""
+    call (torch.cuda.device_count() does not initialise the runtime on this image).  The children are polled
+    (riser_amd/supervise.py): a rank that dies - before the first barrier or after - ends the run at once with its
+    stderr tail and a non-zero exit code instead of leaving its siblings in a collective until an outer timeout; every
+    rank runs on its own slice of the host's cores with its thread pools sized to it."""
     n = args.gpus
     if not args.stub and not os.environ.get("RS_DIST_BACKEND"):          # RS_DIST_BACKEND=gloo: several ranks rehearse on one GPU
         ndev = torch.cuda.device_count()
@@ -121,29 +132,33 @@ def spawn_ranks(args, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    for line in (out0 or "").splitlines():            # stdout carries the ONE JSON line; anything else (library
-        if line.lstrip().startswith("{"):             # chatter such as gloo's connection notes) goes to stderr
-            print(line, flush=True)
+    out0 = []
+
+    def spawn(r):
+        return subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv],
+                                env=supervise.rank_env(r, n, master_port=port),
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def on_line(r, line):
+        if r == 0 and line.lstrip().startswith("{"):      # stdout carries the ONE JSON line of rank 0; anything else
+            out0.append(line)                             # (library chatter such as gloo's connection notes) goes to stderr
         elif line.strip():
-            print(line, file=sys.stderr, flush=True)
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        raise SystemExit(f"bench.py: rank(s) failed: {bad}")
+            print(f"[rank {r}] {line}", file=sys.stderr, flush=True)
+
+    supervise.supervise(spawn, n, on_line, "bench.py")     # raises RankFailure (a SystemExit) on the first dead rank
+    for line in out0:
+        print(line, flush=True)
+    if not out0:
+        raise SystemExit("bench.py: every rank exited 0 but rank 0 printed no JSON line")
     return 0
 
 
 def run_stub(args, rank, world):
     """The rank plumbing without a GPU (tests/test_bench_cpu.py): gloo, a fixed-cost host step, the same barriers,
     reductions and JSON contract."""
+    if args.stub_fail_rank is not None and args.stub_fail_rank == rank:
+        print(f"rank {rank}: simulated failure before the rendezvous (--stub-fail-rank)", file=sys.stderr, flush=True)
+        os._exit(3)
     rdist.init(backend="gloo")
     B = args.batch
     for _ in range(args.warmup):
@@ -245,14 +260,14 @@ def traffic_object(args, model, wl):
         "prog" if args.config == "progressive" and args.dtype == "f16x3" else None)
     if tag is None or args.batch != BATCH or args.chunk != CHUNK:
         return None
-    for rnd in ("r04", "r03"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_fetch_write_{tag}.json")
-        if os.path.exists(path):
-            break
-    else:
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_fetch_write_{tag}.json")    # this round's pass only
+    if not os.path.exists(path):
         return None
     with open(path) as f:
         pmc = json.load(f)
+    from riser_amd.build import csrc_sha16
+    stamp = (pmc.get("_meta") or {}).get("csrc_sha16")
+    fresh = stamp is not None and stamp == csrc_sha16()
     conv = {k: v for k, v in pmc.items() if k.startswith("conv_")}
     if not conv:
         return None
@@ -272,7 +287,7 @@ def traffic_object(args, model, wl):
             "bytes_per_step": round(fetched + written, 1), "fetched_bytes_per_step": round(fetched, 1),
             "written_bytes_per_step": round(written, 1), "algorithmic_bytes_per_step": round(alg, 1),
             "ratio_to_algorithmic": round((fetched + written) / alg, 3), "fetch_doubled_for_gfx950": True,
-            "source": os.path.relpath(path, ROOT)}
+            "source": os.path.relpath(path, ROOT), "profiled_csrc_sha16": stamp, "kernels_match_tree": fresh}
 
 
 def roofline_object(args, model, wl, conv_ms_total, conv_calls, stage_ms, detail_calls):
@@ -319,7 +334,8 @@ def roofline_object(args, model, wl, conv_ms_total, conv_calls, stage_ms, detail
                if getattr(args, "streams", 1) > 1 else {})
     return {**overlap, "bound": "mfma", "kernel": kname + f", {nl - 1} launches per call, layers 1-{nl - 1}",
             "achieved": round(exe_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(exe_tf / peak, 4),
-            "traffic": traffic["bytes_per_launch"] if traffic else None,
+            # counters of OTHER kernel sources are not this tree's traffic: null, the stale figure stays in traffic_detail
+            "traffic": traffic["bytes_per_launch"] if traffic and traffic["kernels_match_tree"] else None,
             "traffic_detail": traffic,
             "traffic_note": "HBM-side bytes per conv launch (FETCH_SIZE x 2 + WRITE_SIZE) from the tracked rocprofv3 PMC passes of "
                             "this same command (traffic_detail.source): counters cannot be collected from inside a run; null "
@@ -771,7 +787,7 @@ def main(argv=None):
 
     ms_per_step = elapsed / args.steps * 1e3
     value = total_chunks / elapsed
-    out = {
+    detail = {
         "metric": "signal chunks classified/sec (RNA004 4 s chunks, batch=512)",
         "value": round(value, 1), "unit": "chunks/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -791,15 +807,156 @@ def main(argv=None):
     single = world == 1 and args.config == "rna004_b512"
     # ---- side measurements on the same batch (rank 0, N = 1 only; not the headline) --------------
     if single and not args.no_variants and args.dtype == "f32":
-        out["variants"] = side_variants(args, device, wl, wl.probs.cpu().numpy().copy())
+        detail["variants"] = side_variants(args, device, wl, wl.probs.cpu().numpy().copy())
     if single and not args.no_control_loop:
-        out["control_loop"] = control_loop_object(device, lib_dtype)
+        detail["control_loop"] = control_loop_object(device, lib_dtype)
     # ---- CPU baseline (rank 0, N = 1 only): oracle port timed on this box's host cores ---------
     if single and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_object(args, wl.sample_sigs)
-    print(json.dumps(out), flush=True)
+        detail["cpu_baseline"] = cpu_baseline_object(args, wl.sample_sigs)
+    line = compact_line(detail, args, model, wl)
+    path = write_detail(detail, args)
+    if path:
+        line["detail_file"] = path
+    print(json.dumps(line, separators=(",", ":")), flush=True)
     rdist.finalize()
     return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the ONE line: everything a reader of the driver's record needs, under 6 KB; the verbose objects go to a file
+# ---------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 6000
+MODE_OF_VARIANT = {            # variants key -> (name in roofline.modes, BASELINE config it carries)
+    "bf16x3": ("bf16x3", "the 16-bit MFMA arithmetic of configs 3 / 5 at 512 x 16000"),
+    "f16x3": ("f16x3", ""),
+    "mixed_2s_3s_4s_f16x3": ("mixed_f16x3", "config 5"),
+    "ensemble3_bf16x3": ("ensemble3_bf16x3", "config 3"),
+    "live_357x8615_f32": ("live_357x8615_f32", "the live ReadUntil batch shape"),
+    "resnet_basic_f32": ("resnet_basic_f32", "riser/nets/resnet.py"),
+}
+
+
+def modes_object(detail, model, wl):
+    """roofline.modes: the side measurements that carry BASELINE configs 3 and 5, the live batch shape and the ResNet, each
+    {value (chunks or reads per s), ms_per_step, frac, max_dp_vs_f32, flips}.  `frac` = direct-convolution FLOPs of the
+    step's reads (un-padded, counted once per product whatever the mode issues) / the WHOLE step's time
+    (normalise and head included) / the dense MFMA peak of the mode's matrix instruction (157.3 TF f32-input, 2.5 PF
+    16-bit).  fp32 Winograd issues half to two thirds of those multiplications, so its frac can exceed what the pipe
+    executes (roofline.frac is the executed share)."""
+    v = detail.get("variants") or {}
+    L = wl.args.chunk
+    per_len = {}
+
+    def flops(lens):
+        tot = 0.0
+        for n in lens:
+            n = int(n)
+            if n not in per_len:
+                per_len[n] = float(sum(conv_flops_per_chunk(model.channels, n)[1:]))
+            tot += per_len[n]
+        return tot
+
+    B = wl.args.batch
+    lens_of = {"bf16x3": [L] * B, "f16x3": [L] * B, "ensemble3_bf16x3": [L] * B * 3,
+               "mixed_f16x3": [(L // 2, 3 * L // 4, L)[i % 3] for i in range(B)], "live_357x8615_f32": [8615] * 357}
+    modes = {}
+    for key, (name, _) in MODE_OF_VARIANT.items():
+        e = v.get(key)
+        if not e:
+            continue
+        ms = e["ms_per_step"]
+        vs = e.get("model0", e)
+        m = {"value": e.get("chunks_per_s", e.get("reads_per_s")), "unit": "chunks/s" if "chunks_per_s" in e else "reads/s",
+             "ms_per_step": ms}
+        if name == "resnet_basic_f32":
+            m["frac"] = e.get("roofline_frac_f32_mfma")
+        else:
+            peak = PEAK_F32_MFMA_TF if name.endswith("f32") else PEAK_BF16_MFMA_TF
+            m["frac"] = round(flops(lens_of[name]) / (ms * 1e-3) / 1e12 / peak, 4)
+        if "max_abs_dprob_vs_f32" in vs:
+            m["max_dp_vs_f32"] = float("%.3g" % vs["max_abs_dprob_vs_f32"])
+            m["flips"] = vs["label_flips_at_0.9_vs_f32"]
+        modes[name] = m
+    return modes
+
+
+def compact_line(detail, args, model, wl):
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")
+    line = {k: detail[k] for k in keep}
+    c = detail["config"]
+    line["config"] = {"workload": c["workload"], "name": c["name"], "conv_algorithm": c["conv_algorithm"],
+                      "batch_per_call": c["batch_per_call"], "chunk_samples": c["chunk_samples"], "sharding": c["sharding"]}
+    for k in ("p50_batch_latency_ms", "p99_batch_latency_ms", "latency_samples"):
+        line[k] = detail[k]
+    r = detail["roofline"]
+    layers = [x for x in r["layers"] if x["ms"]]
+    dom = max(layers, key=lambda x: x["ms"]) if layers else None
+    roof = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+            "traffic": r["traffic"],
+            "traffic_source": (r["traffic_detail"] or {}).get("source"),
+            "traffic_kernels_match_tree": (r["traffic_detail"] or {}).get("kernels_match_tree"),
+            "traffic_ratio_to_algorithmic": (r["traffic_detail"] or {}).get("ratio_to_algorithmic"),
+            "kernel": r["kernel"][:120],
+            "achieved_is": "MFMA FLOPs executed (padded tiles, Winograd-reduced) / HIP-event time of conv layers 1-11",
+            "algorithmic_tflops": r["algorithmic_tflops"],
+            "algorithmic_frac": round(r["algorithmic_tflops"] / r["peak"], 4),
+            "avg_launch_ms": r["avg_launch_ms"], "conv_stack_ms_per_call": r["conv_stack_ms_per_call"],
+            "normalise_ms": r["stage_ms"]["normalise"], "head_ms": r["stage_ms"]["head"],
+            "p50_batch_latency_ms": detail["p50_batch_latency_ms"], "p99_batch_latency_ms": detail["p99_batch_latency_ms"],
+            "latency_window_s": 1.0}
+    if dom:
+        roof.update({"slowest_layer": dom["layer"], "slowest_layer_ms": dom["ms"],
+                     "slowest_layer_executed_tflops": dom["executed_tflops"],
+                     "slowest_layer_algorithmic_tflops": dom["algorithmic_tflops"]})
+    modes = modes_object(detail, model, wl)
+    if modes:
+        roof["modes"] = modes
+        for name, m in modes.items():                      # the same figures as scalars: a record that keeps one level only
+            roof[f"{name}_value"] = m["value"]
+            roof[f"{name}_ms"] = m["ms_per_step"]
+            roof[f"{name}_frac"] = m["frac"]
+            if "max_dp_vs_f32" in m:
+                roof[f"{name}_max_dp"] = m["max_dp_vs_f32"]
+                roof[f"{name}_flips"] = m["flips"]
+    line["roofline"] = roof
+    cb = detail.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "batched64_value", "batched64_cores",
+                                                   "host_logical_cpus")}
+        line["cpu_baseline"]["sample"] = cb["sample"][:200]
+    cl = detail.get("control_loop")
+    if cl:
+        rows = {}
+        for name, e in cl.items():
+            if not isinstance(e, dict):
+                continue
+            rows[name] = {"p50_ms": e["p50_ms"], "p99_ms": e["p99_ms"], "max_ms": e["max_ms"], "samples": e["latency_samples"],
+                          "loop_p50_ms": e["loop_p50_ms"], "assessed_per_batch": e["assessed_per_batch"]}
+        big = cl.get("promethion_18000_channels") or {}
+        line["control_loop"] = {"kit": cl["kit"], "dtype": cl["dtype"], "window_s": cl["window_s"], "lines": rows,
+                                "phase_ms_median_18000_channels": big.get("phase_ms_median")}
+    blob = json.dumps(line, separators=(",", ":"))
+    if len(blob) > LINE_LIMIT:                             # never let the line outgrow the driver's tail: drop the widest extras
+        for k in ("control_loop", "modes"):
+            (line if k in line else line["roofline"]).pop(k, None)
+            if len(json.dumps(line, separators=(",", ":"))) <= LINE_LIMIT:
+                break
+    return line
+
+
+def write_detail(detail, args):
+    """the verbose objects (per-layer table, notes, variants, control-loop phases and counters, CPU thread sweep) as a
+    file next to the run: gpurun_out/bench_detail_<config>_<dtype>.json (what profiles/rNN_bench_*.json are copies of)"""
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, f"bench_detail_{args.config}_{args.dtype}.json")
+        with open(path, "w") as f:
+            json.dump(detail, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
 
 
 if __name__ == "__main__":

@@ -27,6 +27,19 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
          "-Wall", "-Wno-unused-function"]
 
 
+def csrc_sha16() -> str:
+    """sha256[:16] over the device sources (csrc/*.hip, *.hpp, sorted by name): the stamp a rocprofv3 PMC summary carries
+    (tools/pmc_summary.py) so that bench.py can tell whether tracked counters still describe the kernels of this tree"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):

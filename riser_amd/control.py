@@ -90,11 +90,23 @@ class _Pinned:
         self.device = device
         self.buf = None
         self.used = 0
+        self._copied = {}                      # stream -> event recorded behind the last copy issued from the scratch there
 
     def reset(self, need: int):
+        """Start a new batch at offset 0 - once every copy of the previous batch has READ its source: a batch may return
+        without a stream synchronise (no assessable read), and its index arrays may still be queued."""
+        for ev in self._copied.values():
+            ev.synchronize()
         if self.buf is None or self.buf.numel() < need:
             self.buf = torch.empty(max(need, 1 << 16), dtype=torch.uint8).pin_memory()
         self.used = 0
+
+    def _mark(self):
+        st = torch.cuda.current_stream(self.device)
+        ev = self._copied.get(st.cuda_stream)
+        if ev is None:
+            ev = self._copied[st.cuda_stream] = torch.cuda.Event()
+        ev.record(st)
 
     def to_device_many(self, arrs) -> list:
         """several small contiguous 1-D arrays -> device tensors of their dtypes, as ONE asynchronous copy (a copy per array
@@ -111,6 +123,7 @@ class _Pinned:
         for a, (o, nb) in zip(arrs, spans):
             self.buf[o: o + nb].view(torch.from_numpy(a[:0]).dtype).numpy()[:] = a
         dev = self.buf[at0: at].to(self.device, non_blocking=True)
+        self._mark()
         return [dev[o - at0: o - at0 + nb].view(torch.from_numpy(a[:0]).dtype) for a, (o, nb) in zip(arrs, spans)]
 
     def to_device(self, arr: np.ndarray) -> torch.Tensor:
@@ -122,7 +135,9 @@ class _Pinned:
             return torch.from_numpy(arr).to(self.device)
         host = self.buf[at: at + nb].view(torch.from_numpy(arr[:0]).dtype)
         host.numpy()[:] = arr
-        return host.to(self.device, non_blocking=True)
+        dev = host.to(self.device, non_blocking=True)
+        self._mark()
+        return dev
 
 
 def _object_array(items: list) -> np.ndarray:
@@ -244,6 +259,10 @@ class _SignalStore:
     def _stage(self, n: int, exact: bool = False):
         if self.stage is None or self.stage.numel() < n:
             cap = max(n if exact else 2 * n, 1 << 22)   # generous: pinning memory is a slow system call, growth must be rare
+            if self.stage_dev is not None:
+                # the previous slice's transfer and scatter may still read the buffers being replaced, on either stream of
+                # the slice pipeline: growth is rare (reserve() sizes them for the run), so it may wait for the device
+                torch.cuda.synchronize(self.device)
             self.stage = torch.empty(cap, dtype=torch.int16).pin_memory()
             self.stage_dev = torch.empty(cap, dtype=torch.int16, device=self.device)
         return self.stage.numpy()
@@ -429,7 +448,8 @@ class SequencerControl:
         window)."""
         from .model import reserve_ensemble
         reads = int(reads)
-        reserve_ensemble(self.models, reads, self.proc.get_max_length())
+        # the largest call of a run is one slice (assess_batch), not the flow cell's channel count
+        reserve_ensemble(self.models, min(reads, self.SLICE_READS * 3 // 2 + 1), self.proc.get_max_length())
         # a first batch carries every read whole: typically <= 6 s of signal per pore
         self._store.reserve(reads, min(reads * 24576, 1 << 29))
         self._pinned.reset(96 * reads + (1 << 12))

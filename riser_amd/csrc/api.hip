@@ -1142,20 +1142,36 @@ int rs_classify_ensemble(rs_model* const* models, int n_models, const int16_t* d
     prof_mark(m0, 0, st);
     const float* xn = reinterpret_cast<const float*>(static_cast<char*>(d_ws) + w.xnorm_off);
     if (concurrent) {
-        for (int k = 1; k < n_models; ++k) {
+        // Whatever fails after the first fork, every side stream that has received work is JOINED to the caller's stream
+        // before this call returns: the caller owns the workspace and d_probs and may reuse or free them behind `st` the
+        // moment it sees the error code.  A join that itself fails falls back to a host-side wait.
+        int forked = 0;
+        auto join_all = [&]() {
+            for (int k = 1; k <= forked; ++k) {
+                rs_model* mk = models[k];
+                if (hipEventRecord(mk->ev_join, mk->side_stream) != hipSuccess ||
+                    hipStreamWaitEvent(st, mk->ev_join, 0) != hipSuccess)
+                    (void)hipStreamSynchronize(mk->side_stream);
+            }
+        };
+        for (int k = 1; k < n_models && rc == RS_OK; ++k) {
             rs_model* mk = models[k];
-            RS_HIP(hipEventRecord(mk->ev_fork, st));
-            RS_HIP(hipStreamWaitEvent(mk->side_stream, mk->ev_fork, 0));
+            hipError_t he = hipEventRecord(mk->ev_fork, st);
+            if (he == hipSuccess) he = hipStreamWaitEvent(mk->side_stream, mk->ev_fork, 0);
+            if (he != hipSuccess) {
+                set_error("rs_classify_ensemble: fork of model %d: %s", k, hipGetErrorString(he));
+                rc = RS_ERR_HIP;
+                break;
+            }
+            forked = k;
             WsLayout wk = w;
             wk.bufa_off += (size_t)k * 2 * buf_bytes;
             wk.bufb_off += (size_t)k * 2 * buf_bytes;
             rc = forward_impl(mk, xn, w.Uf, d_len, B, bt, wk, d_ws, d_probs + (size_t)k * B * 2, nullptr, mk->side_stream, true);
-            if (rc != RS_OK) return rc;
-            RS_HIP(hipEventRecord(mk->ev_join, mk->side_stream));
         }
-        rc = forward_impl(m0, xn, w.Uf, d_len, B, bt, w, d_ws, d_probs, nullptr, stream, true);
+        if (rc == RS_OK) rc = forward_impl(m0, xn, w.Uf, d_len, B, bt, w, d_ws, d_probs, nullptr, stream, true);
+        join_all();
         if (rc != RS_OK) return rc;
-        for (int k = 1; k < n_models; ++k) RS_HIP(hipStreamWaitEvent(st, models[k]->ev_join, 0));
     } else {
         for (int k = 0; k < n_models; ++k) {
             // every model keeps the block table and the normalised rows at the head of the workspace and ping-pongs behind them

@@ -20,6 +20,7 @@
 #include <Python.h>
 #include <pthread.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 static int get_wbuf(PyObject* o, Py_buffer* v, const char* what) {
@@ -95,6 +96,9 @@ static void* copy_job(void* arg) {
 }
 
 #define HP_MAX_THREADS 8
+/* copy threads per gather: RS_HOST_THREADS (1..8) caps it - a launcher that runs several ranks on one host gives each
+ * rank a slice of the cores (riser_amd/supervise.py) and this pool must fit the slice */
+static int hp_thread_cap = HP_MAX_THREADS;
 
 static PyObject* hp_gather(PyObject* self, PyObject* args) {
     PyObject *reads, *start, *out;
@@ -152,6 +156,7 @@ static PyObject* hp_gather(PyObject* self, PyObject* args) {
         /* the views pin the exporters: the copies need no interpreter state */
         Py_BEGIN_ALLOW_THREADS
         int nt = at > (8 << 20) ? HP_MAX_THREADS : at > (3 << 20) ? 4 : 1;
+        if (nt > hp_thread_cap) nt = hp_thread_cap;
         if (nt > n) nt = (int)(n ? n : 1);
         job_t jobs[HP_MAX_THREADS];
         pthread_t th[HP_MAX_THREADS];
@@ -453,4 +458,13 @@ static PyMethodDef methods[] = {
 
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_hostpack", "per-read host loops of a ReadUntil batch", -1, methods};
 
-PyMODINIT_FUNC PyInit__hostpack(void) { return PyModule_Create(&moddef); }
+PyMODINIT_FUNC PyInit__hostpack(void) {
+    const char* cap = getenv("RS_HOST_THREADS");
+    if (cap && *cap) {
+        const long v = strtol(cap, NULL, 10);
+        hp_thread_cap = v < 1 ? 1 : v > HP_MAX_THREADS ? HP_MAX_THREADS : (int)v;
+    }
+    PyObject* m = PyModule_Create(&moddef);
+    if (m) PyModule_AddIntConstant(m, "thread_cap", hp_thread_cap);
+    return m;
+}

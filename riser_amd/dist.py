@@ -8,6 +8,7 @@ RCCL on ROCm; "gloo" serves the CPU tests.  xGMI carries nothing on this path.
 """
 from __future__ import annotations
 
+import datetime
 import os
 import zlib
 
@@ -29,7 +30,9 @@ def init(backend: str | None = None, device: torch.device | None = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         # RS_DIST_BACKEND=gloo rehearses the multi-rank path with several ranks sharing one GPU
         backend = backend or os.environ.get("RS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        kw = {}
+        # bounded rendezvous: a sibling that died before it reached the store must not leave this rank waiting for the
+        # library's default 10-30 minutes (the launcher's poll ends the run first; this is the second line of defence)
+        kw = {"timeout": datetime.timedelta(seconds=float(os.environ.get("RS_DIST_TIMEOUT_S", "60")))}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)

@@ -1,7 +1,8 @@
 """Sharded live control loop: N processes, N channel ranges, N GPUs, no collective.
 
     python -m riser_amd.launch --gpus N --channels C --kit RNA004 --mode enrich --out run \\
-        [--client pkg.module:factory] [--model target=state.pth ...] [--dtype f32w] [--duration-h 48] [--threshold 0.9]
+        [--client pkg.module:factory] [--model-dir model --targets mRNA,mtRNA | --model target=state.pth ...]
+        [--dtype f32w] [--duration-h 48] [--threshold 0.9] [--on-rank-failure abort|restart] [--max-restarts 2]
         [--replay-script tests/golden/control.json | --replay-synthetic BATCHES] [--seeds 1,2,3] [--share-gpus] [--stub]
 
 The reference drives ONE flow cell from one process: `ReadUntilClient.run(first_channel=1, last_channel=512)` and one
@@ -18,6 +19,17 @@ ReadUntil API lets a client choose:
   * nothing is exchanged between ranks.  Each child reports its once-a-minute counters (riser/control.py:116-123) and a
     final summary as JSON lines on its stdout; the parent merges them into one progress line per minute and one summary
     (`<out>.summary.json`).
+
+Models: `--model-dir DIR --targets mRNA,mtRNA --kit RNA004` resolves `DIR/{target}_config_{kit}_{pore}.yaml` and
+`DIR/{target}_model_{kit}_{pore}.pth` exactly as the reference's `get_models` does (riser/riser.py:26-42,
+riser_amd/modeldir.py); `--model target=state.pth` takes a state dict with the shipped 12-layer config.
+
+Supervision (riser_amd/supervise.py): the parent POLLS its children.  A rank that exits non-zero is logged at once with
+the tail of its stderr; `--on-rank-failure abort` (default) then terminates the other ranks and exits non-zero,
+`restart` starts a FRESH process for that channel range (at most `--max-restarts` times per rank; never a re-exec of a
+process that has touched the GPU) so that the other ranges stay under control meanwhile.  The merged per-minute line is
+printed over the ranks that are alive and names the ones that are not.  Every rank runs on its own slice of the host's
+cores, its torch / hostpack thread pools sized to the slice.
 
 `--client pkg.module:factory` names a callable `factory(logger, first_channel, last_channel)` returning an object with the
 eight client methods (riser/client.py:25-69).  Without it the launcher replays scripted traffic through FakeClient -
@@ -37,6 +49,8 @@ import subprocess
 import sys
 import threading
 import time
+
+from . import supervise
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # the directory that holds the package
 _MINUTE_RE = re.compile(r"In the last minute (\d+) signals were assessed, (\d+) were accepted and (\d+) were rejected")
@@ -66,6 +80,14 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="f32w")
     ap.add_argument("--client", default=None, help="pkg.module:factory(logger, first_channel, last_channel)")
     ap.add_argument("--model", action="append", default=[], help="target=state.pth (repeatable; the shipped 12-layer config)")
+    ap.add_argument("--model-dir", default=None, help="directory laid out as the reference's model/: {target}_config_{kit}_{pore}.yaml "
+                                                     "+ {target}_model_{kit}_{pore}.pth (riser/riser.py:35-42)")
+    ap.add_argument("--targets", default="mRNA", help="comma list of targets to load from --model-dir")
+    ap.add_argument("--on-rank-failure", default="abort", choices=["abort", "restart"])
+    ap.add_argument("--max-restarts", type=int, default=2)
+    ap.add_argument("--fail-rank", type=int, default=None, help=argparse.SUPPRESS)        # tests: this rank exits 3 ...
+    ap.add_argument("--fail-after-s", type=float, default=0.0, help=argparse.SUPPRESS)    # ... this long after it started
+    ap.add_argument("--fail-once", default=None, help=argparse.SUPPRESS)                  # ... only while this marker file is absent
     ap.add_argument("--seeds", default="1", help="synthetic weights for the replay modes: comma list of riser_amd.synth seeds")
     ap.add_argument("--replay-script", default=None)
     ap.add_argument("--replay-synthetic", type=int, default=0, metavar="BATCHES")
@@ -91,50 +113,77 @@ def launch(args, argv) -> dict:
             raise SystemExit(f"riser_amd.launch: --gpus {n} but only {ndev} ROCm device(s) visible (--share-gpus rehearses "
                              "several ranks on one GPU)")
     log = logging.getLogger("riser_amd.launch")
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    def spawn(r):
+        env = supervise.rank_env(r, n)
         env["PYTHONPATH"] = _ROOT + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
-        procs.append(subprocess.Popen([sys.executable, "-m", "riser_amd.launch", *argv], env=env, stdout=subprocess.PIPE,
-                                      text=True, cwd=os.getcwd()))
+        return subprocess.Popen([sys.executable, "-m", "riser_amd.launch", *argv], env=env, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True, cwd=os.getcwd())
+
     minutes, summaries, lock = {}, {}, threading.Lock()
+    down, failures = set(), []
 
-    def pump(rank, pipe):
-        for line in pipe:
-            line = line.strip()
-            if not line.startswith("{"):
-                if line:
-                    print(f"[rank {rank}] {line}", file=sys.stderr, flush=True)
-                continue
-            try:
-                msg = json.loads(line)
-            except ValueError:
-                continue
-            with lock:
-                if msg.get("kind") == "minute":
-                    slot = minutes.setdefault(msg["minute"], {})
-                    slot[rank] = msg
-                    if len(slot) == n:                         # every rank has reported this minute: one merged line
-                        tot = [sum(m[k] for m in slot.values()) for k in ("assessed", "accepted", "rejected")]
-                        log.info(f"In the last minute {tot[0]} signals were assessed, {tot[1]} were accepted and {tot[2]} "
-                                 f"were rejected ({n} ranks)")
-                elif msg.get("kind") == "summary":
-                    summaries[rank] = msg
+    def merged_line(minute, final=False):
+        """one line per minute over the ranks that reported it; called with the lock held"""
+        slot = minutes.get(minute)
+        if not slot or slot.get("printed"):
+            return
+        alive = [r for r in range(n) if r not in down]
+        have = [r for r in alive if r in slot]
+        if not final and len(have) < len(alive):
+            return
+        slot["printed"] = True
+        tot = [sum(slot[r][k] for r in slot if isinstance(r, int)) for k in ("assessed", "accepted", "rejected")]
+        missing = sorted(set(range(n)) - {r for r in slot if isinstance(r, int)})
+        log.info(f"In the last minute {tot[0]} signals were assessed, {tot[1]} were accepted and {tot[2]} "
+                 f"were rejected ({n - len(missing)} of {n} ranks" +
+                 (f"; no report from rank(s) {missing}: their channels are not under control" if missing else "") + ")")
 
-    threads = [threading.Thread(target=pump, args=(r, p.stdout), daemon=True) for r, p in enumerate(procs)]
-    for t in threads:
-        t.start()
-    rcs = [p.wait() for p in procs]
-    for t in threads:
-        t.join(timeout=10)
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        raise SystemExit(f"riser_amd.launch: rank(s) failed: {bad}")
+    def on_line(rank, line):
+        line = line.strip()
+        if not line.startswith("{"):
+            if line:
+                print(f"[rank {rank}] {line}", file=sys.stderr, flush=True)
+            return
+        try:
+            msg = json.loads(line)
+        except ValueError:
+            return
+        with lock:
+            if msg.get("kind") == "minute":
+                minutes.setdefault(msg["minute"], {})[rank] = msg
+                merged_line(msg["minute"])
+            elif msg.get("kind") == "summary":
+                summaries[rank] = msg
+
+    def on_event(kind, rank, rc, tail):
+        first, last = rank_channel_range(rank, n, args.channels)
+        with lock:
+            if kind == "failed":
+                down.add(rank)
+                failures.append({"rank": rank, "returncode": rc, "channels": [first, last], "time": time.time(),
+                                 "stderr_tail": tail[-10:]})
+                log.error(f"rank {rank} (channels {first}-{last}) exited with code {rc}: its channels are not under control. "
+                          "Last stderr lines:\n" + "\n".join("    " + ln for ln in tail[-10:]))
+                for m in list(minutes):                        # minutes that were waiting for this rank only
+                    merged_line(m)
+            elif kind == "restarted":
+                down.discard(rank)
+                log.warning(f"rank {rank} (channels {first}-{last}) started again as a fresh process")
+
+    restarts = args.max_restarts if args.on_rank_failure == "restart" else 0
+    try:
+        supervise.supervise(spawn, n, on_line, "riser_amd.launch", restarts=restarts, on_event=on_event, quiet_stderr=False)
+    finally:
+        with lock:
+            for m in list(minutes):
+                merged_line(m, final=True)
     merged = {"ranks": n, "channels": args.channels,
               "channel_ranges": [list(rank_channel_range(r, n, args.channels)) for r in range(n)],
               "per_rank": [summaries.get(r, {}) for r in range(n)],
-              "minutes_merged": {str(k): {f: sum(m[f] for m in v.values()) for f in ("assessed", "accepted", "rejected")}
+              "rank_failures": failures,
+              "minutes_merged": {str(k): {f: sum(m[f] for r, m in v.items() if isinstance(r, int))
+                                          for f in ("assessed", "accepted", "rejected")}
                                  for k, v in sorted(minutes.items())}}
     for f in ("batches", "reads_received", "reads_assessed", "rejected", "finished"):
         merged[f] = sum(int(s.get(f, 0)) for s in summaries.values())
@@ -205,8 +254,26 @@ class _StubControl:
         self.logger.info(f"In the last minute {n} signals were assessed, 0 were accepted and 0 were rejected")
 
 
+def _arm_test_failure(args, rank):
+    """tests only (--fail-rank): this rank dies with exit code 3, at once or from a timer thread mid-run"""
+    if args.fail_rank is None or args.fail_rank != rank:
+        return
+    if args.fail_once:
+        if os.path.exists(args.fail_once):
+            return                                   # the restarted process runs to completion
+        open(args.fail_once, "w").close()
+
+    def die():
+        print(f"rank {rank}: simulated failure (--fail-rank)", file=sys.stderr, flush=True)
+        os._exit(3)
+    if args.fail_after_s <= 0:
+        die()
+    threading.Timer(args.fail_after_s, die).start()
+
+
 def run_rank(args) -> int:
     rank, local_rank, world = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ["WORLD_SIZE"])
+    _arm_test_failure(args, rank)
     first, last = rank_channel_range(rank, world, args.channels)
     logger = logging.getLogger(f"riser_amd.rank{rank}")
     logger.setLevel(logging.INFO)
@@ -222,6 +289,7 @@ def run_rank(args) -> int:
         ctl = _StubControl(client, logger, out)
     else:
         import torch
+        supervise.apply_torch_threads()
         from . import synth
         from .control import SequencerControl
         from .model import Model
@@ -231,7 +299,11 @@ def run_rank(args) -> int:
             raise SystemExit(f"rank {rank}: {world} ranks but {ndev} ROCm device(s) visible")
         device = torch.device("cuda", local_rank % ndev)
         torch.cuda.set_device(device)
-        if args.model:
+        if args.model_dir:
+            from .modeldir import get_models
+            models = get_models([t for t in args.targets.split(",") if t], logger, args.kit, args.model_dir,
+                                dtype=args.dtype, device=device)
+        elif args.model:
             spec = [m.partition("=")[::2] for m in args.model]
             models = [Model(path, synth.Config(), logger, target, dtype=args.dtype, device=device) for target, path in spec]
         else:
@@ -267,6 +339,7 @@ def main(argv=None):
     args = parse_args(argv)
     logging.basicConfig(level=logging.INFO, stream=sys.stderr, format="%(asctime)s %(name)s %(message)s")
     if "WORLD_SIZE" in os.environ and "RANK" in os.environ:
+        supervise.apply_rank_limits()                # core slice first: torch sizes its pools when it is imported
         if int(os.environ["WORLD_SIZE"]) != args.gpus:
             raise SystemExit(f"riser_amd.launch: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
         return run_rank(args)

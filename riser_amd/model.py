@@ -402,14 +402,22 @@ def _autotune(self, sig_dev: torch.Tensor, off_dev: torch.Tensor, len_dev: torch
 Model.autotune = _autotune
 
 
+_CONCURRENT_BELOW_SAMPLES = 1800 * 4096          # csrc/api.hip: kConcurrentBelowSamples
+
+
 def _ensemble_bytes(models, B: int, lmax: int) -> int:
     """workspace of one rs_classify_ensemble call: a pair of activation buffers per model, so that the forwards of the
     models run concurrently (include/riser_amd.h)"""
     hs = (C.c_void_p * len(models))(*[m._h for m in models])
-    need = nv.lib().rs_ensemble_workspace_bytes(hs, len(models), int(B), int(lmax))
-    if need == 0:          # models that cannot run concurrently (an `fc` classifier): the widest single-model workspace
-        need = max(nv.lib().rs_workspace_bytes(m._h, int(B), int(lmax)) for m in models)
-    return need
+    L = nv.lib()
+    serial = max(L.rs_workspace_bytes(m._h, int(B), int(lmax)) for m in models)
+    # the library forks the forwards only below ~1800 blocks of 4096 samples (csrc/api.hip, rs_classify_ensemble: beyond that
+    # one model's launches fill the chip): a call that can never take the fork needs - and pins - the serial workspace only
+    U = int(L.rs_block_samples(models[0]._h))
+    if len(models) < 2 or int(B) * (int(lmax) // U + 1) * U >= _CONCURRENT_BELOW_SAMPLES:
+        return serial
+    need = L.rs_ensemble_workspace_bytes(hs, len(models), int(B), int(lmax))
+    return need if need else serial       # 0: models that cannot run concurrently (an `fc` classifier)
 
 
 def reserve_ensemble(models, B: int, lmax: int):

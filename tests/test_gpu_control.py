@@ -182,6 +182,60 @@ def test_sharded_launch_two_ranks_one_gpu(tmp_path, golden_dir, run_index):
     assert two["reads_assessed"] == len(single) and two["rejected"] == sum(len(x) for x in run["rejected"])
 
 
+def test_launch_from_a_model_directory_in_the_reference_layout(tmp_path, golden_dir):
+    """--model-dir DIR --targets ... --kit RNA004: DIR/{target}_config_{kit}_{pore}.yaml + DIR/{target}_model_{kit}_{pore}.pth
+    as riser/riser.py:26-42 lays them out (the .pth read by torch.load as riser/model.py:19 does, the YAML's `cnn` section
+    as config.cnn).  The synthetic weights of golden run 5 saved that way and launched on two ranks reproduce the
+    reference's rows for that run."""
+    import torch
+    with open(os.path.join(golden_dir, "control.json")) as f:
+        g = json.load(f)
+    run = g["runs"][5]
+    names = ("mRNA", "mtRNA", "globin")
+    targets = [names[k % 3] for k in range(len(run["seeds"]))]
+    mdir = tmp_path / "model"
+    mdir.mkdir()
+    pore = {"RNA002": "R9.4.1", "RNA004": "RP4"}[g["kit"]]
+    yaml_text = ("model: cnn\nbatch_size: 32\nn_epochs: 30\nlearning_rate: 0.0001\n\ncnn:\n  n_layers: 12\n  depth: 1\n"
+                 "  channels: [20,30,45,67,100,150,225,337,505,757,1135,1702]\n  kernels: [3,3,3,3,3,3,3,3,3,3,3,3]\n"
+                 "  n_classes: 2\n  classifier: gap_fc # fc / gap_fc / gap\n")
+    for t, seed in zip(targets, run["seeds"]):
+        (mdir / f"{t}_config_{g['kit']}_{pore}.yaml").write_text(yaml_text)
+        torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_state_dict(int(seed)).items()},
+                   str(mdir / f"{t}_model_{g['kit']}_{pore}.pth"))
+    two = _launch(["--gpus", "2", "--share-gpus", "--channels", "22", "--replay-script", os.path.join(golden_dir, "control.json"),
+                   "--kit", g["kit"], "--mode", run["mode"], "--threshold", str(run["threshold"]), "--duration-h", "1.0",
+                   "--model-dir", str(mdir), "--targets", ",".join(targets), "--out", str(tmp_path / "md")])
+    rows = []
+    for r in range(2):
+        rows += [ln.split(",", 1)[1] for ln in open(str(tmp_path / f"md.rank{r}.csv")).read().strip().split("\n")[1:]]
+    assert two["ranks"] == 2 and len(rows) == len(run["rows"])
+    want = {(w["read_id"], w["channel"]): w for w in run["rows"]}
+    for ln in rows:
+        p = ln.split(",")
+        w = want[(p[0], int(p[1]))]
+        assert (int(p[2]), p[3], p[7]) == (w["sig_length"], w["models"], w["decision"])
+        assert np.allclose([float(v) for v in p[4].split(";")], w["prob_targets"], atol=1e-3)
+
+
+def test_four_ranks_share_the_gpu_on_the_live_config(tmp_path):
+    """The N-rank live path (`bench.py --config promethion_live --gpus N`, gloo, every rank on the one GPU of the box): what
+    the 8-GPU run does per rank - own channel range, own client, own models, barriers around K batches, one JSON line.
+    Four ranks, not eight: a GPU box admits at most six processes on its card and this test process is one of them (the
+    8-rank shape itself is rehearsed on CPU, tests/test_bench_cpu.py, tests/test_host_cpu.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["RS_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "promethion_live",
+                        "--reads-per-gpu", "64", "--steps", "6", "--warmup", "2"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["steps"] == 6 and out["config"]["channels_per_rank"] == 64
+    assert out["value"] > 0 and out["reads_received_per_s"] >= out["value"] and out["latency_samples"] == 6
+
+
 @pytest.mark.parametrize("dtype", ["f32w", "f32", "bf16x3"])
 def test_length_mismatch_is_contained_on_every_path(dev, dtype):
     """host lengths that disagree with the device's - above AND below - on the fused path of every dtype

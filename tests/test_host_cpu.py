@@ -188,3 +188,88 @@ def test_polya_end_is_prefix_stable():
                 assert part == full, (rid, n, part, full)
                 checked += 1
     assert checked > 60
+
+
+def _launch_raw(args, timeout=300):
+    return subprocess.run([sys.executable, "-m", "riser_amd.launch", *args], cwd=ROOT, capture_output=True, text=True,
+                          timeout=timeout,
+                          env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")} |
+                              {"PYTHONPATH": ROOT})
+
+
+def _csv_rows(path):
+    return sorted(ln.split(",", 1)[1] for ln in open(path).read().strip().split("\n")[1:] if not ln.startswith("batch_start"))
+
+
+def test_launcher_eight_ranks_stub(tmp_path):
+    """the PromethION deployment shape rehearsed on CPU: eight ranks, eight channel ranges, union of rows = one rank's"""
+    script = os.path.join(ROOT, "tests", "golden", "control.json")
+    common = ["--channels", "24", "--stub", "--replay-script", script]
+    one = _launch(["--gpus", "1", "--out", str(tmp_path / "one"), *common], ROOT)
+    eight = _launch(["--gpus", "8", "--out", str(tmp_path / "eight"), *common], ROOT)
+    assert eight["ranks"] == 8 and eight["channel_ranges"] == [[3 * r + 1, 3 * r + 3] for r in range(8)]
+    parts = [_csv_rows(str(tmp_path / f"eight.rank{r}.csv")) for r in range(8)]
+    assert sorted(sum(parts, [])) == _csv_rows(str(tmp_path / "one.rank0.csv"))
+    assert eight["reads_received"] == one["reads_received"] == 25 and eight["rank_failures"] == []
+
+
+def test_launcher_client_factory(tmp_path):
+    """--client pkg.module:factory(logger, first_channel, last_channel): the path a real deployment takes"""
+    script = os.path.join(ROOT, "tests", "golden", "control.json")
+    ref = _launch(["--gpus", "2", "--channels", "22", "--stub", "--replay-script", script, "--out", str(tmp_path / "ref")], ROOT)
+    fac = _launch(["--gpus", "2", "--channels", "22", "--stub", "--client", "tests.helpers:make_client", "--out",
+                   str(tmp_path / "fac")], ROOT)
+    for r in range(2):
+        assert _csv_rows(str(tmp_path / f"fac.rank{r}.csv")) == _csv_rows(str(tmp_path / f"ref.rank{r}.csv"))
+    assert fac["reads_received"] == ref["reads_received"] == 25
+
+
+def test_launcher_dead_rank_aborts_the_run_at_once(tmp_path):
+    """a rank that dies must be reported when it dies, not after every other rank has finished.  Rank 3
+    of 8 exits with code 3; the parent terminates the rest and exits non-zero with rank 3's stderr tail."""
+    import time
+    t0 = time.monotonic()
+    r = _launch_raw(["--gpus", "8", "--channels", "24", "--stub", "--replay-synthetic", "2", "--fail-rank", "3", "--out",
+                     str(tmp_path / "x")])
+    assert r.returncode != 0 and time.monotonic() - t0 < 40
+    assert "rank 3 (channels 10-12) exited with code 3" in r.stderr
+    assert "simulated failure" in r.stderr and "riser_amd.launch: rank 3 exited with code 3" in r.stderr
+
+
+def test_launcher_restarts_a_dead_rank_as_a_fresh_process(tmp_path):
+    """--on-rank-failure restart: the dead rank's channel range gets a fresh child; the run completes with every row"""
+    script = os.path.join(ROOT, "tests", "golden", "control.json")
+    marker = str(tmp_path / "died-once")
+    r = _launch_raw(["--gpus", "2", "--channels", "22", "--stub", "--replay-script", script, "--fail-rank", "1",
+                     "--fail-once", marker, "--on-rank-failure", "restart", "--out", str(tmp_path / "re")])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert [f["rank"] for f in out["rank_failures"]] == [1] and out["rank_failures"][0]["channels"] == [12, 22]
+    assert "started again as a fresh process" in r.stderr
+    one = _launch(["--gpus", "1", "--channels", "22", "--stub", "--replay-script", script, "--out", str(tmp_path / "one")], ROOT)
+    assert sorted(_csv_rows(str(tmp_path / "re.rank0.csv")) + _csv_rows(str(tmp_path / "re.rank1.csv"))) == \
+        _csv_rows(str(tmp_path / "one.rank0.csv"))
+    assert out["reads_received"] == one["reads_received"]
+
+
+def test_model_dir_convention(tmp_path):
+    """riser/riser.py:21-42: {target}_config_{kit}_{pore}.yaml / {target}_model_{kit}_{pore}.pth, pore by kit; the YAML of
+    the reference's shipped configs parses to the same object with and without PyYAML"""
+    from riser_amd import modeldir
+    assert modeldir.get_pore_version("RNA002") == "R9.4.1" and modeldir.get_pore_version("RNA004") == "RP4"
+    with pytest.raises(Exception, match="Invalid kit"):
+        modeldir.get_pore_version("RNA003")
+    cfg, pth = modeldir.model_files("model", "mtRNA", "RNA004")
+    assert cfg == os.path.join("model", "mtRNA_config_RNA004_RP4.yaml") and pth == os.path.join("model", "mtRNA_model_RNA004_RP4.pth")
+    text = ("model: cnn\nbatch_size: 32\nn_epochs: 30\nlearning_rate: 0.0001\n\ncnn:\n  n_layers: 12\n  depth: 1\n"
+            "  channels: [20,30,45,67,100,150,225,337,505,757,1135,1702]\n  kernels: [3,3,3,3,3,3,3,3,3,3,3,3]\n"
+            "  n_classes: 2\n  classifier: gap_fc # fc / gap_fc / gap\n")
+    p = tmp_path / "mRNA_config_RNA004_RP4.yaml"
+    p.write_text(text)
+    c = modeldir.get_config(str(p))
+    flat = modeldir._namespace(modeldir._parse_flat_yaml(text))
+    for obj in (c, flat):
+        assert obj.model == "cnn" and obj.learning_rate == 0.0001 and obj.cnn.n_layers == 12 and obj.cnn.depth == 1
+        assert obj.cnn.channels == list(synth.CHANNELS) and obj.cnn.kernels == [3] * 12 and obj.cnn.classifier == "gap_fc"
+    with pytest.raises(FileNotFoundError, match="riser/riser.py:35-42"):
+        modeldir.get_models(["globin"], None, "RNA004", str(tmp_path))

@@ -11,4 +11,13 @@ for d in sys.argv[1:]:
                 k = k.replace("void rs::(anonymous namespace)::", "").split("(")[0]
                 out[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"dispatches": max(len(v) for v in cs.values())} for k, cs in out.items()}
+# which kernels these counters belong to: bench.py reports `roofline.traffic` only while the tree's kernel sources still
+# hash to this value (riser_amd/supervise.py has no torch import; neither does this)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+try:
+    from riser_amd.build import csrc_sha16
+    res["_meta"] = {"csrc_sha16": csrc_sha16()}
+except Exception as e:                                   # noqa: BLE001 - a summary without the stamp is still a summary
+    res["_meta"] = {"csrc_sha16": None, "error": str(e)}
 print(json.dumps(res, indent=1, sort_keys=True))
