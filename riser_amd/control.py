@@ -31,8 +31,11 @@ is dropped at batch granularity once it holds >= 1000 entries (riser/control.py:
 """
 from __future__ import annotations
 
+import queue
+import threading
 import time
 from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -91,6 +94,7 @@ class _Pinned:
         self.buf = None
         self.used = 0
         self._copied = {}                      # stream -> event recorded behind the last copy issued from the scratch there
+        self._lock = threading.Lock()          # the staging thread of the slice pipeline takes pieces too
 
     def reset(self, need: int):
         """Start a new batch at offset 0 - once every copy of the previous batch has READ its source: a batch may return
@@ -103,23 +107,32 @@ class _Pinned:
 
     def _mark(self):
         st = torch.cuda.current_stream(self.device)
-        ev = self._copied.get(st.cuda_stream)
-        if ev is None:
-            ev = self._copied[st.cuda_stream] = torch.cuda.Event()
+        with self._lock:
+            ev = self._copied.get(st.cuda_stream)
+            if ev is None:
+                ev = self._copied[st.cuda_stream] = torch.cuda.Event()
         ev.record(st)
+
+    def _take(self, nbytes_list):
+        """-> (start, [(offset, nbytes)], end) of a run of 64-byte-aligned pieces, or None when the scratch is too small"""
+        with self._lock:
+            at0 = at = self.used
+            spans = []
+            for nb in nbytes_list:
+                spans.append((at, nb))
+                at = (at + nb + 63) & ~63
+            if at > self.buf.numel():
+                return None
+            self.used = at
+        return at0, spans, at
 
     def to_device_many(self, arrs) -> list:
         """several small contiguous 1-D arrays -> device tensors of their dtypes, as ONE asynchronous copy (a copy per array
         costs ~10 us of launch time each, and a batch uploads seven of them)"""
-        at0 = self.used
-        spans = []
-        at = at0
-        for a in arrs:
-            spans.append((at, a.nbytes))
-            at = (at + a.nbytes + 63) & ~63
-        if at > self.buf.numel():                                # not reserved for: one by one (blocking fall-back inside)
+        got = self._take([a.nbytes for a in arrs])
+        if got is None:                                          # not reserved for: one by one (blocking fall-back inside)
             return [self.to_device(a) for a in arrs]
-        self.used = at
+        at0, spans, at = got
         for a, (o, nb) in zip(arrs, spans):
             self.buf[o: o + nb].view(torch.from_numpy(a[:0]).dtype).numpy()[:] = a
         dev = self.buf[at0: at].to(self.device, non_blocking=True)
@@ -129,10 +142,10 @@ class _Pinned:
     def to_device(self, arr: np.ndarray) -> torch.Tensor:
         """arr (contiguous) -> device tensor of the same dtype, copied asynchronously on the current stream"""
         nb = arr.nbytes
-        at = self.used
-        self.used = (at + nb + 63) & ~63
-        if self.used > self.buf.numel():                         # not reserved for: fall back to a blocking copy
+        got = self._take([nb])
+        if got is None:                                          # not reserved for: fall back to a blocking copy
             return torch.from_numpy(arr).to(self.device)
+        at = got[0]
         host = self.buf[at: at + nb].view(torch.from_numpy(arr[:0]).dtype)
         host.numpy()[:] = arr
         dev = host.to(self.device, non_blocking=True)
@@ -195,6 +208,44 @@ class _Batch:
         else:
             np.concatenate(self.raws, out=out[:total])
         return total
+
+
+class _RowWriter:
+    """The CSV rows of batch k are formatted and written by this thread while the loop assesses batch k + 1
+    (riser/control.py:91-93,145-153 writes them inside the loop: same rows, same order, off the critical path).  The text
+    is built by `_hostpack.format_rows` without the interpreter lock; rows reach the file in batch order (one thread, one
+    queue) and `close()` - called before `target()` returns - waits for the last of them."""
+
+    MAX_PENDING = 16                      # batches: a writer that cannot keep up slows the loop down instead of growing
+
+    def __init__(self, sink, make_rows):
+        self._sink, self._make_rows = sink, make_rows
+        self._q = queue.Queue(maxsize=self.MAX_PENDING)
+        self._err = None
+        self._thread = threading.Thread(target=self._run, name="riser_amd-csv", daemon=True)
+        self._thread.start()
+
+    def put(self, *job):
+        if self._err is not None:
+            raise self._err
+        self._q.put(job)
+
+    def _run(self):
+        while True:
+            job = self._q.get()
+            if job is None:
+                return
+            if self._err is None:
+                try:
+                    self._sink.write(self._make_rows(*job))
+                except BaseException as e:                      # noqa: BLE001 - re-raised on the loop's thread
+                    self._err = e
+
+    def close(self):
+        self._q.put(None)
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
 
 
 class _SignalStore:
@@ -436,6 +487,7 @@ class SequencerControl:
         self._res_probs = self._res_dec = self._polya_host = self._polya_state_host = None
         self._pa_events = []                      # one per slice: the poly(A) scan's result is in pinned memory
         self._side, self._events = None, []       # PromethION-scale batches: the upload / poly(A) stream of the slice pipeline
+        self._stage_pool = None                   # ... and the host thread that stages the next slice
         self._channels_seen = 0
         self._reserved_for = 0
         self._ph = np.zeros(len(PHASES))
@@ -522,16 +574,14 @@ class SequencerControl:
 
         def upload_and_scan(k):
             """slice k: its new samples to the device rows, the poly(A) scan of its reads not in the cache launched, the
-            scan's result on its way to pinned memory - nothing here waits for the device"""
-            nonlocal t
+            scan's result on its way to pinned memory - nothing here waits for the device.  Runs on the loop's thread for
+            the first slice and on the staging thread for the others (the current device and stream are per thread)."""
             lo, hi = bounds[k], bounds[k + 1]
             part = batch.view(lo, hi)
-            with torch.cuda.stream(side):
+            with torch.cuda.device(dev), torch.cuda.stream(side):
                 offs = store.update(channels[lo:hi], part, self._pinned)
                 if side is not caller:
                     self._events[k].record(side)            # the slice's samples are in the rows behind this point
-                t, dt = self._tick(t, 1)
-                ph[1] += dt
                 end = np.zeros(hi - lo, dtype=np.int64)
                 if polyA_cache:
                     if _hp is not None and type(polyA_cache) is dict:
@@ -598,13 +648,21 @@ class SequencerControl:
             t, dt = self._tick(t, 3)
             ph[3] += dt
 
-        # slice k + 1 is staged, uploaded and scanned BEFORE the host waits for slice k's scan: the wait has the next
-        # slice's host work in front of it, and the classification of slice k runs under the staging of slice k + 2
+        # Slice k + 1 is staged, uploaded and scanned WHILE the loop's thread waits for slice k's scan, gates it and launches
+        # its classification: the staging runs on a second host thread (its memcpy and the waits of the loop's thread
+        # release the interpreter lock), so a PromethION-scale batch costs max(staging, gating) per slice, not their sum;
+        # the classification of slice k runs under the staging of slice k + 2.  What the two threads share: the pinned
+        # scratch (locked), the poly(A) cache (slices hold different reads; dict operations are atomic), the store's row
+        # tables (begin_batch assigned every row; slices touch different rows).
         staged = upload_and_scan(0)
+        t, ph[1] = self._tick(t, 1)
         for k in range(n_slices):
-            ahead = upload_and_scan(k + 1) if k + 1 < n_slices else None
+            ahead = self._stager().submit(upload_and_scan, k + 1) if k + 1 < n_slices else None
             gate_and_classify(k, staged)
-            staged = ahead
+            if ahead is not None:
+                staged = ahead.result()
+                t, dt = self._tick(t, 1)                   # what the loop's thread still had to wait for the staging
+                ph[1] += dt
         store.end_batch()
         if n_total == 0:
             if side is not caller:
@@ -626,6 +684,12 @@ class SequencerControl:
         t, ph[4] = self._tick(t, 4)
         return res
 
+    def _stager(self):
+        """the host thread that stages slice k + 1 of a PromethION-scale batch (created at the first such batch)"""
+        if self._stage_pool is None:
+            self._stage_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="riser_amd-stage")
+        return self._stage_pool
+
     @staticmethod
     def _tick(t_prev, _k):
         now = time.perf_counter()
@@ -646,15 +710,19 @@ class SequencerControl:
             t_stop = t_begin + duration_h * 3600
             tally = _MinuteTally(self.logger, t_begin)
             cache = {}
-            while client.is_running() and time.monotonic() < t_stop:
-                cache = self._run_batch(sink, mode, threshold, unblock_duration, cache, tally)
+            writer = _RowWriter(sink, self._csv_rows)
+            try:
+                while client.is_running() and time.monotonic() < t_stop:
+                    cache = self._run_batch(writer, mode, threshold, unblock_duration, cache, tally)
+            finally:
+                writer.close()                                   # every row is in the file before target() returns
             client.send_warning(_WARN_STOP)
             if not client.is_running():
                 self.logger.info("Client has stopped.")
             if time.monotonic() > t_stop:
                 self.logger.info(f"RISER has timed out after {duration_h} hours as requested.")
 
-    def _run_batch(self, sink, mode, threshold, unblock_duration, cache, tally):
+    def _run_batch(self, writer, mode, threshold, unblock_duration, cache, tally):
         t0 = time.monotonic()
         self._ph[:] = 0.0
         res = self.assess_batch(list(self.client.get_read_batch()), mode, threshold, cache)
@@ -679,7 +747,7 @@ class SequencerControl:
             self.batch_latencies.append(time.monotonic() - t0)
         t, self._ph[5] = self._tick(t, 5)
         if res is not None:
-            sink.write(self._csv_rows(res, t0, mode, threshold))
+            writer.put(res, t0, mode, threshold)                 # formatted and written by the writer thread
             t, self._ph[6] = self._tick(t, 6)
             self.batch_loop_times.append(time.monotonic() - t0)
             self.batch_phases.append(self._ph.copy())

@@ -118,6 +118,10 @@ __device__ __forceinline__ void dma_piece(unsigned voff, const __amdgpu_buffer_r
     const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
                  :: "v"(voff), "s"(m0v), "s"(rsrc) : "memory");
+#if defined(RS_EMU_DMA_X) && RS_EMU_DMA_X == 2       // measurement build: every staging piece issued twice (2 x the L2 -> LDS bytes)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                 :: "v"(voff), "s"(m0v), "s"(rsrc) : "memory");
+#endif
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -241,7 +245,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     // schedule below first reads it.  Compiler-issued vector-memory operations all sit between a barrier and the next
     // sub-stage's first piece, so they only ever make the counted wait stricter.
     auto stage_end = [&](auto KEEP_) {
+#if defined(RS_EMU_DMA_X) && RS_EMU_DMA_X == 2
+        constexpr int KEEP = 2 * decltype(KEEP_)::value;
+#else
         constexpr int KEEP = decltype(KEEP_)::value;
+#endif
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -319,6 +327,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     // the deferred pass (the epilogue, when the previous sub-stage ended a tile).  `dma(idx)` issues the idx-th of this
     // sub-stage's NDMA staging pieces of this wave, spread over the sub-stage's own passes.
     u32x4 keep_a[MT], keep_b[NT];
+#ifdef RS_ABL_NOFRAG
+    u32x4 nf_a0[MT], nf_b0[NT], nf_a1[MT], nf_b1[NT];
+#endif
     auto deferred_pass = [&]() {
 #if defined(RS_X2_DROP) && RS_X2_DROP == 2     // measurement build: split precision without the x hi * w lo term
         if constexpr (X3) return;
@@ -327,9 +338,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         if (X3 && !(a.terms & 4)) return;
 #endif
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
+#if defined(RS_EMU_MFMA_FRAC)                  // measurement build (tools/wino_x3_price.py): see substage()
+            if (RS_EMU_MFMA_FRAC == 2 && i >= (MT + 1) / 2) continue;
+#endif
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(keep_a[i], keep_b[j], acc[i][j]);
+        }
     };
     auto substage = [&](auto TAP, int xb, bool have_prev, auto NDMA_, auto&& dma, auto&& between) {
         constexpr int tap = decltype(TAP)::value;
@@ -341,21 +356,49 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
 #endif
         constexpr int GAP = NM / (NDMA + 1) > 0 ? NM / (NDMA + 1) : 1;
         const unsigned ax0 = a_rd[tap][0] + (unsigned)(xb * XS), ax1 = a_rd[tap][1] + (unsigned)(xb * XS);
+#ifdef RS_ABL_NOFRAG
+        // measurement build, results wrong: the fragments of the workgroup's FIRST sub-stage are re-used by every later one
+        // (no ds_read in the steady state): the upper bound of anything that reads fewer fragment bytes per MFMA - wider
+        // wave tiles, v_mfma_f32_32x32x16
+        u32x4(&a0)[MT] = nf_a0, (&b0)[NT] = nf_b0, (&a1)[MT] = nf_a1, (&b1)[NT] = nf_b1;
+        if (!have_prev) {
+#else
         u32x4 a0[MT], b0[NT], a1[MT], b1[NT];
+        {
+#endif
 #pragma unroll
         for (int j = 0; j < NT; ++j) b0[j] = *reinterpret_cast<const u32x4*>(lds + b_rd[0] + tap * WS + j * 16 * kRowB);
 #pragma unroll
         for (int i = 0; i < MT; ++i) a0[i] = *reinterpret_cast<const u32x4*>(lds + ax0 + i * 16 * kRowB);
+        }
+#if defined(RS_EMU_MFMA_FRAC)
+        if (have_prev && !(RS_EMU_MFMA_FRAC == 3 && tap == 0)) deferred_pass();     // tap 0 runs tap 2's deferred pass
+#else
         if (have_prev) deferred_pass();
+#endif
         between();
+#ifdef RS_ABL_NOFRAG
+        if (!have_prev)
+#endif
+        {
 #pragma unroll
         for (int i = 0; i < MT; ++i) a1[i] = *reinterpret_cast<const u32x4*>(lds + ax1 + i * 16 * kRowB);
 #pragma unroll
         for (int j = 0; j < NT; ++j) b1[j] = *reinterpret_cast<const u32x4*>(lds + b_rd[1] + tap * WS + j * 16 * kRowB);
+        }
         static_for<NM>([&](auto N_) {
             constexpr int n = decltype(N_)::value;
             constexpr int pass = n / (MT * NT), ij = n % (MT * NT), i = ij / NT, j = ij % NT;
-            if constexpr (pass == 0)
+#if defined(RS_EMU_MFMA_FRAC)
+            // measurement build, results wrong, timing only: what a Winograd lowering could gain AT BEST on this kernel's
+            // data path - the same staging (every DMA piece, every fragment read, the epilogue) with a fraction of the
+            // MFMAs: 2 = the upper half of the row blocks skipped in every pass (1/2: F(4,3)), 3 = tap 2 skipped (2/3: F(2,3))
+            constexpr bool emu_skip = (RS_EMU_MFMA_FRAC == 2 && i >= (MT + 1) / 2) || (RS_EMU_MFMA_FRAC == 3 && tap == 2);
+#else
+            constexpr bool emu_skip = false;
+#endif
+            if constexpr (emu_skip) {
+            } else if constexpr (pass == 0)
                 acc[i][j] = mfma16<F16>(a0[i], b0[j], acc[i][j]);       // hi * hi  (plain: h0 * h0)
             else {
 #ifdef RS_X3_MASK
@@ -558,7 +601,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         xb ^= 1;
     }
     // the walk's last sub-stage: its deferred pass and the last tile's epilogue
+#if !defined(RS_EMU_MFMA_FRAC) || RS_EMU_MFMA_FRAC != 3
     deferred_pass();
+#endif
     epilogue(done, done_cb, done_xb);
     RS_STAMP(2);
 #ifdef RS_RING_STAMPS

@@ -192,38 +192,84 @@ static PyObject* hp_gather(PyObject* self, PyObject* args) {
     return PyLong_FromSsize_t(at / 2);
 }
 
-/* growable byte sink */
+/* growable byte sink on the C heap: usable without the interpreter lock */
 typedef struct {
     char* p;
     size_t n, cap;
-} sink_t;
+    int oom;
+} csink_t;
 
-static int sink_put(sink_t* s, const char* src, size_t k) {
+static void cs_put(csink_t* s, const char* src, size_t k) {
+    if (s->oom) return;
     if (s->n + k + 1 > s->cap) {
         size_t cap = s->cap ? s->cap * 2 : 1 << 16;
         while (cap < s->n + k + 1) cap *= 2;
-        char* q = (char*)PyMem_Realloc(s->p, cap);
+        char* q = (char*)realloc(s->p, cap);
         if (!q) {
-            PyErr_NoMemory();
-            return -1;
+            s->oom = 1;
+            return;
         }
         s->p = q;
         s->cap = cap;
     }
     memcpy(s->p + s->n, src, k);
     s->n += k;
-    return 0;
 }
 
-static int sink_i64(sink_t* s, long long v) {
+static void cs_i64(csink_t* s, long long v) {
     char tmp[32];
     const int k = snprintf(tmp, sizeof(tmp), "%lld", v);
-    return sink_put(s, tmp, (size_t)k);
+    cs_put(s, tmp, (size_t)k);
+}
+
+/* repr() of a Python float without the interpreter: the shortest decimal string that reads back as the same double, in
+ * repr's layout (exponent form below 1e-4 and from 1e16 on, ".0" behind an integer).  A correctly rounded 15-digit
+ * decimal is the shortest form whenever one of <= 15 digits exists (trailing zeros stripped by %g); otherwise the
+ * correctly rounded 16-digit decimal if it reads back, else 17 digits - which is what David Gay's mode-0 conversion
+ * behind repr() returns (tests/test_host_cpu.py compares the two on 400 k values).  Returns the length. */
+static int fmt_double_repr(double v, char* out /* >= 40 bytes */) {
+    if (v != v) return snprintf(out, 40, "nan");
+    if (v - v != 0.0) return snprintf(out, 40, v > 0 ? "inf" : "-inf");
+    int k = 0;
+    const double mag = v < 0 ? -v : v;
+    /* a subnormal carries fewer than 15 significant digits: its shortest form can be shorter than its 15-digit rounding */
+    for (int prec = (mag != 0.0 && mag < 2.2250738585072014e-308) ? 1 : 15; prec <= 17; ++prec) {
+        k = snprintf(out, 40, "%.*g", prec, v);
+        if (prec == 17 || strtod(out, NULL) == v) break;
+    }
+    /* %g switches to the exponent form at 10^precision, repr at 10^16: values in [1e15, 1e17) can differ */
+    const double a = v < 0 ? -v : v;
+    if (a >= 1e15 && a < 1e17) {
+        if (a < 1e16 && memchr(out, 'e', (size_t)k)) {            /* repr: positional */
+            k = snprintf(out, 40, "%.1f", v);
+        } else if (a >= 1e16 && !memchr(out, 'e', (size_t)k)) {   /* repr: exponent form, shortest mantissa */
+            for (int prec = 0; prec <= 16; ++prec) {
+                k = snprintf(out, 40, "%.*e", prec, v);
+                if (prec == 16 || strtod(out, NULL) == v) break;
+            }
+        }
+    }
+    if (!memchr(out, '.', (size_t)k) && !memchr(out, 'e', (size_t)k)) {
+        out[k++] = '.';
+        out[k++] = '0';
+        out[k] = 0;
+    }
+    return k;
+}
+
+static PyObject* hp_repr_double(PyObject* self, PyObject* arg) {
+    const double v = PyFloat_AsDouble(arg);
+    if (v == -1.0 && PyErr_Occurred()) return NULL;
+    char tmp[40];
+    const int k = fmt_double_repr(v, tmp);
+    return PyUnicode_FromStringAndSize(tmp, k);
 }
 
 /* format_rows(head, reads, sel_i64, channels_i64, nsamp_i32, mid, p_on_f64 [n, m], m, tail, dec_u8, names) -> str
  * row k: head + str(reads[sel[k]].id) + "," + channels[k] + "," + nsamp[k] + mid + ";".join(repr(p_on[k][j])) + tail +
- * names[dec[k]] + "\n"   (riser/control.py:145-153: p.item() of an fp32 tensor printed with str() = repr of the double) */
+ * names[dec[k]] + "\n"   (riser/control.py:145-153: p.item() of an fp32 tensor printed with str() = repr of the double).
+ * Two phases: the ids are collected with the interpreter lock held (references kept until the end), the text is built
+ * WITHOUT it - a writer thread formats the rows of batch k while the control loop assesses batch k + 1. */
 static PyObject* hp_format_rows(PyObject* self, PyObject* args) {
     const char *head, *mid, *tail;
     Py_ssize_t head_n, mid_n, tail_n;
@@ -262,7 +308,6 @@ static PyObject* hp_format_rows(PyObject* self, PyObject* args) {
     }
     const Py_ssize_t n = bs.len / (Py_ssize_t)sizeof(int64_t);
     const Py_ssize_t n_reads = PyList_GET_SIZE(reads), n_names = PyTuple_GET_SIZE(names);
-    sink_t s = {NULL, 0, 0};
     int bad = 0;
     if (bc.len < (Py_ssize_t)(n * sizeof(int64_t)) || bn.len < (Py_ssize_t)(n * sizeof(int32_t)) ||
         bp.len < (Py_ssize_t)(n * m * sizeof(double)) || bd.len < n) {
@@ -274,6 +319,24 @@ static PyObject* hp_format_rows(PyObject* self, PyObject* args) {
     const int32_t* ns_ = (const int32_t*)bn.buf;
     const double* p_ = (const double*)bp.buf;
     const uint8_t* d_ = (const uint8_t*)bd.buf;
+    /* ---- phase 1, interpreter lock held: the id text of every row, the decision names ---- */
+    PyObject* keep = bad ? NULL : PyList_New(n);                  /* owns the id strings while phase 2 reads their bytes */
+    const char** idp = (const char**)malloc((size_t)(n ? n : 1) * sizeof(char*));
+    Py_ssize_t* idn = (Py_ssize_t*)malloc((size_t)(n ? n : 1) * sizeof(Py_ssize_t));
+    const char* namep[256];
+    Py_ssize_t namen[256];
+    if (!bad && (!keep || !idp || !idn)) {
+        PyErr_NoMemory();
+        bad = 1;
+    }
+    if (!bad && n_names > 256) {
+        PyErr_SetString(PyExc_ValueError, "format_rows: more than 256 decision names");
+        bad = 1;
+    }
+    for (Py_ssize_t j = 0; j < n_names && !bad; ++j) {
+        namep[j] = PyUnicode_AsUTF8AndSize(PyTuple_GET_ITEM(names, j), &namen[j]);
+        if (!namep[j]) bad = 1;
+    }
     for (Py_ssize_t k = 0; k < n && !bad; ++k) {
         if (sel_[k] < 0 || sel_[k] >= n_reads || d_[k] >= n_names) {
             PyErr_SetString(PyExc_ValueError, "format_rows: index out of range");
@@ -291,25 +354,35 @@ static PyObject* hp_format_rows(PyObject* self, PyObject* args) {
             bad = 1;
             break;
         }
-        Py_ssize_t idn;
-        const char* idc = PyUnicode_AsUTF8AndSize(ids, &idn);
-        if (!idc || sink_put(&s, head, (size_t)head_n) || sink_put(&s, idc, (size_t)idn) || sink_put(&s, ",", 1) ||
-            sink_i64(&s, ch_[k]) || sink_put(&s, ",", 1) || sink_i64(&s, ns_[k]) || sink_put(&s, mid, (size_t)mid_n))
-            bad = 1;
-        Py_DECREF(ids);
-        for (int j = 0; j < m && !bad; ++j) {
-            char* txt = PyOS_double_to_string(p_[k * m + j], 'r', 0, Py_DTSF_ADD_DOT_0, NULL);
-            if (!txt) {
-                bad = 1;
-                break;
+        PyList_SET_ITEM(keep, k, ids);                            /* steals the reference */
+        idp[k] = PyUnicode_AsUTF8AndSize(ids, &idn[k]);
+        if (!idp[k]) bad = 1;
+    }
+    /* ---- phase 2, no interpreter lock: the text ---- */
+    csink_t s = {NULL, 0, 0, 0};
+    if (!bad) {
+        Py_BEGIN_ALLOW_THREADS
+        char tmp[40];
+        for (Py_ssize_t k = 0; k < n; ++k) {
+            cs_put(&s, head, (size_t)head_n);
+            cs_put(&s, idp[k], (size_t)idn[k]);
+            cs_put(&s, ",", 1);
+            cs_i64(&s, ch_[k]);
+            cs_put(&s, ",", 1);
+            cs_i64(&s, ns_[k]);
+            cs_put(&s, mid, (size_t)mid_n);
+            for (int j = 0; j < m; ++j) {
+                if (j) cs_put(&s, ";", 1);
+                cs_put(&s, tmp, (size_t)fmt_double_repr(p_[k * m + j], tmp));
             }
-            if ((j && sink_put(&s, ";", 1)) || sink_put(&s, txt, strlen(txt))) bad = 1;
-            PyMem_Free(txt);
+            cs_put(&s, tail, (size_t)tail_n);
+            cs_put(&s, namep[d_[k]], (size_t)namen[d_[k]]);
+            cs_put(&s, "\n", 1);
         }
-        if (!bad) {
-            Py_ssize_t dn;
-            const char* dc = PyUnicode_AsUTF8AndSize(PyTuple_GET_ITEM(names, d_[k]), &dn);
-            if (!dc || sink_put(&s, tail, (size_t)tail_n) || sink_put(&s, dc, (size_t)dn) || sink_put(&s, "\n", 1)) bad = 1;
+        Py_END_ALLOW_THREADS
+        if (s.oom) {
+            PyErr_NoMemory();
+            bad = 1;
         }
     }
     PyBuffer_Release(&bs);
@@ -319,7 +392,10 @@ static PyObject* hp_format_rows(PyObject* self, PyObject* args) {
     PyBuffer_Release(&bd);
     PyObject* res = NULL;
     if (!bad) res = PyUnicode_DecodeUTF8(s.p ? s.p : "", (Py_ssize_t)s.n, "strict");
-    PyMem_Free(s.p);
+    free(s.p);
+    free((void*)idp);
+    free(idn);
+    Py_XDECREF(keep);
     return res;
 }
 
@@ -450,7 +526,8 @@ static PyObject* hp_lookup(PyObject* self, PyObject* args) {
 static PyMethodDef methods[] = {
     {"lengths", hp_lengths, METH_VARARGS, "lengths(reads, out_int64): samples of every read's raw_data"},
     {"gather", hp_gather, METH_VARARGS, "gather(reads, start_int64, out_int16) -> samples written"},
-    {"format_rows", hp_format_rows, METH_VARARGS, "CSV rows of one batch as one string"},
+    {"format_rows", hp_format_rows, METH_VARARGS, "CSV rows of one batch as one string (text built without the GIL)"},
+    {"repr_double", hp_repr_double, METH_O, "repr(float) as format_rows writes it (test hook)"},
     {"unpack", hp_unpack, METH_VARARGS, "unpack(entries, channels_int64) -> reads: splits [(channel, read), ...]"},
     {"attrs", hp_attrs, METH_VARARGS, "attrs(reads, name) -> [getattr(r, name) for r in reads]"},
     {"lookup", hp_lookup, METH_VARARGS, "lookup(dict, keys, out_int64): out[i] = dict.get(keys[i], 0)"},

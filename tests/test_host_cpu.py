@@ -273,3 +273,15 @@ def test_model_dir_convention(tmp_path):
         assert obj.cnn.channels == list(synth.CHANNELS) and obj.cnn.kernels == [3] * 12 and obj.cnn.classifier == "gap_fc"
     with pytest.raises(FileNotFoundError, match="riser/riser.py:35-42"):
         modeldir.get_models(["globin"], None, "RNA004", str(tmp_path))
+
+
+def test_csv_double_format_is_python_repr(hp):
+    """the rows' probabilities are written as str(p.item()) writes them (riser/control.py:152): repr of the double.  The
+    writer thread formats them without the interpreter (csrc/hostpack.c:fmt_double_repr): same text, digit for digit"""
+    rng = np.random.default_rng(5)
+    vals = list(rng.random(60000, dtype=np.float32).astype(np.float64)) + list((rng.random(30000) ** 9).astype(np.float32).astype(np.float64))
+    vals += list(rng.random(20000)) + list(np.exp(rng.uniform(-60, 60, 20000))) + list(rng.random(2000) * 1e-310)
+    vals += [0.0, -0.0, 1.0, 0.5, 1e-5, 1e-4, 9.999e-5, 1e15, 1e16, 1e17, 1e22, 9999999999999998.0, 1e16 + 2, 5e-324,
+             1.7976931348623157e308, 2.0 ** -149, float("nan"), float("inf"), -float("inf"), 0.1, 1 / 3, 2.0 ** 53 + 2]
+    bad = [(v, hp.repr_double(float(v)), repr(float(v))) for v in vals if hp.repr_double(float(v)) != repr(float(v))]
+    assert not bad, bad[:5]
