@@ -551,7 +551,9 @@ class SequencerControl:
         store = self._store
         store.begin_batch(channels, batch.lens)
         n_slices = 1 if B <= self.SLICE_READS * 3 // 2 else -(-B // self.SLICE_READS)
-        bounds = [B * k // n_slices for k in range(n_slices + 1)]
+        # the first slice is half a slice: nothing runs on the device until its samples are staged and uploaded
+        bounds = ([0, B] if n_slices == 1 else
+                  [0] + [B * (2 * k + 1) // (2 * n_slices - 1) for k in range(n_slices - 1)] + [B])
         caller = torch.cuda.current_stream(dev)
         if n_slices > 1:
             if self._side is None:

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     auto tile_origin = [&](int q, int& tm0, int& tn0) -> bool {
         int mi, nt_;
         const bool ok = walk_tile(a.walk, q, mi, nt_);
-        tm0 = mi * BMP;
+        tm0 = a.walk.m_base + mi * BMP;
         tn0 = nt_ * BN;
         return ok;
     };
@@ -549,21 +549,27 @@ size_t lds_bytes(const Shape& s, int kc) {
 
 // Tile shape for a layer launch.  Model: one persistent workgroup per CU; time = rounds x (MFMA
 // issue of a tile + per-item staging and barrier + per-tile epilogue), in SIMD cycles.
+double tile_cost(const Shape& s, int kc, int nch) {
+    if (lds_bytes(s, kc) > 160 * 1024) return -1.0;
+    const int bmp = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
+    const double slots = kc;                                    // 4 components x kc / 4 k-steps
+    const double staged = ((2.0 * bmp + 2) + 4.0 * bnt * 16) * kc * 4.0;   // bytes per item
+    const double item = slots * (2.0 * s.mt * s.nt * 32.0 + 4.0 * (s.mt + s.nt)) + 900.0 + 0.06 * staged;
+    return nch * item + 1500.0 + 60.0 * s.mt * s.nt;
+}
+
 const Shape* choose_shape(int64_t rows_out, int n16, int kc, int nch, int num_cu, double* cost_out) {
     const Shape* best = nullptr;
     double best_cost = 1e300;
     for (int k = 0; k < kNumShapes; ++k) {
         const Shape& s = kShapes[k];
-        if (lds_bytes(s, kc) > 160 * 1024) continue;
+        const double tile = tile_cost(s, kc, nch);
+        if (tile < 0) continue;
         const int bmp = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
         const int64_t mtiles = (rows_out + bmp - 1) / bmp;
         const int64_t ntiles = (n16 + bnt - 1) / bnt;
         const int64_t tiles = mtiles * ntiles;
         const int64_t rounds = (tiles + num_cu - 1) / num_cu;
-        const double slots = kc;                                    // 4 components x kc / 4 k-steps
-        const double staged = ((2.0 * bmp + 2) + 4.0 * bnt * 16) * kc * 4.0;   // bytes per item
-        const double item = slots * (2.0 * s.mt * s.nt * 32.0 + 4.0 * (s.mt + s.nt)) + 900.0 + 0.06 * staged;
-        const double tile = nch * item + 1500.0 + 60.0 * s.mt * s.nt;
         const double cost = (double)rounds * tile;
         if (cost < best_cost) {
             best_cost = cost;
@@ -610,18 +616,23 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
         return RS_ERR_ARG;
     }
     const int n16 = round_up(L.c_out, 16) / 16;
-    const Shape* s = choose_shape(rows64 / 2, n16, p.kc, p.nch, num_cu, nullptr);
+    double single_cost = 0.0;
+    const Shape* s = choose_shape(rows64 / 2, n16, p.kc, p.nch, num_cu, &single_cost);
+    bool pinned = false;                                          // a forced, fused or tuned shape runs as one launch
     if (const char* force = L.hooks->force_wino; *force) {        // tuning aid: "layer:wm,wn,mt,nt;..."
         int l, wm, wn, mt, nt;
         for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
             if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
                 for (int k = 0; k < kNumShapes; ++k)
                     if (kShapes[k].wm == wm && kShapes[k].wn == wn && kShapes[k].mt == mt && kShapes[k].nt == nt &&
-                        lds_bytes(kShapes[k], p.kc) <= 160 * 1024)
+                        lds_bytes(kShapes[k], p.kc) <= 160 * 1024) {
                         s = &kShapes[k];
+                        pinned = true;
+                    }
     }
     const bool fused = fuse_xs != nullptr;
     if (fused) {
+        pinned = true;
         if (!conv_wino_can_fuse0(L, P_in) || !fuse_w0) {
             set_error("conv_wino: layer cannot take the fused layer-0 path");
             return RS_ERR_ARG;
@@ -629,12 +640,14 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
         for (int k = 0; k < kNumShapes; ++k)
             if (kShapes[k].wm == 8 && kShapes[k].wn == 1 && kShapes[k].mt == 2 && kShapes[k].nt == 2) s = &kShapes[k];
     }
-    if (const int k = tuned_shape(L, rows64); k >= 0 && conv_wino_shape_ok(L, k)) s = &kShapes[k];
+    if (const int k = tuned_shape(L, rows64); k >= 0 && conv_wino_shape_ok(L, k)) {
+        s = &kShapes[k];
+        pinned = true;
+    }
     if (!s) {
         set_error("conv_wino: no tile shape fits (kc=%d)", p.kc);
         return RS_ERR_ARG;
     }
-    const int BMP = s->wm * 16 * s->mt, BN = s->wn * 16 * s->nt;
     WinoArgs a;
     a.xs = fuse_xs;
     a.xs_bytes = (unsigned)std::min<int64_t>(rows64 * 2 * 4, 0x7fffffffLL);      // B * P0 floats (P0 = 2 * P_in)
@@ -673,16 +686,51 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
     a.cp_out = L.cp_out;
     a.nch = p.nch;
     a.shift_out = layer_index + 1;
-    const size_t lds = lds_bytes(*s, p.kc);
-    KernelFn fn = fused ? kFusedL1 : s->fn[p.kc == 16 ? 0 : p.kc == 20 ? 1 : 2];
-    RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024));
-    const int n_mtiles = (a.rows_out + BMP - 1) / BMP, n_ntiles = (n16 * 16 + BN - 1) / BN;
-    const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
-    const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 2.0 * BMP, 4.0 * BN, check_dead, !L.hooks->no_rect_order);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, a);
-    RS_HIP(hipGetLastError());
+    // one launch over the row tiles [m_base, m_base + n_mtiles x BMP) of shape sh
+    auto launch_part = [&](const Shape& sh, int m_base, int n_mtiles) -> int {
+        const int BN_ = sh.wn * 16 * sh.nt;
+        KernelFn fn = fused ? kFusedL1 : sh.fn[p.kc == 16 ? 0 : p.kc == 20 ? 1 : 2];
+        RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        const int n_ntiles = (n16 * 16 + BN_ - 1) / BN_;
+        const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
+        const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+        a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 2.0 * sh.wm * 16 * sh.mt, 4.0 * BN_, check_dead,
+                           !L.hooks->no_rect_order);
+        a.walk.m_base = m_base;
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds_bytes(sh, p.kc), st, a);
+        RS_HIP(hipGetLastError());
+        return RS_OK;
+    };
+    TailSplit split;
+    if (!pinned && !L.hooks->no_tail_split)
+        split = plan_tail_split(
+            kNumShapes, (int64_t)a.rows_out, num_cu, single_cost, [&](int k) { return tile_cost(kShapes[k], p.kc, p.nch); },
+            [&](int k) { return kShapes[k].wm * 16 * kShapes[k].mt; },
+            [&](int k) { return (n16 + kShapes[k].wn * kShapes[k].nt - 1) / (kShapes[k].wn * kShapes[k].nt); },
+            [&](int64_t r, double* c) {
+                const Shape* t = choose_shape(r, n16, p.kc, p.nch, num_cu, c);
+                return t ? (int)(t - kShapes) : -1;
+            });
+    int BMP, BN;
+    if (split.head_shape >= 0) {
+        const Shape &h = kShapes[split.head_shape], &t = kShapes[split.tail_shape];
+        if (L.hooks->tail_debug)
+            fprintf(stderr, "[tail-split] layer %d: head %dx%dx%dx%d x %d row tiles, tail %dx%dx%dx%d; planned %.0f vs %.0f cycles\n",
+                    layer_index, h.wm, h.wn, h.mt, h.nt, split.head_mtiles, t.wm, t.wn, t.mt, t.nt, split.cost, single_cost);
+        BMP = h.wm * 16 * h.mt;
+        BN = h.wn * 16 * h.nt;
+        int rc = launch_part(h, 0, split.head_mtiles);
+        if (rc != RS_OK) return rc;
+        const int m_base = split.head_mtiles * BMP, tbm = t.wm * 16 * t.mt;
+        rc = launch_part(t, m_base, (a.rows_out - m_base + tbm - 1) / tbm);
+        if (rc != RS_OK) return rc;
+    } else {
+        BMP = s->wm * 16 * s->mt;
+        BN = s->wn * 16 * s->nt;
+        const int rc = launch_part(*s, 0, (a.rows_out + BMP - 1) / BMP);
+        if (rc != RS_OK) return rc;
+    }
     if (bm_out) *bm_out = 2 * BMP;          // reported in conv rows, like the direct kernels
     if (bn_out) *bn_out = BN;
     return RS_OK;

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
     auto tile_origin = [&](int q, int& tm0, int& tn0) -> bool {
         int mi, nt_;
         const bool ok = walk_tile(a.walk, q, mi, nt_);
-        tm0 = mi * BG;
+        tm0 = a.walk.m_base + mi * BG;
         tn0 = nt_ * BN;
         return ok;
     };
@@ -449,26 +449,32 @@ size_t lds_bytes(const Shape& s, int kc) {
     return 2 * (size_t)(4 * (bg + 1) + 6 * bn) * (kc + 2) * sizeof(float);
 }
 
+// per slot: MFMAs of the two waves of a SIMD, fragment reads, 1/6 of the k-step's input transform (12 VALU
+// per MT, not hidden behind the MFMAs); per item: fixed cost, staging, and the activation slab's trip from
+// L2 / Infinity Cache (the weight slab is an L2 hit).  Calibrated on tools/shape_sweep.py (B = 512).
+double tile_cost(const Shape& s, int kc, int nch) {
+    if (lds_bytes(s, kc) > 160 * 1024) return -1.0;
+    const int bg = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
+    const double slots = 6.0 * kc / 4.0;
+    const double staged = ((4.0 * bg + 2) + 6.0 * bnt * 16) * kc * 4.0;
+    const double xslab = (4.0 * bg + 2) * kc * 4.0;
+    const double item = slots * (2.0 * s.mt * s.nt * 32.0 + 6.0 * (s.mt + s.nt) + 12.0 * s.mt) + 900.0 +
+                        0.06 * staged + 0.02 * xslab;
+    return nch * item + 1500.0 + 90.0 * s.mt * s.nt;
+}
+
 const Shape* choose_shape(int64_t groups, int n16, int kc, int nch, int num_cu, double* cost_out) {
     const Shape* best = nullptr;
     double best_cost = 1e300;
     for (int k = 0; k < kNumShapes; ++k) {
         const Shape& s = kShapes[k];
-        if (lds_bytes(s, kc) > 160 * 1024) continue;
+        const double tile = tile_cost(s, kc, nch);
+        if (tile < 0) continue;
         const int bg = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
         const int64_t mtiles = (groups + bg - 1) / bg;
         const int64_t ntiles = (n16 + bnt - 1) / bnt;
         const int64_t tiles = mtiles * ntiles;
         const int64_t rounds = (tiles + num_cu - 1) / num_cu;
-        const double slots = 6.0 * kc / 4.0;
-        const double staged = ((4.0 * bg + 2) + 6.0 * bnt * 16) * kc * 4.0;
-        // per slot: MFMAs of the two waves of a SIMD, fragment reads, 1/6 of the k-step's input transform (12 VALU
-        // per MT, not hidden behind the MFMAs); per item: fixed cost, staging, and the activation slab's trip from
-        // L2 / Infinity Cache (the weight slab is an L2 hit).  Calibrated on tools/shape_sweep.py (B = 512).
-        const double xslab = (4.0 * bg + 2) * kc * 4.0;
-        const double item = slots * (2.0 * s.mt * s.nt * 32.0 + 6.0 * (s.mt + s.nt) + 12.0 * s.mt) + 900.0 +
-                            0.06 * staged + 0.02 * xslab;
-        const double tile = nch * item + 1500.0 + 90.0 * s.mt * s.nt;
         const double cost = (double)rounds * tile;
         if (cost < best_cost) {
             best_cost = cost;
@@ -511,22 +517,28 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
     }
     const int n16 = round_up(L.c_out, 16) / 16;
     const int64_t groups = (rows64 + 3) / 4;
-    const Shape* s = choose_shape(groups, n16, p.kc, p.nch, num_cu, nullptr);
+    double single_cost = 0.0;
+    const Shape* s = choose_shape(groups, n16, p.kc, p.nch, num_cu, &single_cost);
+    bool pinned = false;                                          // a forced or tuned shape runs as one launch
     if (const char* force = L.hooks->force_wino4; *force) {       // tuning aid: "layer:wm,wn,mt,nt;..."
         int l, wm, wn, mt, nt;
         for (const char* q = force; q && *q; q = strchr(q, ';') ? strchr(q, ';') + 1 : nullptr)
             if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
                 for (int k = 0; k < kNumShapes; ++k)
                     if (kShapes[k].wm == wm && kShapes[k].wn == wn && kShapes[k].mt == mt && kShapes[k].nt == nt &&
-                        lds_bytes(kShapes[k], p.kc) <= 160 * 1024)
+                        lds_bytes(kShapes[k], p.kc) <= 160 * 1024) {
                         s = &kShapes[k];
+                        pinned = true;
+                    }
     }
-    if (const int k = tuned_shape(L, rows64); k >= 0 && conv_wino4_shape_ok(L, k)) s = &kShapes[k];
+    if (const int k = tuned_shape(L, rows64); k >= 0 && conv_wino4_shape_ok(L, k)) {
+        s = &kShapes[k];
+        pinned = true;
+    }
     if (!s) {
         set_error("conv_wino4: no tile shape fits (kc=%d)", p.kc);
         return RS_ERR_ARG;
     }
-    const int BG = s->wm * 16 * s->mt, BN = s->wn * 16 * s->nt;
     Wino4Args a;
     a.x = d_x;
     a.w = static_cast<const float*>(L.d_w);
@@ -548,16 +560,51 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
     a.cp_out = L.cp_out;
     a.nch = p.nch;
     a.shift_out = layer_index + 1;
-    const int n_mtiles = (a.n_groups + BG - 1) / BG, n_ntiles = (n16 * 16 + BN - 1) / BN;
-    const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
-    const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-    a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 4.0 * BG, 6.0 * BN, check_dead, !L.hooks->no_rect_order);
-    const size_t lds = lds_bytes(*s, p.kc);
-    KernelFn fn = s->fn[p.kc == 16 ? 0 : 1];
-    RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, a);
-    RS_HIP(hipGetLastError());
+    // one launch over the row tiles [m_base, m_base + n_mtiles x BG) of shape sh
+    auto launch_part = [&](const Shape& sh, int m_base, int n_mtiles) -> int {
+        const int BN = sh.wn * 16 * sh.nt;
+        const int n_ntiles = (n16 * 16 + BN - 1) / BN;
+        const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
+        const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
+        a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 4.0 * sh.wm * 16 * sh.mt, 6.0 * BN, check_dead,
+                           !L.hooks->no_rect_order);
+        a.walk.m_base = m_base;
+        KernelFn fn = sh.fn[p.kc == 16 ? 0 : 1];
+        RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds_bytes(sh, p.kc), st, a);
+        RS_HIP(hipGetLastError());
+        return RS_OK;
+    };
+    TailSplit split;
+    if (!pinned && !L.hooks->no_tail_split)
+        split = plan_tail_split(
+            kNumShapes, groups, num_cu, single_cost, [&](int k) { return tile_cost(kShapes[k], p.kc, p.nch); },
+            [&](int k) { return kShapes[k].wm * 16 * kShapes[k].mt; },
+            [&](int k) { return (n16 + kShapes[k].wn * kShapes[k].nt - 1) / (kShapes[k].wn * kShapes[k].nt); },
+            [&](int64_t g, double* c) {
+                const Shape* t = choose_shape(g, n16, p.kc, p.nch, num_cu, c);
+                return t ? (int)(t - kShapes) : -1;
+            });
+    int BG, BN;
+    if (split.head_shape >= 0) {
+        const Shape &h = kShapes[split.head_shape], &t = kShapes[split.tail_shape];
+        if (L.hooks->tail_debug)
+            fprintf(stderr, "[tail-split] layer %d: head %dx%dx%dx%d x %d row tiles, tail %dx%dx%dx%d; planned %.0f vs %.0f cycles\n",
+                    layer_index, h.wm, h.wn, h.mt, h.nt, split.head_mtiles, t.wm, t.wn, t.mt, t.nt, split.cost, single_cost);
+        BG = h.wm * 16 * h.mt;
+        BN = h.wn * 16 * h.nt;
+        int rc = launch_part(h, 0, split.head_mtiles);
+        if (rc != RS_OK) return rc;
+        const int m_base = split.head_mtiles * BG, tbg = t.wm * 16 * t.mt;
+        rc = launch_part(t, m_base, (int)((groups - m_base + tbg - 1) / tbg));
+        if (rc != RS_OK) return rc;
+    } else {
+        BG = s->wm * 16 * s->mt;
+        BN = s->wn * 16 * s->nt;
+        const int rc = launch_part(*s, 0, (a.n_groups + BG - 1) / BG);
+        if (rc != RS_OK) return rc;
+    }
     if (bm_out) *bm_out = 4 * BG;           // reported in conv rows, like the other kernels
     if (bn_out) *bn_out = BN;
     return RS_OK;

@@ -24,6 +24,9 @@ struct WalkArgs {
     int gm, gn, n_mb;        // rectangle order (gm == 0: n-major)
     int q_total;             // order indices in all (>= n_mtiles * n_ntiles)
     int check_dead;          // 0: no tile can be all padding (skip the test and the rotation)
+    int m_base;              // first row unit (the kernel's own: pooled rows / F(4,3) groups) of this launch's row tiles: a
+                             // layer may run as a HEAD launch of whole rounds of a large tile shape and a TAIL launch of a
+                             // smaller one over the rows behind it (plan_tail_split below)
 };
 
 // host: fill a WalkArgs for a launch of `grid` workgroups on `num_cu` CUs.  x_rows / w_rows = rows per K channel
@@ -57,6 +60,50 @@ inline WalkArgs plan_walk(int n_mtiles, int n_ntiles, int64_t grid, int num_cu, 
         }
     }
     return w;
+}
+
+// A launch costs (rounds over the CUs) x (one tile): 300 tiles of the best shape on 256 CUs cost two full rounds for 1.17
+// rounds of work.  Host-side search shared by the fp32 Winograd kernels: run `head_mtiles` row tiles of shape h - as many
+// whole rounds as the grid holds - and leave the rows behind them to a second launch with the shape that suits THAT row
+// count best.  Every output keeps its accumulation order (it does not depend on the tile shape: the batch-invariance
+// tests), so the bits are those of the single launch.  cost units: the planners' SIMD cycles.
+struct TailSplit {
+    int head_shape = -1;     // -1: single launch
+    int head_mtiles = 0;
+    int tail_shape = -1;
+    double cost = 0.0;
+};
+
+// tile_cost(k) / bm(k) / ntiles(k): per-tile cost, row units per tile and channel tiles of shape k (k < n_shapes, < 0 cost =
+// shape unusable); best_single(rows, &cost) -> best shape for a launch over `rows` row units.
+template <class TileCost, class Bm, class Ntiles, class BestSingle>
+inline TailSplit plan_tail_split(int n_shapes, int64_t rows, int num_cu, double single_cost, TileCost tile_cost, Bm bm,
+                                 Ntiles ntiles, BestSingle best_single) {
+    constexpr double kLaunch = 6000.0;        // a second launch: boundary + its own prologue
+    TailSplit out;
+    out.cost = single_cost;
+    for (int h = 0; h < n_shapes; ++h) {
+        const double tc = tile_cost(h);
+        if (tc < 0) continue;
+        const int64_t n_m = (rows + bm(h) - 1) / bm(h), n_n = ntiles(h);
+        const int64_t tiles = n_m * n_n;
+        const int64_t full = tiles / num_cu;                     // whole rounds the launch holds
+        if (full < 1 || tiles % num_cu == 0) continue;
+        const int64_t m1 = full * num_cu / n_n;                  // row tiles of those rounds
+        if (m1 < 1 || m1 >= n_m) continue;
+        const int64_t head_rounds = (m1 * n_n + num_cu - 1) / num_cu;
+        double tail_cost = 0.0;
+        const int t = best_single(rows - m1 * bm(h), &tail_cost);
+        if (t < 0) continue;
+        const double cost = head_rounds * tc + tail_cost + kLaunch;
+        if (cost < 0.97 * single_cost && cost < out.cost) {          // the margin is against ONE launch; the best split wins
+            out.cost = cost;
+            out.head_shape = h;
+            out.head_mtiles = (int)m1;
+            out.tail_shape = t;
+        }
+    }
+    return out;
 }
 
 #ifdef __HIPCC__

@@ -248,11 +248,29 @@ class Model:
             return 1 << 30
         return max(1, nv.lib().rs_max_batch(self._h, int(lmax)))
 
+    # samples (reads x padded length) per library call beyond which a batch is cut into equal sub-batches: throughput is flat
+    # from ~1000 reads of 16000 samples on and falls off once a layer's activations outgrow the 256 MB Infinity Cache
+    # (profiles/r04_batch_sweep_*.txt: fp32 4096 reads -4 %, split precision 2048 reads -5 %; two bytes more per element there)
+    _CALL_SAMPLES = {"f32w": 2048 << 14, "f32": 2048 << 14, "bf16": 2048 << 14, "f16": 2048 << 14,
+                     "bf16x3": 1024 << 14, "f16x3": 1024 << 14}
+
+    def call_batch(self, B: int, lmax: int) -> int:
+        """Reads per library call for a batch of B reads of up to lmax samples: B itself, or - beyond the 2 GiB buffer
+        window (max_batch) or the cache-friendly size - the size of equal sub-batches.  Reads are independent and their
+        bits do not depend on their batch-mates, so the cut changes nothing but the time."""
+        cap = self.max_batch(lmax)
+        if self._seq is None:
+            cap = min(cap, max(512, self._CALL_SAMPLES.get(self.dtype, 2048 << 14) // ((int(lmax) // 1024 + 1) * 1024)))
+        if B <= cap:
+            return B
+        n = -(-B // cap)
+        return min(cap, -(-(-(-B // n)) // 64) * 64)
+
     def reserve(self, B: int, lmax: int):
         """Allocate the workspace of the current stream for batches of up to B reads of up to lmax samples now (a
         growing workspace is a device allocation inside some later call)."""
         if self._h is not None:
-            B = max(1, min(int(B), self.max_batch(lmax)))
+            B = max(1, self.call_batch(int(B), lmax))
             self._ws.get(nv.lib().rs_workspace_bytes(self._h, B, int(lmax)))
 
     def _check_lengths(self, lens_host: np.ndarray):
@@ -314,7 +332,7 @@ class Model:
             raise ValueError("a length exceeds the row pitch")
         if self._seq is not None:
             return self._seq_forward(x, np.asarray(lens_host), return_logits, out)
-        mb = self.max_batch(lmax)
+        mb = self.call_batch(B, lmax)
         if B > mb:                                                     # split: reads are independent
             probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
             logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
@@ -354,7 +372,7 @@ class Model:
                                            xn.data_ptr(), lmax, lmax, None, 0, None, _stream_ptr(self.device)),
                      "rs_normalise")
             return self._seq_forward(xn, np.asarray(lens_host), return_logits, out)
-        mb = self.max_batch(lmax)
+        mb = self.call_batch(B, lmax)
         if B > mb:                                                     # split: reads are independent
             probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
             logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
@@ -425,7 +443,7 @@ def reserve_ensemble(models, B: int, lmax: int):
     m0 = models[0]
     if any(m._h is None for m in models):
         return
-    B = max(1, min(int(B), min(m.max_batch(lmax) for m in models)))
+    B = max(1, min(m.call_batch(int(B), lmax) for m in models))
     m0._ws.get(_ensemble_bytes(models, B, lmax))
 
 
@@ -450,7 +468,7 @@ def classify_raw_ensemble(models, sig_dev: torch.Tensor, off_dev: torch.Tensor, 
             nv.check(nv.lib().rs_decide(probs.data_ptr(), len(models), B, len_dev.data_ptr(), int(max_len), float(threshold),
                                         int(mode), decision.data_ptr(), _stream_ptr(m0.device)), "rs_decide")
         return probs
-    mb = min(m.max_batch(lmax) for m in models)
+    mb = min(m.call_batch(B, lmax) for m in models)
     if B > mb:                                                         # split: reads are independent
         probs = out if out is not None else torch.empty((len(models), B, 2), dtype=torch.float32, device=m0.device)
         for s0 in range(0, B, mb):
