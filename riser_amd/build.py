@@ -28,12 +28,14 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
 
 
 def csrc_sha16() -> str:
-    """sha256[:16] over the device sources (csrc/*.hip, *.hpp, sorted by name): the stamp a rocprofv3 PMC summary carries
-    (tools/pmc_summary.py) so that bench.py can tell whether tracked counters still describe the kernels of this tree"""
+    """sha256[:16] over the sources of the ConvNet path (csrc/*.hpp, api.hip, normalise.hip, pointwise.hip, conv_*.hip, sorted
+    by name; not the generic conv programs, the fc head, the float normaliser or the poly(A) detector): the stamp a
+    rocprofv3 PMC summary carries (tools/pmc_summary.py) so that bench.py can tell whether tracked counters still describe
+    the kernels of this tree"""
     import hashlib
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".hpp")):
+        if f.endswith(".hpp") or f in ("api.hip", "normalise.hip", "pointwise.hip") or (f.startswith("conv_") and f.endswith(".hip")):
             h.update(f.encode())
             with open(os.path.join(CSRC, f), "rb") as fh:
                 h.update(fh.read())

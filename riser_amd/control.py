@@ -521,6 +521,13 @@ class SequencerControl:
             self._polya_state_host = torch.empty((cap, 4), dtype=torch.int32).pin_memory()
 
     SLICE_READS = 4096          # a batch of more than 1.5 x this many reads is assessed in slices of about this size
+    FIRST_SLICE_HALF = True     # the first slice of a sliced batch is half a slice (the device idles until it is staged)
+    # slices k >= 1 staged on a second host thread instead of on the loop's thread one slice ahead.  Built and measured in
+    # round 5 (tools/control_ab.py, variants interleaved in one process, 18 000 channels): 22.4 against 22.5 ms in bf16x3, 33.0
+    # against 34.1 ms in fp32 - inside the run-to-run spread.  What the thread can overlap is the memcpy (it releases the
+    # interpreter lock); the array arithmetic around it does not, and the loop's own phases grow by what the thread takes
+    # (gate_launch 1.2 -> 2.4 ms, client_calls 1.4 -> 3.2 ms).  Off; kept for the day the staging is one C call.
+    STAGE_THREAD = False
 
     def assess_batch(self, entries, mode, threshold, polyA_cache):
         """entries: list of (channel, read).  -> _Assessed (the assessed reads in batch order) or None.
@@ -552,8 +559,10 @@ class SequencerControl:
         store.begin_batch(channels, batch.lens)
         n_slices = 1 if B <= self.SLICE_READS * 3 // 2 else -(-B // self.SLICE_READS)
         # the first slice is half a slice: nothing runs on the device until its samples are staged and uploaded
-        bounds = ([0, B] if n_slices == 1 else
-                  [0] + [B * (2 * k + 1) // (2 * n_slices - 1) for k in range(n_slices - 1)] + [B])
+        if n_slices > 1 and self.FIRST_SLICE_HALF:
+            bounds = [0] + [B * (2 * k + 1) // (2 * n_slices - 1) for k in range(n_slices - 1)] + [B]
+        else:
+            bounds = [B * k // n_slices for k in range(n_slices + 1)]
         caller = torch.cuda.current_stream(dev)
         if n_slices > 1:
             if self._side is None:
@@ -650,21 +659,29 @@ class SequencerControl:
             t, dt = self._tick(t, 3)
             ph[3] += dt
 
-        # Slice k + 1 is staged, uploaded and scanned WHILE the loop's thread waits for slice k's scan, gates it and launches
-        # its classification: the staging runs on a second host thread (its memcpy and the waits of the loop's thread
-        # release the interpreter lock), so a PromethION-scale batch costs max(staging, gating) per slice, not their sum;
-        # the classification of slice k runs under the staging of slice k + 2.  What the two threads share: the pinned
-        # scratch (locked), the poly(A) cache (slices hold different reads; dict operations are atomic), the store's row
-        # tables (begin_batch assigned every row; slices touch different rows).
+        # slice k + 1 is staged, uploaded and scanned BEFORE the host waits for slice k's scan: the wait has the next
+        # slice's host work in front of it, and the classification of slice k runs under the staging of slice k + 2.
+        # With STAGE_THREAD that staging runs on a second host thread instead (see the class attribute: measured, no gain);
+        # what the two threads share is the pinned scratch (locked), the poly(A) cache (slices hold different reads; dict
+        # operations are atomic) and the store's row tables (begin_batch assigned every row; slices touch different rows).
         staged = upload_and_scan(0)
         t, ph[1] = self._tick(t, 1)
         for k in range(n_slices):
-            ahead = self._stager().submit(upload_and_scan, k + 1) if k + 1 < n_slices else None
+            ahead = None
+            if k + 1 < n_slices:
+                if self.STAGE_THREAD:
+                    ahead = self._stager().submit(upload_and_scan, k + 1)
+                else:                                      # one slice ahead on this thread (the round-4 order)
+                    nxt = upload_and_scan(k + 1)
+                    t, dt = self._tick(t, 1)
+                    ph[1] += dt
             gate_and_classify(k, staged)
             if ahead is not None:
                 staged = ahead.result()
                 t, dt = self._tick(t, 1)                   # what the loop's thread still had to wait for the staging
                 ph[1] += dt
+            elif k + 1 < n_slices:
+                staged = nxt
         store.end_batch()
         if n_total == 0:
             if side is not caller:
