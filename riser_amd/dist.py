@@ -32,7 +32,9 @@ def init(backend: str | None = None, device: torch.device | None = None):
         backend = backend or os.environ.get("RS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         # bounded rendezvous: a sibling that died before it reached the store must not leave this rank waiting for the
         # library's default 10-30 minutes (the launcher's poll ends the run first; this is the second line of defence)
-        kw = {"timeout": datetime.timedelta(seconds=float(os.environ.get("RS_DIST_TIMEOUT_S", "60")))}
+        # (180 s, not 60: with the nccl backend the same figure bounds every later collective, and RCCL's first
+        # communicator set-up on an 8-GPU node can itself take tens of seconds; RS_DIST_TIMEOUT_S overrides)
+        kw = {"timeout": datetime.timedelta(seconds=float(os.environ.get("RS_DIST_TIMEOUT_S", "180")))}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
