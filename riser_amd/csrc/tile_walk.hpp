@@ -78,7 +78,7 @@ struct TailSplit {
 // shape unusable); best_single(rows, &cost) -> best shape for a launch over `rows` row units.
 template <class TileCost, class Bm, class Ntiles, class BestSingle>
 inline TailSplit plan_tail_split(int n_shapes, int64_t rows, int num_cu, double single_cost, TileCost tile_cost, Bm bm,
-                                 Ntiles ntiles, BestSingle best_single) {
+                                 Ntiles ntiles, BestSingle best_single, double margin = 0.97) {
     constexpr double kLaunch = 6000.0;        // a second launch: boundary + its own prologue
     TailSplit out;
     out.cost = single_cost;
@@ -96,7 +96,7 @@ inline TailSplit plan_tail_split(int n_shapes, int64_t rows, int num_cu, double 
         const int t = best_single(rows - m1 * bm(h), &tail_cost);
         if (t < 0) continue;
         const double cost = head_rounds * tc + tail_cost + kLaunch;
-        if (cost < 0.97 * single_cost && cost < out.cost) {          // the margin is against ONE launch; the best split wins
+        if (cost < margin * single_cost && cost < out.cost) {          // the margin is against ONE launch; the best split wins
             out.cost = cost;
             out.head_shape = h;
             out.head_mtiles = (int)m1;
