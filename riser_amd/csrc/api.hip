@@ -390,7 +390,7 @@ extern "C" {
 
 const char* rs_last_error(void) { return g_err; }
 
-int rs_version(void) { return (2 << 16) | 2; }
+int rs_version(void) { return (2 << 16) | 3; }
 
 int rs_device_count(void) {
     int n = 0;

@@ -588,6 +588,338 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same residual basic block in SPLIT PRECISION on the bf16 MFMA (rs_seqnet_set_mode(m, RS_BF16X3); BASELINE.json's
+// north_star names "the nets/ 1D-ResNet forward pass ... im2col -> MFMA bf16").  Arithmetic of conv_ring_h16.hip: every
+// activation and weight is a pair hi = bf16(v), lo = bf16(v - hi); a product is hi*hi + lo*hi + hi*lo on three
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulate (~2^-17 per operand).  What changes against the fp32 kernel above:
+//   * a k-step is 32 K elements: lane (row r, k-group kq) supplies K elements 8 kq .. 8 kq + 7 - eight CONSECUTIVE floats of the
+//     position's im2col run (two 16-byte loads), split into a hi and a lo fragment in registers (24 VALU per fragment, shared by
+//     the NT column tiles);
+//   * the weights are split on the host and live in LDS as two planes [k-step][kq][n][8 x bf16] (a 16-lane group reads 256
+//     contiguous bytes: conflict-free ds_read_b128), the same 4 bytes per (k, n) as the fp32 matrices;
+//   * the intermediate tile is stored ALREADY SPLIT (two bf16 planes [row][Cp]): phase 2 reads its fragments with two
+//     ds_read_b128 and converts nothing.  Cp = 8 (mod 16) halfwords keeps those reads 16-byte aligned and the 16 rows of a group
+//     on distinct banks (row pitch 12 / 20 / 28 / 36 dwords);
+//   * activations between blocks stay fp32 in HBM (x in, y out, as before).
+// 3 MFMAs of 16 cycles per 32 K elements and accumulator tile against 8 of 32 cycles: 5.3 x less matrix-pipe time; the
+// kernel becomes bound by the split's VALU work and its loads.
+struct BlockX3Args {
+    const float* x;
+    unsigned x_bytes;
+    float* y;
+    const unsigned short* w1;  // planes [hi | lo], each [S1][4][NPs][8]
+    const float* b1;
+    const unsigned short* w2;  // planes [hi | lo], each [S2a + Ssc][4][NPs][8]; the shortcut's k-steps behind the 3x3 conv's
+    const float* b2;
+    int NPs;
+    int B, T_in, T_out, c_in, c_out, Cp, stride;
+    int K1, Ksc;               // 3 c_in; c_in if the shortcut is a conv, else 0
+    int S1, S2a, Ssc;          // k-steps of 32: ceil(3 c_in / 32), ceil(3 Cp / 32), ceil(Ksc / 32)
+    int tiles_per_read, n_tiles;
+};
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// eight floats -> their bf16 hi parts and the bf16 roundings of the residuals
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+    hi[0] = pack_bf16x2(a[0], a[1]);
+    hi[1] = pack_bf16x2(a[2], a[3]);
+    hi[2] = pack_bf16x2(b[0], b[1]);
+    hi[3] = pack_bf16x2(b[2], b[3]);
+    auto lo_of = [](unsigned h, float e0, float e1) {
+        return pack_bf16x2(e0 - __builtin_bit_cast(float, h << 16), e1 - __builtin_bit_cast(float, h & 0xffff0000u));
+    };
+    lo[0] = lo_of(hi[0], a[0], a[1]);
+    lo[1] = lo_of(hi[1], a[2], a[3]);
+    lo[2] = lo_of(hi[2], b[0], b[1]);
+    lo[3] = lo_of(hi[3], b[2], b[3]);
+}
+__device__ __forceinline__ f32x4 mfma_x3(const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bl), c, 0, 0, 0);
+}
+
+template <int NT, int MTW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void seq_basic_block_x3_kernel(const BlockX3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    const int NP = a.NPs;
+    constexpr int R = 16 * MTW * WAVES;
+    constexpr int kThr = 64 * WAVES;
+    constexpr int TO = R - 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int S2 = a.S2a + a.Ssc;
+    const int w1_plane = a.S1 * 4 * NP * 8, w2_plane = S2 * 4 * NP * 8;          // halfwords per plane
+    unsigned short* wl1 = reinterpret_cast<unsigned short*>(lds8);                // [hi plane | lo plane]
+    unsigned short* wl2 = wl1 + 2 * w1_plane;
+    unsigned short* tlh = wl2 + 2 * w2_plane;                                     // [(R + 4)][Cp] hi, then the same lo
+    unsigned short* tll = tlh + (R + 4) * a.Cp;
+    for (int i = threadIdx.x; i < 2 * w1_plane / 8; i += kThr)
+        reinterpret_cast<u32x4*>(wl1)[i] = reinterpret_cast<const u32x4*>(a.w1)[i];
+    for (int i = threadIdx.x; i < 2 * w2_plane / 8; i += kThr)
+        reinterpret_cast<u32x4*>(wl2)[i] = reinterpret_cast<const u32x4*>(a.w2)[i];
+    for (int i = threadIdx.x; i < 2 * (R + 4) * a.Cp / 2; i += kThr) reinterpret_cast<unsigned*>(tlh)[i] = 0u;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const int lim = a.T_in * a.c_in;
+    float b1c[NT], b2c[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        b1c[j] = a.b1[16 * j + r];
+        b2c[j] = a.b2[16 * j + r];
+    }
+    // weight fragments of k-step s: column 16 j + r, k-group kq; columns behind the compact pitch are zeros from a register
+    auto load_b = [&](const unsigned short* w, int plane, int s, u32x4 (&bh)[NT], u32x4 (&bl)[NT]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = 16 * j + r;
+            if (n < NP) {
+                const unsigned short* q = w + ((s * 4 + kq) * NP + n) * 8;
+                bh[j] = *reinterpret_cast<const u32x4*>(q);
+                bl[j] = *reinterpret_cast<const u32x4*>(q + plane);
+            } else {
+                bh[j] = (u32x4){0u, 0u, 0u, 0u};
+                bl[j] = (u32x4){0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    auto do_tile = [&](int tile, auto EDGE_) {
+        constexpr bool EDGE = decltype(EDGE_)::value;
+        const int b = tile / a.tiles_per_read;
+        const int to0 = (tile - b * a.tiles_per_read) * TO;
+        const int64_t xbase = (int64_t)b * lim;
+        // eight consecutive floats of x from element offset o of read b (zeros outside the read; inside it every element is
+        // real data - K indices behind the conv's own meet zero weights)
+        auto load8 = [&](bool ok, int o, int klim, int kidx, f32x4& lo4, f32x4& hi4) {
+            if (!EDGE || (ok && o >= 0 && o + 7 < lim)) {
+                lo4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)((xbase + o) * 4), 0, 0));
+                hi4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)((xbase + o) * 4 + 16), 0, 0));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo4[i] = (ok && kidx + i < klim && o + i >= 0 && o + i < lim) ? a.x[xbase + o + i] : 0.0f;
+                    hi4[i] = (ok && kidx + 4 + i < klim && o + 4 + i >= 0 && o + 4 + i < lim) ? a.x[xbase + o + 4 + i] : 0.0f;
+                }
+            }
+        };
+        // ---- phase 1: the intermediate rows j = 0 .. R-1 (positions to0 - 1 + j) = relu(conv3(x; stride) + b1) -> LDS, split ----
+        {
+            int off0[MTW];
+            bool ok[MTW];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int p = to0 - 1 + (wave * MTW + m) * 16 + r;
+                ok[m] = !EDGE || (p >= 0 && p < a.T_out);
+                off0[m] = (p * a.stride - 1) * a.c_in;
+            }
+            f32x4 acc[MTW][NT];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 xa[MTW], xb[MTW], xan[MTW], xbn[MTW];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) load8(ok[m], off0[m] + 8 * kq, a.K1, 8 * kq, xa[m], xb[m]);
+            for (int s = 0; s < a.S1; ++s) {
+                if (s + 1 < a.S1) {
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m)
+                        load8(ok[m], off0[m] + 32 * (s + 1) + 8 * kq, a.K1, 32 * (s + 1) + 8 * kq, xan[m], xbn[m]);
+                }
+                u32x4 bh[NT], bl[NT];
+                load_b(wl1, w1_plane, s, bh, bl);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    u32x4 ah, al;
+                    split8(xa[m], xb[m], ah, al);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[m][j] = mfma_x3(ah, al, bh[j], bl[j], acc[m][j]);
+                }
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    xa[m] = xan[m];
+                    xb[m] = xbn[m];
+                }
+            }
+            // rows outside [0, T_out) are the second conv's zero padding; channels >= c_out of a row stay zero.  A lane holds
+            // one channel of four rows: neighbouring lanes (channels c, c + 1) exchange two values by DPP so that the even lane
+            // owns the channel PAIR of rows 0 and 1 and the odd lane that of rows 2 and 3 - a dword per row and plane instead of
+            // two halfwords
+            const bool odd = r & 1;
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int jrow0 = (wave * MTW + m) * 16 + 4 * kq;
+                bool okp[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) okp[e] = !EDGE || (to0 - 1 + jrow0 + e >= 0 && to0 - 1 + jrow0 + e < a.T_out);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = 16 * j + r;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (okp[e] && col < a.c_out) ? fmaxf(acc[m][j][e] + b1c[j], 0.0f) : 0.0f;
+                    const float g02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, odd ? v[0] : v[2]), 0xB1, 0xF, 0xF, true));
+                    const float g13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, odd ? v[1] : v[3]), 0xB1, 0xF, 0xF, true));
+                    const int c2 = 16 * j + (r & ~1);
+                    if (c2 < a.c_out) {
+                        // even lane: rows 0, 1 = (own, neighbour's); odd lane: rows 2, 3 = (neighbour's, own)
+                        const float a0 = odd ? g02 : v[0], b0 = odd ? v[2] : g02;
+                        const float a1 = odd ? g13 : v[1], b1 = odd ? v[3] : g13;
+                        const int at = (jrow0 + (odd ? 2 : 0)) * a.Cp + c2;
+                        const unsigned h0 = pack_bf16x2(a0, b0), h1 = pack_bf16x2(a1, b1);
+                        *reinterpret_cast<unsigned*>(tlh + at) = h0;
+                        *reinterpret_cast<unsigned*>(tlh + at + a.Cp) = h1;
+                        *reinterpret_cast<unsigned*>(tll + at) =
+                            pack_bf16x2(a0 - __builtin_bit_cast(float, h0 << 16), b0 - __builtin_bit_cast(float, h0 & 0xffff0000u));
+                        *reinterpret_cast<unsigned*>(tll + at + a.Cp) =
+                            pack_bf16x2(a1 - __builtin_bit_cast(float, h1 << 16), b1 - __builtin_bit_cast(float, h1 & 0xffff0000u));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: output rows i = 0 .. TO-1 (positions to0 + i): conv3 over LDS rows i .. i+2 (+ the 1x1 shortcut) ----
+        {
+            f32x4 acc[MTW][NT];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            int trow[MTW];                                   // halfword index of the lane's fragment in a tile plane
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) trow[m] = ((wave * MTW + m) * 16 + r) * a.Cp + 8 * kq;
+            for (int s = 0; s < a.S2a; ++s) {
+                u32x4 bh[NT], bl[NT];
+                load_b(wl2, w2_plane, s, bh, bl);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const u32x4 ah = *reinterpret_cast<const u32x4*>(tlh + trow[m] + 32 * s);
+                    const u32x4 al = *reinterpret_cast<const u32x4*>(tll + trow[m] + 32 * s);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[m][j] = mfma_x3(ah, al, bh[j], bl[j], acc[m][j]);
+                }
+            }
+            if (a.Ksc) {                                             // 1x1 shortcut conv: x[(to0 + i) * stride][0 .. c_in)
+                int off0[MTW];
+                bool ok[MTW];
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const int i = (wave * MTW + m) * 16 + r;
+                    ok[m] = i < TO && (!EDGE || to0 + i < a.T_out);
+                    off0[m] = (to0 + i) * a.stride * a.c_in;
+                }
+                for (int s = 0; s < a.Ssc; ++s) {
+                    u32x4 bh[NT], bl[NT];
+                    load_b(wl2, w2_plane, a.S2a + s, bh, bl);
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) {
+                        f32x4 xa, xb;
+                        // a row past the tile's outputs (i >= TO) is never stored: it may read anything finite - keep it zero
+                        if (ok[m] || !EDGE) {
+                            if (ok[m])
+                                load8(true, off0[m] + 32 * s + 8 * kq, a.Ksc, 32 * s + 8 * kq, xa, xb);
+                            else
+                                xa = xb = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        } else {
+                            xa = xb = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                        u32x4 ah, al;
+                        split8(xa, xb, ah, al);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[m][j] = mfma_x3(ah, al, bh[j], bl[j], acc[m][j]);
+                    }
+                }
+            }
+            // ---- output: through an fp32 IMAGE of the tile's outputs in LDS, so that the tile leaves in coalesced 16-byte
+            // pieces.  y[b][to0 .. to0 + n_out)[0 .. c_out) is ONE contiguous span of memory (rows hold exactly c_out floats), a
+            // lane of the accumulator holds one channel of four rows: direct stores are 4 bytes wide in 64-byte segments.  The
+            // image aliases the intermediate tile (every wave has finished reading it behind the barrier); it starts `mis` floats
+            // in, so that image float 4 q and global float (s0 - mis) + 4 q are both 16-byte aligned.  An identity shortcut's
+            // residual is the same span of x (c_in == c_out, stride 1): it is added in the copy-out, from coalesced loads.
+            __syncthreads();
+            float* img = reinterpret_cast<float*>(tlh);
+            const int n_out = min(TO, a.T_out - to0);                                  // valid output rows of this tile
+            const int64_t s0 = ((int64_t)b * a.T_out + to0) * a.c_out;                 // first float of the span in y
+            const int mis = (int)(s0 & 3);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = (wave * MTW + m) * 16 + 4 * kq + e;
+                    if (i >= n_out) continue;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int col = 16 * j + r;
+                        if (col < a.c_out) img[mis + i * a.c_out + col] = acc[m][j][e] + b2c[j];
+                    }
+                }
+            __syncthreads();
+            {
+                const int n_f = n_out * a.c_out;                                       // floats of the span
+                const int n_q = (mis + n_f + 3) >> 2;                                  // 16-byte pieces that touch it
+                const float* xres = a.x + xbase + (int64_t)to0 * a.c_in - mis;          // identity: same span, same phase
+                float* ydst = a.y + (s0 - mis);
+                for (int q = threadIdx.x; q < n_q; q += kThr) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(img + 4 * q);
+                    const int lo = 4 * q - mis;                                        // span index of the piece's first float
+                    if (lo >= 0 && lo + 3 < n_f) {
+                        if (!a.Ksc) v += *reinterpret_cast<const f32x4*>(xres + 4 * q);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+                        *reinterpret_cast<f32x4*>(ydst + 4 * q) = v;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (lo + i >= 0 && lo + i < n_f) {
+                                float w = v[i];
+                                if (!a.Ksc) w += xres[4 * q + i];
+                                ydst[4 * q + i] = fmaxf(w, 0.0f);
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+            // the image overwrote zeros the tile must keep: its padding channels [c_out, Cp) and the 4 rows behind it (phase 2
+            // multiplies them by zero weights - a float's halfword may be a bf16 NaN).  Phase 1 rewrites every (row < R,
+            // channel < c_out) itself.
+            {
+                const int n_pad = a.Cp - a.c_out;
+                for (int row = threadIdx.x; row < R + 4; row += kThr)
+                    for (int c = a.c_out; c < a.Cp; ++c) {
+                        tlh[row * a.Cp + c] = 0;
+                        tll[row * a.Cp + c] = 0;
+                    }
+                for (int t = threadIdx.x; t < 4 * a.c_out; t += kThr) {
+                    tlh[R * a.Cp + (t / a.c_out) * a.Cp + t % a.c_out] = 0;
+                    tll[R * a.Cp + (t / a.c_out) * a.Cp + t % a.c_out] = 0;
+                }
+                (void)n_pad;
+            }
+        }
+        // (no barrier here: the next tile's phase 1 writes rows < R x channels < c_out only, which nobody reads before its
+        // own barrier, and the copy-out above ended with one)
+    };
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int tt = tile % a.tiles_per_read;
+        const int to0 = tt * TO;
+        // interior: every intermediate row, output and x access (the k-steps' over-read of up to 31 elements included) lies
+        // inside the read
+        const bool interior = to0 >= 2 && to0 + TO <= a.T_out && ((to0 + R - 2) * a.stride + 2) * a.c_in + 32 * (a.S1 + 1) <= lim;
+        if (interior)
+            do_tile(tile, std::false_type{});
+        else
+            do_tile(tile, std::true_type{});
+    }
+}
+
 // BOTTLENECK block (riser/nets/resnet.py:60-70): y = relu( conv1(relu(conv3(relu(conv1(x) + b1); stride) + b2)) + b3 +
 // shortcut(x) ) in one launch, three GEMM phases with two LDS tiles between them:
 //   A  t1 = relu(conv1x1(x) + b1) for the RA = 128 input positions (to0 * stride - 1 ..) the tile's 3x3 conv reads (zero
@@ -863,6 +1195,11 @@ struct OpDev {
     float* d_f_b1 = nullptr;  // [Npad]
     float* d_f_b2 = nullptr;  // [Npad]
     size_t f_wfloats = 0;     // floats of the weight matrices in LDS
+    // the same block in split precision (seq_basic_block_x3_kernel): bf16 [hi | lo] planes, own row / column pitches
+    unsigned short* d_x_w1 = nullptr;
+    unsigned short* d_x_w2 = nullptr;
+    int x_cp = 0, x_np = 0, x_s1 = 0, x_s2a = 0, x_ssc = 0;
+    size_t x_wbytes = 0;      // bytes of both weight matrices in LDS
     // bottleneck block (fuse == 3): third conv (+ shortcut), mid width
     float* d_f_w3 = nullptr;
     float* d_f_b3 = nullptr;
@@ -876,6 +1213,7 @@ using namespace rs;
 
 struct rs_seqnet {
     bool fuse = true;              // RS_SEQ_NOFUSE=1 (read at create): one launch per op, as the program is written
+    int mode = 0;                  // rs_seqnet_set_mode: 0 fp32 (f32-input MFMA), 1 split precision on the bf16 MFMA (basic blocks)
     std::vector<std::vector<float>> keep_w;   // host copies of the conv weights until fusion has packed them
     int device = 0;
     int n_buffers = 0;
@@ -931,6 +1269,26 @@ bool dead_after(const std::vector<OpDev>& ops, size_t after, int buf) {
         if (ops[k].dst == buf) return true;
     }
     return true;
+}
+
+// float -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does for finite values)
+unsigned short bf16_rne(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);       // inf / nan: truncate
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+float bf16_widen(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+hipError_t upload_u16(unsigned short** d, const std::vector<unsigned short>& h) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(d), std::max<size_t>(h.size(), 8) * sizeof(unsigned short));
+    if (e == hipSuccess) e = hipMemcpy(*d, h.data(), h.size() * sizeof(unsigned short), hipMemcpyHostToDevice);
+    return e;
 }
 
 template <class T>
@@ -1087,6 +1445,43 @@ hipError_t fuse_program(rs_seqnet* m, const std::vector<const float*>& hw, const
         if (e == hipSuccess) e = upload_vec(&o.d_f_b1, b1);
         if (e == hipSuccess) e = upload_vec(&o.d_f_b2, b2);
         if (e != hipSuccess) return e;
+        // ---- the split-precision packing of the same block (seq_basic_block_x3_kernel): k-steps of 32, bf16 planes
+        // [hi | lo] of [k-step][kq][n][8], tile row pitch Cpx = 8 (mod 16) halfwords ------------------------------------------
+        {
+            int Cpx = (c_out + 7) & ~7;
+            while (Cpx % 16 != 8) Cpx += 8;
+            const int S1 = (3 * c_in + 31) / 32, S2a = (3 * Cpx + 31) / 32, Ssc = (Ksc + 31) / 32;
+            int NPx = 16 * nt;
+            if ((size_t)(S1 + S2a + Ssc) * 128 * NPx > 60 * 1024) NPx = (c_out + 3) & ~3;
+            const size_t wbytes = (size_t)(S1 + S2a + Ssc) * 128 * NPx;
+            if (wbytes + (size_t)(64 + 4) * Cpx * 4 <= lds_cap) {
+                const size_t p1 = (size_t)S1 * 4 * NPx * 8, p2 = (size_t)(S2a + Ssc) * 4 * NPx * 8;
+                std::vector<unsigned short> x1(2 * p1, 0), x2(2 * p2, 0);
+                auto put = [&](std::vector<unsigned short>& dst, size_t plane, int kidx, int n, float w) {
+                    const size_t at = (((size_t)(kidx / 32) * 4 + (kidx % 32) / 8) * NPx + n) * 8 + kidx % 8;
+                    const unsigned short h = bf16_rne(w);
+                    dst[at] = h;
+                    dst[plane + at] = bf16_rne(w - bf16_widen(h));
+                };
+                for (int co = 0; co < c_out; ++co) {
+                    for (int ci = 0; ci < c_in; ++ci)
+                        for (int kk = 0; kk < 3; ++kk) put(x1, p1, kk * c_in + ci, co, hw[k1][((size_t)co * c_in + ci) * 3 + kk]);
+                    for (int ci = 0; ci < c_out; ++ci)
+                        for (int kk = 0; kk < 3; ++kk) put(x2, p2, kk * Cpx + ci, co, hw[k1 + 1][((size_t)co * c_out + ci) * 3 + kk]);
+                    if (ksc != (size_t)-1)
+                        for (int ci = 0; ci < c_in; ++ci) put(x2, p2, 32 * S2a + ci, co, hw[ksc][(size_t)co * c_in + ci]);
+                }
+                e = upload_u16(&o.d_x_w1, x1);
+                if (e == hipSuccess) e = upload_u16(&o.d_x_w2, x2);
+                if (e != hipSuccess) return e;
+                o.x_cp = Cpx;
+                o.x_np = NPx;
+                o.x_s1 = S1;
+                o.x_s2a = S2a;
+                o.x_ssc = Ssc;
+                o.x_wbytes = wbytes;
+            }
+        }
         o.fuse = 2;
         o.fuse_skip = (int)(k1 + 1 - k);
         o.f_src = X;
@@ -1217,6 +1612,8 @@ int rs_seqnet_destroy(rs_seqnet* m) {
         if (o.d_wq) (void)hipFree(o.d_wq);
         if (o.d_f_w3) (void)hipFree(o.d_f_w3);
         if (o.d_f_b3) (void)hipFree(o.d_f_b3);
+        if (o.d_x_w1) (void)hipFree(o.d_x_w1);
+        if (o.d_x_w2) (void)hipFree(o.d_x_w2);
         if (o.d_f_w1) (void)hipFree(o.d_f_w1);
         if (o.d_f_w2) (void)hipFree(o.d_f_w2);
         if (o.d_f_b1) (void)hipFree(o.d_f_b1);
@@ -1225,6 +1622,31 @@ int rs_seqnet_destroy(rs_seqnet* m) {
     if (m->d_fcw) (void)hipFree(m->d_fcw);
     if (m->d_fcb) (void)hipFree(m->d_fcb);
     delete m;
+    return RS_OK;
+}
+
+int rs_seqnet_set_mode(rs_seqnet* m, int dtype) {
+    if (!m) {
+        set_error("rs_seqnet_set_mode: null program");
+        return RS_ERR_ARG;
+    }
+    if (dtype == RS_F32 || dtype == RS_F32W) {
+        m->mode = 0;
+        return RS_OK;
+    }
+    if (dtype != RS_BF16X3) {
+        set_error("rs_seqnet_set_mode: generic conv programs run in RS_F32 or RS_BF16X3 (split precision on the bf16 MFMA)");
+        return RS_ERR_ARG;
+    }
+    // split precision covers the residual BASIC blocks of a program (where a ResNet's time is); everything else - stem, head,
+    // bottleneck blocks, unfused ops - keeps the f32-input MFMA.  A program without a single such block has nothing to switch.
+    bool any = false;
+    for (const OpDev& o : m->ops) any = any || (o.fuse == 2 && o.d_x_w1);
+    if (!any) {
+        set_error("rs_seqnet_set_mode: this program has no residual basic block that runs in split precision");
+        return RS_ERR_ARG;
+    }
+    m->mode = 1;
     return RS_OK;
 }
 
@@ -1283,6 +1705,62 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
             // residual basic block in one launch (shapes of its first 3x3 conv: ops[k + fuse_skip - 1])
             const OpShape& s1 = shp[k + o.fuse_skip - 1];
             const int64_t xb = (int64_t)B * s1.t_in * o.f_cin * 4;
+            if (xb < 0x7fffffffLL && m->mode == 1 && o.d_x_w1) {
+                // the block in split precision on the bf16 MFMA: same tiling rules, its own LDS footprint
+                BlockX3Args a;
+                a.x = buf(o.f_src);
+                a.x_bytes = (unsigned)xb;
+                a.y = buf(o.f_dst);
+                a.w1 = o.d_x_w1;
+                a.b1 = o.d_f_b1;
+                a.w2 = o.d_x_w2;
+                a.b2 = o.d_f_b2;
+                a.NPs = o.x_np;
+                a.B = B;
+                a.T_in = s1.t_in;
+                a.T_out = s1.t_out;
+                a.c_in = o.f_cin;
+                a.c_out = o.f_cout;
+                a.Cp = o.x_cp;
+                a.stride = o.f_stride;
+                a.K1 = 3 * o.f_cin;
+                a.Ksc = o.f_ksc;
+                a.S1 = o.x_s1;
+                a.S2a = o.x_s2a;
+                a.Ssc = o.x_ssc;
+                const size_t lds_cap = 160 * 1024;
+                auto lds_of = [&](int rows) { return o.x_wbytes + (size_t)(rows + 4) * o.x_cp * 4; };
+                auto waste = [&](int rows) {
+                    const int to = rows - 2, n = (s1.t_out + to - 1) / to;
+                    return (double)(n * to - s1.t_out) / (double)(n * to);
+                };
+                int mtw = 1, waves = 4;
+                if (lds_cap / lds_of(64) < 2) {
+                    if (lds_of(128) <= lds_cap) waves = 8;
+                } else {
+                    if (lds_cap / lds_of(128) >= 2 && waste(128) < 0.06) mtw = 2;
+                }
+                const size_t f_lds = lds_of(16 * mtw * waves);
+                const int TO = 16 * mtw * waves - 2;
+                a.tiles_per_read = (s1.t_out + TO - 1) / TO;
+                a.n_tiles = B * a.tiles_per_read;
+                using Fn = void (*)(const BlockX3Args);
+                static const Fn table[5][3] = {
+                    {seq_basic_block_x3_kernel<1, 1, 4>, seq_basic_block_x3_kernel<1, 2, 4>, seq_basic_block_x3_kernel<1, 1, 8>},
+                    {seq_basic_block_x3_kernel<2, 1, 4>, seq_basic_block_x3_kernel<2, 2, 4>, seq_basic_block_x3_kernel<2, 1, 8>},
+                    {seq_basic_block_x3_kernel<3, 1, 4>, seq_basic_block_x3_kernel<3, 2, 4>, seq_basic_block_x3_kernel<3, 1, 8>},
+                    {seq_basic_block_x3_kernel<4, 1, 4>, seq_basic_block_x3_kernel<4, 2, 4>, seq_basic_block_x3_kernel<4, 1, 8>},
+                    {seq_basic_block_x3_kernel<5, 1, 4>, seq_basic_block_x3_kernel<5, 2, 4>, seq_basic_block_x3_kernel<5, 1, 8>}};
+                Fn fn = table[o.f_nt - 1][waves == 8 ? 2 : mtw - 1];
+                RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, lds_cap / f_lds));
+                const int grid = std::min(a.n_tiles, m->num_cu * per_cu);
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), f_lds, st, a);
+                RS_HIP(hipGetLastError());
+                last = o.f_dst;
+                k += o.fuse_skip;
+                continue;
+            }
             if (xb < 0x7fffffffLL) {
                 BlockArgs a;
                 a.x = buf(o.f_src);

@@ -139,7 +139,9 @@ def program_traffic_bytes(prog, L: int, fused: bool = True) -> float:
 class SeqNet:
     """A conv / max-pool program on the device (rs_seqnet_*): uniform-length batches [B, L] -> probabilities."""
 
-    def __init__(self, prog, n_buffers, fw, fb, c_last, device):
+    def __init__(self, prog, n_buffers, fw, fb, c_last, device, dtype: str = "f32"):
+        """dtype: "f32" (every conv on the f32-input MFMA) or "bf16x3" (the residual basic blocks in split precision on the
+        bf16 MFMA, rs_seqnet_set_mode: within 1e-3 of the reference, ~1.5 x the fp32 rate)."""
         nv.require_gpu()
         d = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
@@ -158,6 +160,16 @@ class SeqNet:
                                            self.device.index, C.byref(h)), "rs_seqnet_create")
         self._h = h
         self._ws = None
+        self.dtype = {"f32": "f32", "f32w": "f32", "fp32": "f32", "bf16x3": "bf16x3"}.get(dtype)
+        if self.dtype is None:
+            self.close()
+            raise ValueError(f"dtype {dtype!r}: generic conv programs run in 'f32' or 'bf16x3'")
+        if self.dtype == "bf16x3":
+            try:
+                nv.check(nv.lib().rs_seqnet_set_mode(self._h, nv.RS_BF16X3), "rs_seqnet_set_mode")
+            except Exception:
+                self.close()
+                raise
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
@@ -214,15 +226,17 @@ def build_convnet_program(sd, cnn):
 
 
 class ResNetModel:
-    def __init__(self, state, config, logger, target, device=None):
+    def __init__(self, state, config, logger, target, device=None, dtype: str = "f32"):
+        """dtype "bf16x3": the residual basic blocks in split precision on the bf16 MFMA (SeqNet)."""
         self.target, self.logger = target, logger
         c = config.resnet
         sd = state if isinstance(state, dict) else torch.load(state, map_location="cpu")
         sd = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
         if int(c.n_classes) != 2:
             raise ValueError("riser_amd supports two-class heads only")
-        self._net = SeqNet(*build_program(sd, c), device=device)
+        self._net = SeqNet(*build_program(sd, c), device=device, dtype=dtype)
         self.device = self._net.device
+        self.dtype = self._net.dtype
 
     def close(self):
         self._net.close()

@@ -88,3 +88,47 @@ def test_resnet_fused_blocks_equal_the_op_by_op_program(cfg):
     assert np.abs(fused.classify_batch(x).cpu().numpy() - plain.classify_batch(x).cpu().numpy()).max() < 1e-5
     fused.close()
     plain.close()
+
+
+@pytest.mark.gpu
+def test_resnet_basic_blocks_in_split_precision(golden_dir):
+    """rs_seqnet_set_mode(RS_BF16X3): the residual basic blocks on the bf16 MFMA in split precision (hi + lo pairs, three MFMAs
+    per product) - the north_star's "1D-ResNet forward pass ... MFMA bf16".  Against the REFERENCE's own logits / probabilities
+    for its basic-block net (tests/golden/resnet.npz) within the 1e-3 tolerance, and against the oracle and the fp32 program on the
+    bench's SquiggleNet-like net at several lengths (stride-2 stages, identity and conv shortcuts, edge tiles, one read alone)."""
+    import torch
+    from riser_amd.resnet import ResNetModel
+    dev = torch.device("cuda", 0)
+    g, cfg, sd = _load(golden_dir, "basic")
+    config = types.SimpleNamespace(resnet=types.SimpleNamespace(**cfg))
+    m = ResNetModel(sd, config, None, "x", device=dev, dtype="bf16x3")
+    assert m.dtype == "bf16x3"
+    for L in (3000, 4097):
+        probs, logits = m.classify_batch(_inputs(L), return_logits=True)
+        assert np.abs(probs.cpu().numpy() - g[f"basic.L{L}.probs"]).max() < 1e-3
+        assert np.abs(logits.cpu().numpy() - g[f"basic.L{L}.logits"]).max() < 5e-3
+    m.close()
+    cfg = dict(synth.RESNET_BENCH_CFG)
+    sd = synth.make_resnet_state_dict(7, cfg)
+    config = types.SimpleNamespace(resnet=types.SimpleNamespace(**cfg))
+    x3 = ResNetModel(sd, config, None, "x", device=dev, dtype="bf16x3")
+    f32 = ResNetModel(sd, config, None, "x", device=dev)
+    worst = 0.0
+    for L in (3000, 4097, 6024, 16000):
+        x = _inputs(L)
+        p3, l3 = x3.classify_batch(x, return_logits=True)
+        pf, lf = f32.classify_batch(x, return_logits=True)
+        want = rr.resnet_forward(sd, cfg, x)
+        assert np.abs(ro.softmax(want) - p3.cpu().numpy()).max() < 1e-3, L
+        assert np.abs(l3.cpu().numpy() - want).max() < 5e-3, L
+        worst = max(worst, float(np.abs(l3.cpu().numpy() - lf.cpu().numpy()).max()))
+    assert 0 < worst < 5e-3          # really another arithmetic, and a close one
+    x = _inputs(5000)[:1]
+    assert np.abs(x3.classify_batch(x).cpu().numpy() - f32.classify_batch(x).cpu().numpy()).max() < 1e-3
+    x3.close()
+    f32.close()
+    # a program without a residual basic block has nothing to switch: the library says so
+    bcfg = BOTTLENECK_WIDE_CFG
+    with pytest.raises(Exception, match="basic block"):
+        ResNetModel(synth.make_resnet_state_dict(7, bcfg), types.SimpleNamespace(resnet=types.SimpleNamespace(**bcfg)), None, "x",
+                    device=dev, dtype="bf16x3")
