@@ -504,25 +504,36 @@ def side_variants(args, device, wl, ref):
     from riser_amd.resnet import ResNetModel, build_program, program_flops, program_traffic_bytes
     rcfg = synth.RESNET_BENCH_CFG
     rsd = synth.make_resnet_state_dict(7)
-    rm = ResNetModel(rsd, types.SimpleNamespace(resnet=types.SimpleNamespace(**rcfg)), None, "x", device=device)
     xr = torch.from_numpy(np.stack([np.clip((s.astype(np.float32) - 500.0) / 60.0, -3.5, 3.5)
                                     for s in wl.sample_sigs[:64]])).to(device).repeat(B // 64, 1).contiguous()
-    dtr = timed(lambda: rm._net.forward(xr))
     rprog = build_program(rsd, types.SimpleNamespace(**rcfg))[0]
     fl = program_flops(rprog, L) * xr.shape[0]
     by = program_traffic_bytes(rprog, L, fused=True) * xr.shape[0]
     by_unfused = program_traffic_bytes(rprog, L, fused=False) * xr.shape[0]
-    variants["resnet_basic_f32"] = {"chunks_per_s": round(xr.shape[0] / dtr, 1), "ms_per_step": round(dtr * 1e3, 4),
-                                    "batch": int(xr.shape[0]), "config": rcfg,
-                                    "conv_tflops": round(fl / dtr / 1e12, 2),
-                                    "roofline_frac_f32_mfma": round(fl / dtr / 1e12 / PEAK_F32_MFMA_TF, 4),
-                                    "hbm_gb_per_step": round(by / 1e9, 3), "hbm_gb_per_step_unfused": round(by_unfused / 1e9, 3),
-                                    "hbm_tb_per_s": round(by / dtr / 1e12, 3), "roofline_frac_hbm": round(by / dtr / 8e12, 4),
-                                    "note": "one launch per residual block (conv-BN-ReLU, conv-BN, 1x1 shortcut, add, ReLU) and one for "
-                                            "the stem (conv-BN-ReLU-MaxPool): x in, y out per launch (hbm_gb_per_step, algorithmic); "
-                                            "conv_tflops = un-padded conv FLOPs / step time over the 157.3 TF f32 MFMA peak (channel "
-                                            "widths of 20-67 pad to 32-80 columns of the 16-wide MFMA tile)"}
-    rm.close()
+    rprobs = {}
+    for rdt, peak in (("f32", PEAK_F32_MFMA_TF), ("bf16x3", PEAK_BF16_MFMA_TF)):
+        rm = ResNetModel(rsd, types.SimpleNamespace(resnet=types.SimpleNamespace(**rcfg)), None, "x", device=device, dtype=rdt)
+        dtr = timed(lambda: rm._net.forward(xr))
+        rprobs[rdt] = rm._net.forward(xr).cpu().numpy()
+        entry = {"chunks_per_s": round(xr.shape[0] / dtr, 1), "ms_per_step": round(dtr * 1e3, 4),
+                 "batch": int(xr.shape[0]), "config": rcfg,
+                 "conv_tflops": round(fl / dtr / 1e12, 2),
+                 "roofline_frac_mfma": round(fl / dtr / 1e12 / peak, 4),
+                 "hbm_gb_per_step": round(by / 1e9, 3), "hbm_gb_per_step_unfused": round(by_unfused / 1e9, 3),
+                 "hbm_tb_per_s": round(by / dtr / 1e12, 3), "roofline_frac_hbm": round(by / dtr / 8e12, 4)}
+        if rdt == "f32":
+            entry["roofline_frac_f32_mfma"] = entry["roofline_frac_mfma"]
+            entry["note"] = ("one launch per residual block (conv-BN-ReLU, conv-BN, 1x1 shortcut, add, ReLU) and one for the stem "
+                             "(conv-BN-ReLU-MaxPool): x in, y out per launch (hbm_gb_per_step, algorithmic); conv_tflops = un-padded "
+                             "conv FLOPs / step time over the 157.3 TF f32 MFMA peak (channel widths of 20-67 pad to 32-80 columns)")
+        else:
+            entry["max_abs_dprob_vs_f32"] = float(np.abs(rprobs["bf16x3"] - rprobs["f32"]).max())
+            entry["label_flips_at_0.9_vs_f32"] = int(((rprobs["bf16x3"][:, 1] > 0.9) != (rprobs["f32"][:, 1] > 0.9)).sum())
+            entry["note"] = ("the same program with its stem and residual basic blocks in split precision on the bf16 MFMA "
+                             "(rs_seqnet_set_mode): three v_mfma_f32_16x16x32_bf16 per product, activations fp32 between launches; "
+                             "frac over the 2.5 PF bf16 peak - the blocks are bound by the split's VALU work and their epilogues")
+        variants["resnet_basic_" + rdt] = entry
+        rm.close()
     return variants
 
 
@@ -833,6 +844,7 @@ MODE_OF_VARIANT = {            # variants key -> (name in roofline.modes, BASELI
     "ensemble3_bf16x3": ("ensemble3_bf16x3", "config 3"),
     "live_357x8615_f32": ("live_357x8615_f32", "the live ReadUntil batch shape"),
     "resnet_basic_f32": ("resnet_basic_f32", "riser/nets/resnet.py"),
+    "resnet_basic_bf16x3": ("resnet_basic_bf16x3", "riser/nets/resnet.py on the bf16 MFMA"),
 }
 
 
@@ -868,8 +880,8 @@ def modes_object(detail, model, wl):
         vs = e.get("model0", e)
         m = {"value": e.get("chunks_per_s", e.get("reads_per_s")), "unit": "chunks/s" if "chunks_per_s" in e else "reads/s",
              "ms_per_step": ms}
-        if name == "resnet_basic_f32":
-            m["frac"] = e.get("roofline_frac_f32_mfma")
+        if name.startswith("resnet_basic"):
+            m["frac"] = e.get("roofline_frac_mfma")
         else:
             peak = PEAK_F32_MFMA_TF if name.endswith("f32") else PEAK_BF16_MFMA_TF
             m["frac"] = round(flops(lens_of[name]) / (ms * 1e-3) / 1e12 / peak, 4)

@@ -920,6 +920,131 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_x3_kernel(const Bl
     }
 }
 
+// The stem (conv(1 -> C; k, stride, pad) + BN + ReLU + MaxPool1d(2, 2, padding 1), riser/nets/resnet.py:79-84) in the same split
+// precision: the GEMM of seq_stem_pool_kernel with k-steps of 32 samples (a 19-tap stem is ONE k-step of three bf16 MFMAs
+// instead of eight f32-input ones), the lane's eight consecutive samples split in registers.  Output through a WAVE-PRIVATE fp32
+// image in LDS: a wave's 32 GEMM rows are 16 pooled rows = 16 c_out consecutive floats of y (pooled rows are contiguous across
+// reads: g / 2 = b TP + p), always 64-byte aligned, stored 16 bytes per lane; LDS operations of one wave execute in order, so
+// the image needs no barrier.
+template <int NT>
+__global__ __launch_bounds__(256) void seq_stem_pool_x3_kernel(const float* __restrict__ x, unsigned x_bytes,
+                                                               const unsigned short* __restrict__ wq /* planes [hi | lo] [S][4][16 NT][8] */,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int B, int L,
+                                                               int T_conv, int TP, int c_out, int K, int S, int stride, int pad,
+                                                               int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    constexpr int NP = 16 * NT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int plane = S * 4 * NP * 8;
+    unsigned short* wl = reinterpret_cast<unsigned short*>(lds8);
+    float* img = reinterpret_cast<float*>(lds8 + (size_t)2 * plane * 2) + wave * 16 * c_out;      // 16 pooled rows x c_out
+    for (int i = threadIdx.x; i < 2 * plane / 8; i += 256) reinterpret_cast<u32x4*>(wl)[i] = reinterpret_cast<const u32x4*>(wq)[i];
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+    const int rpr = 2 * TP;
+    const int rows = B * rpr;
+    const int64_t y_floats = (int64_t)B * TP * c_out;
+    float bcol[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bcol[j] = 16 * j + r < c_out ? bias[16 * j + r] : 0.0f;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row0 = tile * 128 + wave * 32;
+        const int tb0 = __builtin_amdgcn_readfirstlane((tile * 128) / rpr);
+        auto locate = [&](int g, int& b, int& j) {
+            b = tb0;
+            j = g - tb0 * rpr;
+            while (j >= rpr) {
+                j -= rpr;
+                ++b;
+            }
+        };
+        int off0[2], base[2];
+        bool ok[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int g = row0 + 16 * m + r;
+            int b, j;
+            locate(g, b, j);
+            const int tc = j - 1;
+            ok[m] = g < rows && tc >= 0 && tc < T_conv;
+            off0[m] = tc * stride - pad;
+            base[m] = b * L;
+        }
+        const int jw = row0 - tb0 * rpr;
+        const bool interior = row0 + 32 <= rows && jw >= 1 && jw + 32 <= rpr - 2 && (jw - 1) * stride - pad >= 0 &&
+                              (jw + 31) * stride - pad + 32 * S + 8 < L;
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {
+            u32x4 bh[NT], bl[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const unsigned short* q = wl + ((s * 4 + kq) * NP + 16 * j + r) * 8;
+                bh[j] = *reinterpret_cast<const u32x4*>(q);
+                bl[j] = *reinterpret_cast<const u32x4*>(q + plane);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int kidx = 32 * s + 8 * kq;
+                const int o = off0[m] + kidx;
+                f32x4 xa, xb;
+                // (samples at K index >= K meet zero weights: inside the read they need no mask)
+                if (interior || (ok[m] && o >= 0 && o + 7 < L)) {
+                    xa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(base[m] + o) * 4u, 0, 0));
+                    xb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(base[m] + o) * 4u + 16u, 0, 0));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xa[i] = (ok[m] && kidx + i < K && o + i >= 0 && o + i < L) ? x[(int64_t)base[m] + o + i] : 0.0f;
+                        xb[i] = (ok[m] && kidx + 4 + i < K && o + 4 + i >= 0 && o + 4 + i < L) ? x[(int64_t)base[m] + o + 4 + i] : 0.0f;
+                    }
+                }
+                u32x4 ah, al;
+                split8(xa, xb, ah, al);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[m][j] = mfma_x3(ah, al, bh[j], bl[j], acc[m][j]);
+            }
+        }
+        // lane (column r, row group kq) holds GEMM rows 4 kq + e: (e = 0, 1) and (2, 3) are pooling windows -> the wave's image
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const int g = row0 + 16 * m + 4 * kq + e;              // even
+                if (g >= rows) continue;
+                int b, j0;
+                locate(g, b, j0);
+                const int ta = j0 - 1, tb = j0;                        // the window's conv positions (MaxPool pads with -inf)
+                const bool va = ta >= 0 && ta < T_conv, vb = tb < T_conv;
+                float* ir = img + (8 * m + 2 * kq + (e >> 1)) * c_out;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = 16 * j + r;
+                    if (col >= c_out) continue;
+                    float v = -INFINITY;
+                    if (va) v = fmaxf(v, acc[m][j][e] + bcol[j]);
+                    if (vb) v = fmaxf(v, acc[m][j][e + 1] + bcol[j]);
+                    ir[col] = fmaxf(v, 0.0f);                          // relu(max) == max(relu)
+                }
+            }
+        {
+            const int64_t f0 = (int64_t)(row0 >> 1) * c_out;           // first float of the wave's span in y
+            const int n_q = 4 * c_out;                                 // 16 c_out floats in 16-byte pieces
+            for (int q = lane; q < n_q; q += 64) {
+                if (f0 + 4 * q + 3 < y_floats)
+                    *reinterpret_cast<f32x4*>(y + f0 + 4 * q) = *reinterpret_cast<const f32x4*>(img + 4 * q);
+                else
+                    for (int i = 0; i < 4; ++i)
+                        if (f0 + 4 * q + i < y_floats) y[f0 + 4 * q + i] = img[4 * q + i];
+            }
+        }
+    }
+}
+
 // BOTTLENECK block (riser/nets/resnet.py:60-70): y = relu( conv1(relu(conv3(relu(conv1(x) + b1); stride) + b2)) + b3 +
 // shortcut(x) ) in one launch, three GEMM phases with two LDS tiles between them:
 //   A  t1 = relu(conv1x1(x) + b1) for the RA = 128 input positions (to0 * stride - 1 ..) the tile's 3x3 conv reads (zero
@@ -1196,7 +1321,7 @@ struct OpDev {
     float* d_f_b2 = nullptr;  // [Npad]
     size_t f_wfloats = 0;     // floats of the weight matrices in LDS
     // the same block in split precision (seq_basic_block_x3_kernel): bf16 [hi | lo] planes, own row / column pitches
-    unsigned short* d_x_w1 = nullptr;
+    unsigned short* d_x_w1 = nullptr;   // (fuse == 1, the stem: its one weight matrix)
     unsigned short* d_x_w2 = nullptr;
     int x_cp = 0, x_np = 0, x_s1 = 0, x_s2a = 0, x_ssc = 0;
     size_t x_wbytes = 0;      // bytes of both weight matrices in LDS
@@ -1314,6 +1439,22 @@ hipError_t fuse_program(rs_seqnet* m, const std::vector<const float*>& hw, const
             o.fuse_skip = 1;
             o.f_src = o.src;
             o.f_dst = ops[k + 1].dst;
+            {   // the split-precision packing (seq_stem_pool_x3_kernel): planes [hi | lo] of [k-step][kq][16 nt][8]
+                const int K = o.k, S = (K + 31) / 32, NPx = 16 * o.nt;
+                const size_t plane = (size_t)S * 4 * NPx * 8;
+                std::vector<unsigned short> xw(2 * plane, 0);
+                for (int co = 0; co < o.c_out; ++co)
+                    for (int kk = 0; kk < K; ++kk) {
+                        const float w = hw[k][(size_t)co * K + kk];
+                        const size_t at = (((size_t)(kk / 32) * 4 + (kk % 32) / 8) * NPx + co) * 8 + kk % 8;
+                        const unsigned short h = bf16_rne(w);
+                        xw[at] = h;
+                        xw[plane + at] = bf16_rne(w - bf16_widen(h));
+                    }
+                const hipError_t e = upload_u16(&o.d_x_w1, xw);
+                if (e != hipSuccess) return e;
+                o.x_s1 = S;
+            }
             continue;
         }
         // ---- basic block: [1x1 shortcut conv]  conv3(stride) + ReLU  conv3 + residual + ReLU -----------------------------
@@ -1687,6 +1828,20 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
             const OpShape& ps = shp[k + 1];
             const int rows = B * 2 * ps.t_out;
             const int n_tiles = (rows + 127) / 128;
+            if (m->mode == 1 && o.d_x_w1) {                        // the stem in split precision on the bf16 MFMA
+                const size_t lds = (size_t)o.x_s1 * 4 * o.nt * 16 * 8 * 2 * 2 + (size_t)4 * 16 * o.c_out * 4;
+                auto fx = o.nt == 1 ? seq_stem_pool_x3_kernel<1> : o.nt == 2 ? seq_stem_pool_x3_kernel<2> : o.nt == 3 ? seq_stem_pool_x3_kernel<3>
+                        : o.nt == 4 ? seq_stem_pool_x3_kernel<4> : seq_stem_pool_x3_kernel<5>;
+                RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fx), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
+                const int grid = std::min(n_tiles, m->num_cu * per_cu);
+                hipLaunchKernelGGL(fx, dim3(grid), dim3(256), lds, st, buf(o.f_src), (unsigned)((int64_t)B * sh.t_in * 4), o.d_x_w1, o.d_b,
+                                   buf(o.f_dst), B, sh.t_in, sh.t_out, ps.t_out, o.c_out, o.k * o.c_in, o.x_s1, o.stride, o.pad, n_tiles);
+                RS_HIP(hipGetLastError());
+                last = o.f_dst;
+                k += o.fuse_skip;
+                continue;
+            }
             const int K = o.k * o.c_in, K16 = (K + 15) & ~15;
             const size_t lds = (size_t)K16 * o.nt * 16 * 4;
             auto fn = o.nt == 1 ? seq_stem_pool_kernel<1> : o.nt == 2 ? seq_stem_pool_kernel<2> : o.nt == 3 ? seq_stem_pool_kernel<3>
