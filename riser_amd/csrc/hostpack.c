@@ -100,6 +100,79 @@ static void* copy_job(void* arg) {
  * rank a slice of the cores (riser_amd/supervise.py) and this pool must fit the slice */
 static int hp_thread_cap = HP_MAX_THREADS;
 
+/* A persistent pool for the copy jobs: a PromethION-scale batch calls gather() once per slice (five times per batch, ~11 MB
+ * each), and creating + joining seven threads per call cost more than a millisecond per batch.  HP_MAX_THREADS - 1 workers are
+ * started at the first large gather and sleep on a condition variable between jobs; the calling thread takes share 0 itself.
+ * One gather at a time (pool_busy): a second caller - the staging thread of the slice pipeline next to the loop's thread -
+ * falls back to copying alone.  The workers never touch the interpreter. */
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t go, done;
+    int started;                 /* worker threads alive */
+    unsigned long gen;           /* job generation */
+    int n_jobs, pending;         /* shares of the current job (share 0 is the caller's), shares not finished yet */
+    const job_t* jobs;
+    int busy;
+} pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, 0, NULL, 0};
+
+static void* pool_worker(void* arg) {
+    const int me = (int)(intptr_t)arg;          /* 1 .. HP_MAX_THREADS - 1: takes share `me` of a job that has one */
+    unsigned long seen = 0;
+    pthread_mutex_lock(&pool.mu);
+    for (;;) {
+        while (pool.gen == seen) pthread_cond_wait(&pool.go, &pool.mu);
+        seen = pool.gen;
+        if (me < pool.n_jobs) {
+            const job_t* j = &pool.jobs[me];
+            pthread_mutex_unlock(&pool.mu);
+            copy_job((void*)j);
+            pthread_mutex_lock(&pool.mu);
+            if (--pool.pending == 0) pthread_cond_signal(&pool.done);
+        }
+    }
+    return NULL;
+}
+
+/* run jobs[0 .. nt) : share 0 on this thread, the others on the pool (or on this thread, when the pool is busy or absent) */
+static void run_copy_jobs(const job_t* jobs, int nt) {
+    int use_pool = 0;
+    if (nt > 1) {
+        pthread_mutex_lock(&pool.mu);
+        if (!pool.busy) {
+            while (pool.started < HP_MAX_THREADS - 1) {
+                pthread_t th;
+                pthread_attr_t at;
+                pthread_attr_init(&at);
+                pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+                const int ok = pthread_create(&th, &at, pool_worker, (void*)(intptr_t)(pool.started + 1)) == 0;
+                pthread_attr_destroy(&at);
+                if (!ok) break;
+                ++pool.started;
+            }
+            if (pool.started >= nt - 1) {
+                pool.busy = 1;
+                pool.jobs = jobs;
+                pool.n_jobs = nt;
+                pool.pending = nt - 1;
+                ++pool.gen;
+                pthread_cond_broadcast(&pool.go);
+                use_pool = 1;
+            }
+        }
+        pthread_mutex_unlock(&pool.mu);
+    }
+    copy_job((void*)&jobs[0]);
+    if (use_pool) {
+        pthread_mutex_lock(&pool.mu);
+        while (pool.pending) pthread_cond_wait(&pool.done, &pool.mu);
+        pool.n_jobs = 0;
+        pool.busy = 0;
+        pthread_mutex_unlock(&pool.mu);
+    } else {
+        for (int t = 1; t < nt; ++t) copy_job((void*)&jobs[t]);
+    }
+}
+
 static PyObject* hp_gather(PyObject* self, PyObject* args) {
     PyObject *reads, *start, *out;
     if (!PyArg_ParseTuple(args, "OOO", &reads, &start, &out)) return NULL;
@@ -159,8 +232,6 @@ static PyObject* hp_gather(PyObject* self, PyObject* args) {
         if (nt > hp_thread_cap) nt = hp_thread_cap;
         if (nt > n) nt = (int)(n ? n : 1);
         job_t jobs[HP_MAX_THREADS];
-        pthread_t th[HP_MAX_THREADS];
-        int started[HP_MAX_THREADS] = {0};
         /* equal byte shares, cut at piece boundaries */
         Py_ssize_t lo = 0;
         size_t acc = 0;
@@ -173,14 +244,7 @@ static PyObject* hp_gather(PyObject* self, PyObject* args) {
             jobs[t].hi = hi;
             lo = hi;
         }
-        for (int t = 1; t < nt; ++t) started[t] = pthread_create(&th[t], NULL, copy_job, &jobs[t]) == 0;
-        copy_job(&jobs[0]);
-        for (int t = 1; t < nt; ++t) {
-            if (started[t])
-                pthread_join(th[t], NULL);
-            else
-                copy_job(&jobs[t]);
-        }
+        run_copy_jobs(jobs, nt);
         Py_END_ALLOW_THREADS
     }
     for (Py_ssize_t i = 0; i < held; ++i) PyBuffer_Release(&views[i]);

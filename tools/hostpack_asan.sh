@@ -21,6 +21,13 @@ for start in (np.zeros(len(reads), dtype=np.int64), np.minimum(lens, rng.integer
     out = np.empty(int((lens - start).sum()), dtype=np.int16); assert hp.gather(reads, start, out) == out.size
 big = [R(f"b{i}", rng.integers(0, 100, size=40000, dtype=np.int16)) for i in range(200)]
 out = np.empty(200 * 40000, dtype=np.int16); hp.gather(big, np.zeros(200, dtype=np.int64), out)          # the threaded path
+import threading
+def many():                                                       # the persistent copy pool, re-used and contended
+    o2 = np.empty(200 * 40000, dtype=np.int16)
+    for _ in range(6): assert hp.gather(big, np.zeros(200, dtype=np.int64), o2) == o2.size
+    assert np.array_equal(o2[:40000], np.frombuffer(big[0].raw_data, dtype=np.int16))
+ts = [threading.Thread(target=many) for _ in range(3)]; [t.start() for t in ts]; many(); [t.join() for t in ts]
+assert hp.repr_double(0.1) == repr(0.1) and hp.repr_double(5e-324) == "5e-324" and hp.repr_double(float("nan")) == "nan"
 ids = np.empty(len(reads), dtype=object); ids[:] = hp.attrs(reads, "id")
 o = np.zeros(len(reads), dtype=np.int64)
 hp.lookup({r.id: i for i, r in enumerate(reads[::2])}, ids, o); hp.lookup({}, list(ids), o); hp.lookup({"a": 1}, ids[3:9], o)
