@@ -65,6 +65,14 @@ class Model:
         self.device = self._get_device(device)
         if logger is not None:
             logger.info('Using %s device', self.device)
+        if getattr(config, "model", None) == "resnet" or (not hasattr(config, "cnn") and hasattr(config, "resnet")):
+            # `config.resnet` (riser/nets/resnet.py:72-99: channels, kernel, padding, stride, block, n_layers, blocks,
+            # n_classes) instead of `config.cnn`: the reference's second architecture.  Its own Model hard-wires ConvNet
+            # (riser/model.py:13) and ships no ResNet config or weights; here the same Model surface - classify, the batched
+            # entry points, SequencerControl - runs it as a generic conv program (csrc/seqnet.hip: one launch for the stem
+            # and one per residual block), in fp32 or, dtype "bf16x3", with stem and basic blocks on the bf16 MFMA.
+            self._init_resnet(state, config.resnet, dtype)
+            return
         cnn = config.cnn
         self.classifier = getattr(cnn, "classifier", "gap_fc")
         if self.classifier not in ("gap_fc", "gap", "fc"):
@@ -166,6 +174,34 @@ class Model:
             return torch.device("cuda", torch.cuda.current_device())
         d = torch.device(device)
         return torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+
+    def _init_resnet(self, state, rc, dtype: str):
+        from .resnet import SeqNet, build_program
+        sd = state if isinstance(state, dict) else torch.load(state, map_location="cpu")
+        sd = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
+        if int(rc.n_classes) != 2:
+            raise ValueError("riser_amd supports two-class heads only")
+        seq_dtype = {"f32w": "f32", "f32": "f32", "bf16x3": "bf16x3"}.get(dtype)
+        if seq_dtype is None:
+            raise ValueError(f"dtype {dtype!r}: a ResNet runs in 'f32w' / 'f32' (f32-input MFMA) or 'bf16x3' (stem and basic "
+                             "blocks in split precision on the bf16 MFMA)")
+        self.classifier, self._fc_positions = "gap_fc", 0
+        self.channels = [int(c) for c in rc.channels]
+        self.n_layers = len(self.channels)
+        self._keep, self._h, self.model = [], None, self
+        self._seq = SeqNet(*build_program(sd, rc), device=self.device, dtype=seq_dtype)
+        self.dtype = seq_dtype
+        self._ws = Workspace(self.device)
+        # shortest input the program accepts (torch raises below it: kernel larger than the padded input, empty pooling)
+        lo, hi = 1, 1 << 16
+        lib = nv.lib()
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if lib.rs_seqnet_workspace_bytes(self._seq._h, 1, mid):
+                hi = mid
+            else:
+                lo = mid + 1
+        self.min_length = lo
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

@@ -132,3 +132,65 @@ def test_resnet_basic_blocks_in_split_precision(golden_dir):
     with pytest.raises(Exception, match="basic block"):
         ResNetModel(synth.make_resnet_state_dict(7, bcfg), types.SimpleNamespace(resnet=types.SimpleNamespace(**bcfg)), None, "x",
                     device=dev, dtype="bf16x3")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32w", "bf16x3"])
+def test_model_surface_runs_a_resnet_config(tmp_path, dtype):
+    """`Model(state, config, logger, target)` with `config.resnet` (riser/nets/resnet.py:72-99) instead of `config.cnn`: the
+    reference's Model hard-wires ConvNet (riser/model.py:13); here the same surface - classify of one normalised read, the
+    batched raw-read entry point with ragged lengths, the ReadUntil control loop - runs the ResNet, against the oracle's ResNet
+    (pinned to the reference's own outputs above) and the oracle's per-read loop."""
+    import logging
+    import torch
+    from riser_amd import Kit, Model, SequencerControl, SignalProcessor
+    from riser_amd.fake_client import FakeClient, FakeRead
+    from riser_amd.preprocess import pack_reads
+    from test_gpu_more import _oracle_loop
+    dev = torch.device("cuda", 0)
+    cfg = dict(synth.RESNET_BENCH_CFG)
+    sd = synth.make_resnet_state_dict(7, cfg)
+    config = types.SimpleNamespace(model="resnet", resnet=types.SimpleNamespace(**cfg))
+    path = str(tmp_path / "mRNA_model_RNA004_RP4.pth")                 # riser/model.py:19 reads a file
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, path)
+    m = Model(path, config, None, "mRNA", dtype=dtype, device=dev)
+    assert m.dtype == ("bf16x3" if dtype == "bf16x3" else "f32")
+    # one read at a time (riser/control.py:68-69)
+    for L in (4097, 8615):
+        x = _inputs(L)[1]
+        want = ro.softmax(rr.resnet_forward(sd, cfg, x[None]))[0]
+        got = m.classify(x)
+        assert got.shape == (2,) and np.abs(got.cpu().numpy() - want).max() < 1e-3
+    # raw int16 reads of different lengths in one call: normalised on the device, grouped by length for the program
+    lens = [4096, 5000, 8615, 5000, 12000]
+    sigs = [synth.make_signals(20260103, 1, n, first_read=300 + i)[0] for i, n in enumerate(lens)]
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    probs = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+    for i, s in enumerate(sigs):
+        want = ro.softmax(rr.resnet_forward(sd, cfg, ro.mad_normalise(s).astype(np.float32)[None]))[0]
+        assert np.abs(probs[i] - want).max() < 1e-3, i
+    with pytest.raises(ValueError):                                     # shorter than the stem + stages accept
+        m.classify(np.zeros(m.min_length - 1, dtype=np.float32))
+    # the control loop with this model: rows, probabilities and decisions of the oracle's per-read loop
+    class _Cpu:
+        def classify(self, x):
+            return torch.from_numpy(ro.softmax(rr.resnet_forward(sd, cfg, np.asarray(x, dtype=np.float32)[None]))[0])
+    rng = np.random.default_rng(11)
+    batches = [[(ch, FakeRead(f"id-{b * 5 + ch}", synth.make_raw_read(55, b * 5 + ch, int(rng.integers(3000, 24000)),
+                                                                      polya=((b * 5 + ch) % 4 != 0))))
+                for ch in range(1, 25)] for b in range(2)]
+    want_rows, want_rej, want_fin = _oracle_loop(batches, "RNA004", (1,), "enrich", 0.9, {1: _Cpu()})
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    client = FakeClient(batches)
+    out = str(tmp_path / "o")
+    ctl = SequencerControl(client, [m], proc, logging.getLogger("c"), out)
+    ctl.start(); ctl.target("enrich", 0.5, 0.9); ctl.finish()
+    lines = open(out + ".csv").read().strip().split("\n")[1:]
+    assert len(lines) == len(want_rows) > 10
+    for ln_, w in zip(lines, want_rows):
+        p = ln_.split(",")
+        assert (p[1], int(p[2]), int(p[3])) == w[:3]
+        assert np.allclose([float(v) for v in p[5].split(";")], w[4], atol=1e-3)
+        if not any(abs(q - 0.9) < 1e-3 or abs(1 - q - 0.9) < 1e-3 for q in w[4]):
+            assert p[8] == w[3], (p, w)
+    m.close()
