@@ -300,7 +300,9 @@ class Model:
         if B <= cap:
             return B
         n = -(-B // cap)
-        return min(cap, -(-(-(-B // n)) // 64) * 64)
+        # equal shares, rounded up to whole tile rounds of the late layers at 16000-sample reads (a 640-read share is two
+        # rounds of tiles for 1.25 rounds of work: 1280 reads run as 768 + 512, not 640 + 640)
+        return min(cap, -(-(-(-B // n)) // 256) * 256)
 
     def reserve(self, B: int, lmax: int):
         """Allocate the workspace of the current stream for batches of up to B reads of up to lmax samples now (a
