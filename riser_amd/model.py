@@ -294,10 +294,11 @@ class Model:
         """Reads per library call for a batch of B reads of up to lmax samples: B itself, or - beyond the 2 GiB buffer
         window (max_batch) or the cache-friendly size - the size of equal sub-batches.  Reads are independent and their
         bits do not depend on their batch-mates, so the cut changes nothing but the time."""
-        cap = self.max_batch(lmax)
+        hard = self.max_batch(lmax)
+        cap = hard
         if self._seq is None:
-            cap = min(cap, max(512, self._CALL_SAMPLES.get(self.dtype, 2048 << 14) // ((int(lmax) // 1024 + 1) * 1024)))
-        if B <= cap:
+            cap = min(hard, max(512, self._CALL_SAMPLES.get(self.dtype, 2048 << 14) // ((int(lmax) // 1024 + 1) * 1024)))
+        if B <= cap or B <= min(hard, cap + cap // 4):          # the cache-friendly size is a preference: no sliver calls
             return B
         n = -(-B // cap)
         # equal shares, rounded up to whole tile rounds of the late layers at 16000-sample reads (a 640-read share is two
