@@ -39,6 +39,7 @@ Hooks Hooks::from_env() {
     h.no_rect_order = flag("RS_NO_RECT_ORDER");
     h.no_tail_split = flag("RS_NO_TAIL_SPLIT");
     h.tail_debug = flag("RS_TAIL_DEBUG");
+    h.ring_tail_split = flag("RS_RING_TAIL_SPLIT");
     h.no_fuse0 = flag("RS_NO_FUSE0");
     h.no_stream_f32 = flag("RS_NO_STREAM_F32");
     h.no_stream_h16 = flag("RS_NO_STREAM_H16");

@@ -56,6 +56,7 @@ struct DeviceGuard {
 struct Hooks {
     bool no_rect_order = false;      // RS_NO_RECT_ORDER: n-major tile order instead of XCD rectangles
     bool tail_debug = false;         // RS_TAIL_DEBUG: print every head / tail decision
+    bool ring_tail_split = false;    // RS_RING_TAIL_SPLIT: head + tail launches for the 16-bit ring kernel too (measured: a wash)
     bool no_tail_split = false;      // RS_NO_TAIL_SPLIT: tiled conv layers (fp32 Winograd, 16-bit ring) always as ONE launch (tile_walk.hpp: plan_tail_split)
     bool no_fuse0 = false;           // RS_NO_FUSE0: layer 0 as its own launch on the fp32 Winograd path
     bool no_stream_f32 = false;      // RS_NO_STREAM_F32 / _H16: tiled kernels instead of the streaming ones

@@ -796,8 +796,12 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
 #endif
         return RS_OK;
     };
+    // Head + tail launches are OFF for this kernel unless RS_RING_TAIL_SPLIT is set: measured over 24 random batch shapes
+    // (tools/tail_split_check.py, bf16x3) the split is worth -2.7 ... +2.3 % with a mean of 0.0 - this kernel's small tiles pay a
+    // prologue and an epilogue each that the planner's tile model does not price well enough to pick the winners - where the
+    // fp32 Winograd kernels gain up to 4 % and never lose.
     TailSplit split;
-    if (!pinned && !L.hooks->no_tail_split)
+    if (!pinned && !L.hooks->no_tail_split && L.hooks->ring_tail_split)
         split = plan_tail_split(
             kNumShapes, rows64, num_cu, single_cost, [&](int k) { return tile_cost(kShapes[k], n_panels, x3); },
             [&](int k) { return kShapes[k].wm * 16 * kShapes[k].mt; },
