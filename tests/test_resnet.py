@@ -194,3 +194,38 @@ def test_model_surface_runs_a_resnet_config(tmp_path, dtype):
         if not any(abs(q - 0.9) < 1e-3 or abs(1 - q - 0.9) < 1e-3 for q in w[4]):
             assert p[8] == w[3], (p, w)
     m.close()
+
+
+RANDOM_BASIC_CFGS = [
+    dict(channels=[16, 24, 40, 64], kernel=7, padding=3, stride=2, block="basic", n_layers=4, blocks=[1, 2, 1, 1], n_classes=2),
+    dict(channels=[21, 35, 77], kernel=19, padding=5, stride=3, block="basic", n_layers=3, blocks=[2, 1, 2], n_classes=2),
+    dict(channels=[8, 80], kernel=5, padding=2, stride=1, block="basic", n_layers=2, blocks=[1, 1], n_classes=2),
+    dict(channels=[30], kernel=33, padding=16, stride=4, block="basic", n_layers=1, blocks=[3], n_classes=2),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", RANDOM_BASIC_CFGS, ids=["16-24-40-64", "21-35-77", "8-80", "30x3-k33"])
+def test_resnet_split_precision_over_other_shapes(cfg):
+    """the split-precision stem and block kernels away from the bench's shape: odd and tiny channel counts (8 -> one MFMA
+    column tile with a 8-halfword row pitch, 77 / 80 -> five), channel counts that are not multiples of 4, stems of one and
+    two k-steps (kernel 33), strides 1 - 4, one to three blocks per stage, lengths that end tiles mid-way - against the oracle
+    and the fp32 program"""
+    import torch
+    from riser_amd.resnet import ResNetModel
+    dev = torch.device("cuda", 0)
+    sd = synth.make_resnet_state_dict(11, cfg)
+    config = types.SimpleNamespace(resnet=types.SimpleNamespace(**cfg))
+    x3 = ResNetModel(sd, config, None, "x", device=dev, dtype="bf16x3")
+    f32 = ResNetModel(sd, config, None, "x", device=dev)
+    for L in (2500, 4099, 9000):
+        x = _inputs(L)
+        p3, l3 = x3.classify_batch(x, return_logits=True)
+        pf, lf = f32.classify_batch(x, return_logits=True)
+        want = rr.resnet_forward(sd, cfg, x)
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(lf.cpu().numpy() - want).max() < 1e-4 * scale, L
+        assert np.abs(l3.cpu().numpy() - want).max() < 5e-3 * scale, L
+        assert np.abs(p3.cpu().numpy() - ro.softmax(want)).max() < 1e-3, L
+    x3.close()
+    f32.close()
