@@ -321,11 +321,12 @@ RS_API size_t rs_seqnet_workspace_bytes(const rs_seqnet* m, int B, int L);
 RS_API int rs_seqnet_forward(rs_seqnet* m, const float* d_x /* fp32 [B, L] */, int B, int L, void* d_ws, size_t ws_bytes,
                       float* d_probs, float* d_logits, void* stream);
 /*
- * ABI 2.3: arithmetic of a program's residual BASIC blocks (riser/nets/resnet.py:50-57 + shortcut :21-24,45-47) - where a
- * ResNet's time is.  RS_F32 (default: the f32-input MFMA) or RS_BF16X3: split precision on the bf16 MFMA as RS_BF16X3 of
- * rs_model_create computes it (hi + lo pairs, three v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate; activations stay fp32
- * between launches) - BASELINE.json's "1D-ResNet forward pass ... MFMA bf16" inside the 1e-3 tolerance.  Stem, head, bottleneck
- * blocks and unfused ops keep the f32-input MFMA.  RS_ERR_ARG for any other dtype, or for a program without such a block.
+ * ABI 2.3: arithmetic of a program's stem and residual basic blocks (riser/nets/resnet.py:50-57, shortcuts :21-24,45-47; the
+ * bottleneck blocks :60-70 too when RS_SEQ_BNECK_X3 was set at rs_seqnet_create - measured slower than their fp32 form, so off):
+ * where a ResNet's time is.  RS_F32 (default: the f32-input MFMA) or RS_BF16X3: split precision
+ * on the bf16 MFMA as RS_BF16X3 of rs_model_create computes it (hi + lo pairs, three v_mfma_f32_16x16x32_bf16 per product, fp32
+ * accumulate; activations stay fp32 between launches) - BASELINE.json's "1D-ResNet forward pass ... MFMA bf16" inside the 1e-3
+ * tolerance.  The head and unfused ops keep fp32.  RS_ERR_ARG for any other dtype, or for a program without a fused residual block.
  */
 RS_API int rs_seqnet_set_mode(rs_seqnet* m, int dtype /* rs_dtype */);
 

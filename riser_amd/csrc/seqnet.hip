@@ -1234,6 +1234,215 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_kernel(const BneckAr
     }
 }
 
+// The bottleneck block in split precision on the bf16 MFMA (the arithmetic and operand layouts of seq_basic_block_x3_kernel:
+// k-steps of 32, weights as two bf16 planes [k-step][kq][n][8], both LDS tiles stored already split with a row pitch of
+// 8 (mod 16) halfwords).  Three GEMM phases as above; the output keeps the fp32 kernel's per-lane stores (c_out = 4 c_mid: an
+// image of the tile's outputs does not fit next to the weights).
+struct BneckX3Args {
+    const float* x;
+    unsigned x_bytes;
+    float* y;
+    const unsigned short *w1, *w2, *w3;            // planes [hi | lo]: [S1][4][NPm][8], [S2][4][NPm][8], [S3 + Ssc][4][NPo][8]
+    const float *b1, *b2, *b3;
+    int NPm, NPo;
+    int B, T_in, T_out, c_in, c_mid, c_out, Cmp, stride;
+    int Ksc, S1, S2, S3, Ssc;
+    int R2, tiles_per_read, n_tiles;
+};
+
+template <int NTM, int NTO>
+__global__ __launch_bounds__(256) void seq_bottleneck_block_x3_kernel(const BneckX3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    constexpr int RA = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int p1 = a.S1 * 4 * a.NPm * 8, p2 = a.S2 * 4 * a.NPm * 8, p3 = (a.S3 + a.Ssc) * 4 * a.NPo * 8;   // halfwords per plane
+    unsigned short* wl1 = reinterpret_cast<unsigned short*>(lds8);
+    unsigned short* wl2 = wl1 + 2 * p1;
+    unsigned short* wl3 = wl2 + 2 * p2;
+    const int tplane = (RA + 4) * a.Cmp;
+    unsigned short* t1h = wl3 + 2 * p3;            // t1: [hi plane | lo plane], then t2 the same
+    unsigned short* t1l = t1h + tplane;
+    unsigned short* t2h = t1l + tplane;
+    unsigned short* t2l = t2h + tplane;
+    for (int i = threadIdx.x; i < 2 * p1 / 8; i += 256) reinterpret_cast<u32x4*>(wl1)[i] = reinterpret_cast<const u32x4*>(a.w1)[i];
+    for (int i = threadIdx.x; i < 2 * p2 / 8; i += 256) reinterpret_cast<u32x4*>(wl2)[i] = reinterpret_cast<const u32x4*>(a.w2)[i];
+    for (int i = threadIdx.x; i < 2 * p3 / 8; i += 256) reinterpret_cast<u32x4*>(wl3)[i] = reinterpret_cast<const u32x4*>(a.w3)[i];
+    for (int i = threadIdx.x; i < 4 * tplane / 2; i += 256) reinterpret_cast<unsigned*>(t1h)[i] = 0u;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const int lim = a.T_in * a.c_in;
+    float b1c[NTM], b2c[NTM], b3c[NTO];
+#pragma unroll
+    for (int j = 0; j < NTM; ++j) {
+        b1c[j] = a.b1[16 * j + r];
+        b2c[j] = a.b2[16 * j + r];
+    }
+#pragma unroll
+    for (int j = 0; j < NTO; ++j) b3c[j] = a.b3[16 * j + r];
+    const int n_mt = (a.R2 + 15) / 16;
+    auto wfrag = [&](const unsigned short* w, int plane, int NP, int s, int j, u32x4& bh, u32x4& bl) {
+        const int n = 16 * j + r;
+        if (n < NP) {
+            const unsigned short* q = w + ((s * 4 + kq) * NP + n) * 8;
+            bh = *reinterpret_cast<const u32x4*>(q);
+            bl = *reinterpret_cast<const u32x4*>(q + plane);
+        } else {
+            bh = bl = (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    // a lane's eight consecutive x values at element o of the read (zero outside it), K index kidx .. kidx + 7 of Klim
+    auto xload8 = [&](int64_t xbase, bool ok, int o, int kidx, int Klim, f32x4& lo4, f32x4& hi4) {
+        if (ok && o >= 0 && o + 7 < lim) {
+            lo4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)((xbase + o) * 4), 0, 0));
+            hi4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)((xbase + o) * 4 + 16), 0, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lo4[i] = (ok && kidx + i < Klim && o + i >= 0 && o + i < lim) ? a.x[xbase + o + i] : 0.0f;
+                hi4[i] = (ok && kidx + 4 + i < Klim && o + 4 + i >= 0 && o + 4 + i < lim) ? a.x[xbase + o + 4 + i] : 0.0f;
+            }
+        }
+    };
+    // relu(acc + bias) of one accumulator register -> the split tile (one channel of one row)
+    auto put_split = [&](unsigned short* th, unsigned short* tl, int at, float v) {
+        const __bf16 h = (__bf16)v;
+        th[at] = __builtin_bit_cast(unsigned short, h);
+        tl[at] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+    };
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int b = tile / a.tiles_per_read;
+        const int to0 = (tile - b * a.tiles_per_read) * a.R2;
+        const int64_t xbase = (int64_t)b * lim;
+        // ---- phase A: t1 rows j = 0 .. RA-1 <-> input positions q0 + j ------------------------------------------------
+        {
+            const int q0 = to0 * a.stride - 1;
+            f32x4 acc[2][NTM];
+            int off0[2];
+            bool ok[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int q = q0 + (wave * 2 + m) * 16 + r;
+                ok[m] = q >= 0 && q < a.T_in;
+                off0[m] = q * a.c_in;
+#pragma unroll
+                for (int j = 0; j < NTM; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            for (int s = 0; s < a.S1; ++s) {
+                u32x4 bh[NTM], bl[NTM];
+#pragma unroll
+                for (int j = 0; j < NTM; ++j) wfrag(wl1, p1, a.NPm, s, j, bh[j], bl[j]);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    f32x4 xa, xb;
+                    xload8(xbase, ok[m], off0[m] + 32 * s + 8 * kq, 32 * s + 8 * kq, a.c_in, xa, xb);
+                    u32x4 ah, al;
+                    split8(xa, xb, ah, al);
+#pragma unroll
+                    for (int j = 0; j < NTM; ++j) acc[m][j] = mfma_x3(ah, al, bh[j], bl[j], acc[m][j]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int jrow = (wave * 2 + m) * 16 + 4 * kq + e;
+                    const int q = q0 + jrow;
+                    const bool okq = q >= 0 && q < a.T_in;
+#pragma unroll
+                    for (int j = 0; j < NTM; ++j) {
+                        const int col = 16 * j + r;
+                        if (col < a.c_mid) put_split(t1h, t1l, jrow * a.Cmp + col, okq ? fmaxf(acc[m][j][e] + b1c[j], 0.0f) : 0.0f);
+                    }
+                }
+        }
+        __syncthreads();
+        // ---- phase B: t2 row i <-> output position to0 + i: conv3 over t1 rows i * stride .. + 2 -----------------------
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int mt = wave + 4 * m;
+            if (mt >= n_mt) break;
+            f32x4 acc[NTM];
+#pragma unroll
+            for (int j = 0; j < NTM; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int trow = ((mt * 16 + r) * a.stride) * a.Cmp + 8 * kq;
+            for (int s = 0; s < a.S2; ++s) {
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(t1h + trow + 32 * s);
+                const u32x4 al = *reinterpret_cast<const u32x4*>(t1l + trow + 32 * s);
+#pragma unroll
+                for (int j = 0; j < NTM; ++j) {
+                    u32x4 bh, bl;
+                    wfrag(wl2, p2, a.NPm, s, j, bh, bl);
+                    acc[j] = mfma_x3(ah, al, bh, bl, acc[j]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = mt * 16 + 4 * kq + e;
+#pragma unroll
+                for (int j = 0; j < NTM; ++j) {
+                    const int col = 16 * j + r;
+                    if (col < a.c_mid) put_split(t2h, t2l, i * a.Cmp + col, fmaxf(acc[j][e] + b2c[j], 0.0f));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase C: y row i = conv1x1(t2 row i) + b3 + shortcut -> ReLU ------------------------------------------------
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int mt = wave + 4 * m;
+            if (mt >= n_mt) break;
+            f32x4 acc[NTO];
+#pragma unroll
+            for (int j = 0; j < NTO; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int trow = (mt * 16 + r) * a.Cmp + 8 * kq;
+            for (int s = 0; s < a.S3; ++s) {
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(t2h + trow + 32 * s);
+                const u32x4 al = *reinterpret_cast<const u32x4*>(t2l + trow + 32 * s);
+#pragma unroll
+                for (int j = 0; j < NTO; ++j) {
+                    u32x4 bh, bl;
+                    wfrag(wl3, p3, a.NPo, s, j, bh, bl);
+                    acc[j] = mfma_x3(ah, al, bh, bl, acc[j]);
+                }
+            }
+            if (a.Ksc) {
+                const int i_r = mt * 16 + r;
+                const bool okr = i_r < a.R2 && to0 + i_r < a.T_out;
+                const int off0 = (to0 + i_r) * a.stride * a.c_in;
+                for (int s = 0; s < a.Ssc; ++s) {
+                    f32x4 xa, xb;
+                    xload8(xbase, okr, off0 + 32 * s + 8 * kq, 32 * s + 8 * kq, a.Ksc, xa, xb);
+                    u32x4 ah, al;
+                    split8(xa, xb, ah, al);
+#pragma unroll
+                    for (int j = 0; j < NTO; ++j) {
+                        u32x4 bh, bl;
+                        wfrag(wl3, p3, a.NPo, a.S3 + s, j, bh, bl);
+                        acc[j] = mfma_x3(ah, al, bh, bl, acc[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = mt * 16 + 4 * kq + e;
+                const int pos = to0 + i;
+                if (i >= a.R2 || pos >= a.T_out) continue;
+                const int64_t orow = ((int64_t)b * a.T_out + pos) * a.c_out;
+#pragma unroll
+                for (int j = 0; j < NTO; ++j) {
+                    const int col = 16 * j + r;
+                    if (col >= a.c_out) continue;
+                    float v = acc[j][e] + b3c[j];
+                    if (!a.Ksc) v += a.x[xbase + (int64_t)pos * a.c_in + col];    // identity shortcut
+                    a.y[orow + col] = fmaxf(v, 0.0f);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void seq_maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
                                                           int T_in, int T_out, int c, int pad) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1323,6 +1532,8 @@ struct OpDev {
     // the same block in split precision (seq_basic_block_x3_kernel): bf16 [hi | lo] planes, own row / column pitches
     unsigned short* d_x_w1 = nullptr;   // (fuse == 1, the stem: its one weight matrix)
     unsigned short* d_x_w2 = nullptr;
+    unsigned short* d_x_w3 = nullptr;   // (fuse == 3, the bottleneck block: third conv + shortcut)
+    int x_npm = 0, x_s3 = 0;            // bottleneck: mid column pitch, k-steps of the third conv
     int x_cp = 0, x_np = 0, x_s1 = 0, x_s2a = 0, x_ssc = 0;
     size_t x_wbytes = 0;      // bytes of both weight matrices in LDS
     // bottleneck block (fuse == 3): third conv (+ shortcut), mid width
@@ -1338,7 +1549,11 @@ using namespace rs;
 
 struct rs_seqnet {
     bool fuse = true;              // RS_SEQ_NOFUSE=1 (read at create): one launch per op, as the program is written
-    int mode = 0;                  // rs_seqnet_set_mode: 0 fp32 (f32-input MFMA), 1 split precision on the bf16 MFMA (basic blocks)
+    int mode = 0;                  // rs_seqnet_set_mode: 0 fp32 (f32-input MFMA), 1 split precision on the bf16 MFMA
+    bool bneck_x3 = false;         // RS_SEQ_BNECK_X3=1 (read at create): bottleneck blocks in split precision too.  Off: measured
+                                   // SLOWER than their fp32 form (0.734 against 0.718 ms on the 32-48-68 net, stem included) - with
+                                   // mid widths of 8-17 channels a block's GEMMs are a few k-steps and the split costs more VALU
+                                   // time than the matrix pipe saves
     std::vector<std::vector<float>> keep_w;   // host copies of the conv weights until fusion has packed them
     int device = 0;
     int n_buffers = 0;
@@ -1527,6 +1742,42 @@ hipError_t fuse_program(rs_seqnet* m, const std::vector<const float*>& hw, const
             if (e == hipSuccess) e = upload_vec(&o.d_f_b2, b2);
             if (e == hipSuccess) e = upload_vec(&o.d_f_b3, b3);
             if (e != hipSuccess) return e;
+            {   // the split-precision packing (seq_bottleneck_block_x3_kernel)
+                int Cmx = (c_mid + 7) & ~7;
+                while (Cmx % 16 != 8) Cmx += 8;
+                const int S1 = (c_in + 31) / 32, S2 = (3 * Cmx + 31) / 32, S3 = (Cmx + 31) / 32, Sscx = (Ksc + 31) / 32;
+                const size_t q1 = (size_t)S1 * 4 * NPm * 8, q2 = (size_t)S2 * 4 * NPm * 8, q3 = (size_t)(S3 + Sscx) * 4 * NPo * 8;
+                const size_t xbytes = (q1 + q2 + q3) * 2 * 2;
+                if (xbytes + (size_t)2 * (128 + 4) * Cmx * 4 <= lds_cap) {
+                    std::vector<unsigned short> x1(2 * q1, 0), x2(2 * q2, 0), x3v(2 * q3, 0);
+                    auto put = [&](std::vector<unsigned short>& dst, size_t plane, int NP, int kidx, int n, float w) {
+                        const size_t at = (((size_t)(kidx / 32) * 4 + (kidx % 32) / 8) * NP + n) * 8 + kidx % 8;
+                        const unsigned short h = bf16_rne(w);
+                        dst[at] = h;
+                        dst[plane + at] = bf16_rne(w - bf16_widen(h));
+                    };
+                    for (int co = 0; co < c_mid; ++co) {
+                        for (int ci = 0; ci < c_in; ++ci) put(x1, q1, NPm, ci, co, hw[k1][(size_t)co * c_in + ci]);
+                        for (int ci = 0; ci < c_mid; ++ci)
+                            for (int kk = 0; kk < 3; ++kk) put(x2, q2, NPm, kk * Cmx + ci, co, hw[k1 + 1][((size_t)co * c_mid + ci) * 3 + kk]);
+                    }
+                    for (int co = 0; co < c_out; ++co) {
+                        for (int ci = 0; ci < c_mid; ++ci) put(x3v, q3, NPo, ci, co, hw[k1 + 2][(size_t)co * c_mid + ci]);
+                        if (ksc != (size_t)-1)
+                            for (int ci = 0; ci < c_in; ++ci) put(x3v, q3, NPo, 32 * S3 + ci, co, hw[ksc][(size_t)co * c_in + ci]);
+                    }
+                    e = upload_u16(&o.d_x_w1, x1);
+                    if (e == hipSuccess) e = upload_u16(&o.d_x_w2, x2);
+                    if (e == hipSuccess) e = upload_u16(&o.d_x_w3, x3v);
+                    if (e != hipSuccess) return e;
+                    o.x_cp = Cmx;
+                    o.x_s1 = S1;
+                    o.x_s2a = S2;
+                    o.x_s3 = S3;
+                    o.x_ssc = Sscx;
+                    o.x_wbytes = xbytes;
+                }
+            }
             o.fuse = 3;
             o.fuse_skip = (int)(k1 + 2 - k);
             o.f_src = X;
@@ -1667,6 +1918,7 @@ int rs_seqnet_create(const rs_seq_op* ops, int n_ops, int n_buffers, const float
     m->c_last = c_last;
     m->scalar_conv = getenv("RS_SEQ_SCALAR") != nullptr;
     m->fuse = getenv("RS_SEQ_NOFUSE") == nullptr && !m->scalar_conv;
+    m->bneck_x3 = getenv("RS_SEQ_BNECK_X3") != nullptr;
     std::vector<const float*> hw, hb;
     {
         int cus = 0;
@@ -1755,6 +2007,7 @@ int rs_seqnet_destroy(rs_seqnet* m) {
         if (o.d_f_b3) (void)hipFree(o.d_f_b3);
         if (o.d_x_w1) (void)hipFree(o.d_x_w1);
         if (o.d_x_w2) (void)hipFree(o.d_x_w2);
+        if (o.d_x_w3) (void)hipFree(o.d_x_w3);
         if (o.d_f_w1) (void)hipFree(o.d_f_w1);
         if (o.d_f_w2) (void)hipFree(o.d_f_w2);
         if (o.d_f_b1) (void)hipFree(o.d_f_b1);
@@ -1779,12 +2032,13 @@ int rs_seqnet_set_mode(rs_seqnet* m, int dtype) {
         set_error("rs_seqnet_set_mode: generic conv programs run in RS_F32 or RS_BF16X3 (split precision on the bf16 MFMA)");
         return RS_ERR_ARG;
     }
-    // split precision covers the residual BASIC blocks of a program (where a ResNet's time is); everything else - stem, head,
-    // bottleneck blocks, unfused ops - keeps the f32-input MFMA.  A program without a single such block has nothing to switch.
+    // split precision covers the stem and the residual BASIC blocks of a program (where a ResNet's time is), and its bottleneck
+    // blocks when RS_SEQ_BNECK_X3 was set at create (measured slower than their fp32 form: off); the head and unfused ops keep
+    // fp32.  A program without a single fused residual block has nothing to switch.
     bool any = false;
-    for (const OpDev& o : m->ops) any = any || (o.fuse == 2 && o.d_x_w1);
+    for (const OpDev& o : m->ops) any = any || ((o.fuse == 2 || o.fuse == 3) && o.d_x_w1);
     if (!any) {
-        set_error("rs_seqnet_set_mode: this program has no residual basic block that runs in split precision");
+        set_error("rs_seqnet_set_mode: this program has no residual block that runs in split precision");
         return RS_ERR_ARG;
     }
     m->mode = 1;
@@ -1981,6 +2235,45 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
             const OpShape& s1 = shp[k + o.fuse_skip - 2];
             const OpShape& s2 = shp[k + o.fuse_skip - 1];
             const int64_t xb = (int64_t)B * s1.t_in * o.f_cin * 4;
+            if (xb < 0x7fffffffLL && (int64_t)B * s2.t_out * o.f_cout * 4 < 0x7fffffffLL && m->mode == 1 && m->bneck_x3 && o.d_x_w1) {
+                BneckX3Args a;
+                a.x = buf(o.f_src);
+                a.x_bytes = (unsigned)xb;
+                a.y = buf(o.f_dst);
+                a.w1 = o.d_x_w1; a.w2 = o.d_x_w2; a.w3 = o.d_x_w3;
+                a.b1 = o.d_f_b1; a.b2 = o.d_f_b2; a.b3 = o.d_f_b3;
+                a.NPm = o.f_npm;
+                a.NPo = o.f_nps;
+                a.B = B;
+                a.T_in = s1.t_in;
+                a.T_out = s2.t_out;
+                a.c_in = o.f_cin;
+                a.c_mid = o.f_cmid;
+                a.c_out = o.f_cout;
+                a.Cmp = o.x_cp;
+                a.stride = o.f_stride;
+                a.Ksc = o.f_ksc;
+                a.S1 = o.x_s1; a.S2 = o.x_s2a; a.S3 = o.x_s3; a.Ssc = o.x_ssc;
+                a.R2 = (128 - 3) / o.f_stride + 1;
+                a.tiles_per_read = (s2.t_out + a.R2 - 1) / a.R2;
+                a.n_tiles = B * a.tiles_per_read;
+                using FnX = void (*)(const BneckX3Args);
+                static const FnX tablex[2][5] = {
+                    {seq_bottleneck_block_x3_kernel<1, 1>, seq_bottleneck_block_x3_kernel<1, 2>, seq_bottleneck_block_x3_kernel<1, 3>,
+                     seq_bottleneck_block_x3_kernel<1, 4>, seq_bottleneck_block_x3_kernel<1, 5>},
+                    {seq_bottleneck_block_x3_kernel<2, 1>, seq_bottleneck_block_x3_kernel<2, 2>, seq_bottleneck_block_x3_kernel<2, 3>,
+                     seq_bottleneck_block_x3_kernel<2, 4>, seq_bottleneck_block_x3_kernel<2, 5>}};
+                FnX fx = tablex[o.f_ntm - 1][o.f_nt - 1];
+                const size_t f_lds = o.x_wbytes + (size_t)2 * (128 + 4) * o.x_cp * 4;
+                RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fx), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / f_lds));
+                const int grid = std::min(a.n_tiles, m->num_cu * per_cu);
+                hipLaunchKernelGGL(fx, dim3(grid), dim3(256), f_lds, st, a);
+                RS_HIP(hipGetLastError());
+                last = o.f_dst;
+                k += o.fuse_skip;
+                continue;
+            }
             if (xb < 0x7fffffffLL && (int64_t)B * s2.t_out * o.f_cout * 4 < 0x7fffffffLL) {
                 BneckArgs a;
                 a.x = buf(o.f_src);

@@ -140,8 +140,8 @@ class SeqNet:
     """A conv / max-pool program on the device (rs_seqnet_*): uniform-length batches [B, L] -> probabilities."""
 
     def __init__(self, prog, n_buffers, fw, fb, c_last, device, dtype: str = "f32"):
-        """dtype: "f32" (every conv on the f32-input MFMA) or "bf16x3" (the residual basic blocks in split precision on the
-        bf16 MFMA, rs_seqnet_set_mode: within 1e-3 of the reference, ~1.5 x the fp32 rate)."""
+        """dtype: "f32" (every conv on the f32-input MFMA) or "bf16x3" (the stem and the residual blocks in split precision on the
+        bf16 MFMA, rs_seqnet_set_mode: within 1e-3 of the reference, ~1.6 x the fp32 rate)."""
         nv.require_gpu()
         d = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
@@ -227,7 +227,7 @@ def build_convnet_program(sd, cnn):
 
 class ResNetModel:
     def __init__(self, state, config, logger, target, device=None, dtype: str = "f32"):
-        """dtype "bf16x3": the residual basic blocks in split precision on the bf16 MFMA (SeqNet)."""
+        """dtype "bf16x3": the stem and the residual blocks in split precision on the bf16 MFMA (SeqNet)."""
         self.target, self.logger = target, logger
         c = config.resnet
         sd = state if isinstance(state, dict) else torch.load(state, map_location="cpu")

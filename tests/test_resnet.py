@@ -127,11 +127,54 @@ def test_resnet_basic_blocks_in_split_precision(golden_dir):
     assert np.abs(x3.classify_batch(x).cpu().numpy() - f32.classify_batch(x).cpu().numpy()).max() < 1e-3
     x3.close()
     f32.close()
-    # a program without a residual basic block has nothing to switch: the library says so
-    bcfg = BOTTLENECK_WIDE_CFG
-    with pytest.raises(Exception, match="basic block"):
-        ResNetModel(synth.make_resnet_state_dict(7, bcfg), types.SimpleNamespace(resnet=types.SimpleNamespace(**bcfg)), None, "x",
-                    device=dev, dtype="bf16x3")
+    # a program without a fused residual block has nothing to switch: the library says so
+    plain_cfg = dict(channels=[100], kernel=7, padding=3, stride=2, block="basic", n_layers=1, blocks=[1], n_classes=2)   # 100 > 80 columns
+    with pytest.raises(Exception, match="residual block"):
+        ResNetModel(synth.make_resnet_state_dict(7, plain_cfg), types.SimpleNamespace(resnet=types.SimpleNamespace(**plain_cfg)),
+                    None, "x", device=dev, dtype="bf16x3")
+
+
+@pytest.mark.gpu
+def test_resnet_bottleneck_blocks_in_split_precision(golden_dir):
+    """the bottleneck block (1x1, strided 3x3, 1x1, shortcut, add, ReLU: riser/nets/resnet.py:60-70) on the bf16 MFMA in split
+    precision: the reference's golden bottleneck net within 1e-3, the wide bottleneck net against the oracle and the fp32 program"""
+    import torch
+    from riser_amd.resnet import ResNetModel
+    dev = torch.device("cuda", 0)
+    g, cfg, sd = _load(golden_dir, "bottleneck")
+    os.environ["RS_SEQ_BNECK_X3"] = "1"         # read when a program is created: the kernel is opt-in (measured slower than fp32)
+    try:
+        _bottleneck_x3_checks(dev, g, cfg, sd)
+    finally:
+        del os.environ["RS_SEQ_BNECK_X3"]
+
+
+def _bottleneck_x3_checks(dev, g, cfg, sd):
+    from riser_amd.resnet import ResNetModel
+    m = ResNetModel(sd, types.SimpleNamespace(resnet=types.SimpleNamespace(**cfg)), None, "x", device=dev, dtype="bf16x3")
+    for L in (3000, 4097):
+        probs, logits = m.classify_batch(_inputs(L), return_logits=True)
+        assert np.abs(probs.cpu().numpy() - g[f"bottleneck.L{L}.probs"]).max() < 1e-3
+        assert np.abs(logits.cpu().numpy() - g[f"bottleneck.L{L}.logits"]).max() < 5e-3
+    m.close()
+    cfg = BOTTLENECK_WIDE_CFG
+    sd = synth.make_resnet_state_dict(7, cfg)
+    config = types.SimpleNamespace(resnet=types.SimpleNamespace(**cfg))
+    x3 = ResNetModel(sd, config, None, "x", device=dev, dtype="bf16x3")
+    f32 = ResNetModel(sd, config, None, "x", device=dev)
+    worst = 0.0
+    for L in (3000, 4097, 6024, 16000):
+        x = _inputs(L)
+        p3, l3 = x3.classify_batch(x, return_logits=True)
+        pf, lf = f32.classify_batch(x, return_logits=True)
+        want = rr.resnet_forward(sd, cfg, x)
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(l3.cpu().numpy() - want).max() < 5e-3 * scale, L
+        assert np.abs(p3.cpu().numpy() - ro.softmax(want)).max() < 1e-3, L
+        worst = max(worst, float(np.abs(l3.cpu().numpy() - lf.cpu().numpy()).max()))
+    assert 0 < worst < 5e-3 * scale
+    x3.close()
+    f32.close()
 
 
 @pytest.mark.gpu

@@ -10,7 +10,9 @@ from riser_amd.resnet import ResNetModel
 B, L = (int(sys.argv[1]) if len(sys.argv) > 1 else 512), (int(sys.argv[2]) if len(sys.argv) > 2 else 16000)
 dev = torch.device("cuda", 0)
 cfg = synth.RESNET_BENCH_CFG
-sd = synth.make_resnet_state_dict(7)
+if os.environ.get("RS_RESNET") == "bottleneck":       # the wide bottleneck net of tools/resnet_bottleneck_probe.py
+    cfg = dict(channels=[32, 48, 68], kernel=19, padding=5, stride=3, block="bottleneck", n_layers=3, blocks=[2, 2, 1], n_classes=2)
+sd = synth.make_resnet_state_dict(7, cfg)
 x = torch.from_numpy(np.stack([np.clip((s.astype(np.float32) - 500.0) / 60.0, -3.5, 3.5)
                                for s in synth.make_signals(20260103, 64, L)])).to(dev).repeat(B // 64, 1).contiguous()
 ms = {dt: ResNetModel(sd, types.SimpleNamespace(resnet=types.SimpleNamespace(**cfg)), None, "x", device=dev, dtype=dt)
