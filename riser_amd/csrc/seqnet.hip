@@ -482,23 +482,6 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
             const float* trow[MTW];
 #pragma unroll
             for (int m = 0; m < MTW; ++m) trow[m] = tl + ((wave * MTW + m) * 16 + r) * a.Cp + 4 * kq;
-            // identity shortcut: the residual values of this lane's outputs, requested before the K loop that hides them
-            float resv[MTW][4][NT];
-            if (!a.Ksc) {
-#pragma unroll
-                for (int m = 0; m < MTW; ++m)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = (wave * MTW + m) * 16 + 4 * kq + e;
-                        const int pos = to0 + i;
-                        const bool okr = i < TO && (!EDGE || pos < a.T_out);
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) {
-                            const int col = 16 * j + r;
-                            resv[m][e][j] = (okr && col < a.c_out) ? a.x[xbase + (int64_t)pos * a.c_in + col] : 0.0f;
-                        }
-                    }
-            }
             for (int k0 = 0; k0 < K2a16; k0 += 16) {
                 f32x4 bv[NT], av[MTW];
 #pragma unroll
@@ -557,23 +540,52 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
                     for (int m = 0; m < MTW; ++m) av[m] = avn[m];
                 }
             }
+            // ---- output through an fp32 IMAGE of the tile's outputs in LDS (round 5, as seq_basic_block_x3_kernel does): the
+            // tile's outputs are ONE contiguous span of y, a lane holds one channel of four rows - direct stores are 4 bytes wide
+            // in 64-byte segments.  The image aliases the intermediate tile (read by nobody behind the barrier; what it leaves in
+            // the tile's padding channels and rows is finite fp32 that meets zero weights), offset by `mis` floats so that image
+            // and span share their 16-byte phase; an identity shortcut's residual is the same span of x, added in the copy-out.
+            __syncthreads();
+            const int n_out = min(TO, a.T_out - to0);
+            const int64_t s0 = ((int64_t)b * a.T_out + to0) * a.c_out;
+            const int mis = (int)(s0 & 3);
 #pragma unroll
             for (int m = 0; m < MTW; ++m)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = (wave * MTW + m) * 16 + 4 * kq + e;
-                    const int pos = to0 + i;
-                    if (i >= TO || (EDGE && pos >= a.T_out)) continue;
-                    const int64_t orow = ((int64_t)b * a.T_out + pos) * a.c_out;
+                    if (i >= n_out) continue;
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         const int col = 16 * j + r;
-                        if (col >= a.c_out) continue;
-                        float v = acc[m][j][e] + b2c[j];
-                        if (!a.Ksc) v += resv[m][e][j];                  // identity shortcut
-                        a.y[orow + col] = fmaxf(v, 0.0f);
+                        if (col < a.c_out) tl[mis + i * a.c_out + col] = acc[m][j][e] + b2c[j];
                     }
                 }
+            __syncthreads();
+            {
+                const int n_f = n_out * a.c_out;
+                const int n_q = (mis + n_f + 3) >> 2;
+                const float* xres = a.x + xbase + (int64_t)to0 * a.c_in - mis;
+                float* ydst = a.y + (s0 - mis);
+                for (int q = threadIdx.x; q < n_q; q += kThr) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(tl + 4 * q);
+                    const int lo = 4 * q - mis;
+                    if (lo >= 0 && lo + 3 < n_f) {
+                        if (!a.Ksc) v += *reinterpret_cast<const f32x4*>(xres + 4 * q);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+                        *reinterpret_cast<f32x4*>(ydst + 4 * q) = v;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (lo + i >= 0 && lo + i < n_f) {
+                                float w = v[i];
+                                if (!a.Ksc) w += xres[4 * q + i];
+                                ydst[4 * q + i] = fmaxf(w, 0.0f);
+                            }
+                    }
+                }
+            }
         }
         __syncthreads();                                             // the next tile's phase 1 overwrites the LDS tile
     };
