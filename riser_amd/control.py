@@ -349,7 +349,7 @@ class _SignalStore:
             rows = self._rows_of(channels)
             # two reads of one channel in one batch (no real client does that: its cache is keyed by channel): nothing of
             # this batch goes to the rows - a later slice would overwrite a row an earlier slice's kernels still read
-            self._dup_channels = np.unique(rows).size != rows.shape[0]
+            self._dup_channels = bool(np.bincount(rows, minlength=self.n_rows).max(initial=0) > 1)
             self._ensure(self.n_rows, int(lens.sum()) if self._dup_channels else int(lens[lens > self.pitch].sum()))
         elif self.buf is None or self.buf.numel() < int(lens.sum()):
             self._ensure(0, int(lens.sum()))
@@ -753,13 +753,17 @@ class SequencerControl:
         else:
             # the decided reads, in batch order per list: rejects are sent first, then every decided read is finished
             # (riser/control.py:85-90,106-112); "try_again" reads stay with the client
-            key = self._client_key
             reads, dec = res.reads, res.decision
-            chan, sel = res.channels.tolist(), res.sel.tolist()
-            lists = []
-            for code in (nv.RS_REJECT, nv.RS_ACCEPT, nv.RS_NO_DECISION):
-                lists.append([(chan[k], key(reads[sel[k]])) for k in np.flatnonzero(dec == code).tolist()])
-            rejected, accepted, undecided = lists
+            codes = (nv.RS_REJECT, nv.RS_ACCEPT, nv.RS_NO_DECISION)
+            if _hp is not None and type(reads) is list:
+                rejected, accepted, undecided = _hp.decided(reads, np.ascontiguousarray(res.sel, dtype=np.int64),
+                                                            np.ascontiguousarray(res.channels, dtype=np.int64),
+                                                            np.ascontiguousarray(dec, dtype=np.uint8), codes)
+            else:
+                key = self._client_key
+                chan, sel = res.channels.tolist(), res.sel.tolist()
+                rejected, accepted, undecided = ([(chan[k], key(reads[sel[k]])) for k in np.flatnonzero(dec == code).tolist()]
+                                                 for code in codes)
             n_acc, n_rej = len(accepted), len(rejected)
             self.client.reject_reads(rejected, unblock_duration)
             self.client.finish_processing_reads(rejected + accepted + undecided)

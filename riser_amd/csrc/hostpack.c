@@ -587,11 +587,107 @@ static PyObject* hp_lookup(PyObject* self, PyObject* args) {
     Py_RETURN_NONE;
 }
 
+/* decided(reads, sel_i64, channels_i64, dec_u8, codes) -> tuple of len(codes) lists: list c holds (channels[k], key(reads[sel[k]]))
+ * for every k with dec[k] == codes[c], in order; key(read) = read.number if the read HAS that attribute (whatever its value),
+ * else read.id - riser/control.py:137-143.  The per-read Python of the reject / finish lists of a batch. */
+static PyObject* hp_decided(PyObject* self, PyObject* args) {
+    PyObject *reads, *sel, *chan, *dec, *codes;
+    if (!PyArg_ParseTuple(args, "OOOOO", &reads, &sel, &chan, &dec, &codes)) return NULL;
+    if (!PyList_Check(reads) || !PyTuple_Check(codes)) {
+        PyErr_SetString(PyExc_TypeError, "decided: reads must be a list, codes a tuple");
+        return NULL;
+    }
+    const Py_ssize_t n_codes = PyTuple_GET_SIZE(codes);
+    long code[8];
+    if (n_codes < 1 || n_codes > 8) {
+        PyErr_SetString(PyExc_ValueError, "decided: 1 to 8 codes");
+        return NULL;
+    }
+    for (Py_ssize_t c = 0; c < n_codes; ++c) {
+        code[c] = PyLong_AsLong(PyTuple_GET_ITEM(codes, c));
+        if (code[c] == -1 && PyErr_Occurred()) return NULL;
+    }
+    Py_buffer bs, bc, bd;
+    if (get_rbuf(sel, &bs, "decided(sel)") != 0) return NULL;
+    if (get_rbuf(chan, &bc, "decided(channels)") != 0) {
+        PyBuffer_Release(&bs);
+        return NULL;
+    }
+    if (get_rbuf(dec, &bd, "decided(dec)") != 0) {
+        PyBuffer_Release(&bs);
+        PyBuffer_Release(&bc);
+        return NULL;
+    }
+    const Py_ssize_t n = bs.len / (Py_ssize_t)sizeof(int64_t), n_reads = PyList_GET_SIZE(reads);
+    PyObject* out = NULL;
+    PyObject* s_number = NULL;
+    PyObject* s_id = NULL;
+    int bad = 0;
+    if (bc.len < (Py_ssize_t)(n * sizeof(int64_t)) || bd.len < n) {
+        PyErr_SetString(PyExc_ValueError, "decided: array shorter than the selection");
+        bad = 1;
+    }
+    if (!bad) {
+        out = PyTuple_New(n_codes);
+        s_number = PyUnicode_InternFromString("number");
+        s_id = PyUnicode_InternFromString("id");
+        if (!out || !s_number || !s_id) bad = 1;
+        for (Py_ssize_t c = 0; c < n_codes && !bad; ++c) {
+            PyObject* l = PyList_New(0);
+            if (!l) bad = 1; else PyTuple_SET_ITEM(out, c, l);
+        }
+    }
+    const int64_t* sel_ = (const int64_t*)bs.buf;
+    const int64_t* ch_ = (const int64_t*)bc.buf;
+    const uint8_t* d_ = (const uint8_t*)bd.buf;
+    for (Py_ssize_t k = 0; k < n && !bad; ++k) {
+        Py_ssize_t c = 0;
+        while (c < n_codes && code[c] != (long)d_[k]) ++c;
+        if (c == n_codes) continue;
+        if (sel_[k] < 0 || sel_[k] >= n_reads) {
+            PyErr_SetString(PyExc_ValueError, "decided: index out of range");
+            bad = 1;
+            break;
+        }
+        PyObject* read = PyList_GET_ITEM(reads, sel_[k]);
+        PyObject* key = PyObject_GetAttr(read, s_number);
+        if (!key) {
+            if (!PyErr_ExceptionMatches(PyExc_AttributeError)) {
+                bad = 1;
+                break;
+            }
+            PyErr_Clear();
+            key = PyObject_GetAttr(read, s_id);
+            if (!key) {
+                bad = 1;
+                break;
+            }
+        }
+        PyObject* chn = PyLong_FromLongLong((long long)ch_[k]);
+        PyObject* tup = chn ? PyTuple_Pack(2, chn, key) : NULL;
+        Py_XDECREF(chn);
+        Py_DECREF(key);
+        if (!tup || PyList_Append(PyTuple_GET_ITEM(out, c), tup) != 0) bad = 1;
+        Py_XDECREF(tup);
+    }
+    PyBuffer_Release(&bs);
+    PyBuffer_Release(&bc);
+    PyBuffer_Release(&bd);
+    Py_XDECREF(s_number);
+    Py_XDECREF(s_id);
+    if (bad) {
+        Py_XDECREF(out);
+        return NULL;
+    }
+    return out;
+}
+
 static PyMethodDef methods[] = {
     {"lengths", hp_lengths, METH_VARARGS, "lengths(reads, out_int64): samples of every read's raw_data"},
     {"gather", hp_gather, METH_VARARGS, "gather(reads, start_int64, out_int16) -> samples written"},
     {"format_rows", hp_format_rows, METH_VARARGS, "CSV rows of one batch as one string (text built without the GIL)"},
     {"repr_double", hp_repr_double, METH_O, "repr(float) as format_rows writes it (test hook)"},
+    {"decided", hp_decided, METH_VARARGS, "decided(reads, sel, channels, dec, codes) -> per code a list of (channel, read key)"},
     {"unpack", hp_unpack, METH_VARARGS, "unpack(entries, channels_int64) -> reads: splits [(channel, read), ...]"},
     {"attrs", hp_attrs, METH_VARARGS, "attrs(reads, name) -> [getattr(r, name) for r in reads]"},
     {"lookup", hp_lookup, METH_VARARGS, "lookup(dict, keys, out_int64): out[i] = dict.get(keys[i], 0)"},

@@ -285,3 +285,26 @@ def test_csv_double_format_is_python_repr(hp):
              1.7976931348623157e308, 2.0 ** -149, float("nan"), float("inf"), -float("inf"), 0.1, 1 / 3, 2.0 ** 53 + 2]
     bad = [(v, hp.repr_double(float(v)), repr(float(v))) for v in vals if hp.repr_double(float(v)) != repr(float(v))]
     assert not bad, bad[:5]
+
+
+def test_hostpack_decided_lists(hp):
+    """the reject / finish lists of a batch: (channel, read.number if the read HAS the attribute else read.id) per decision
+    code, in batch order (riser/control.py:85-90,137-143) - against the Python loop it replaces"""
+    from riser_amd.control import SequencerControl
+    rng = np.random.default_rng(8)
+    reads = []
+    for i in range(300):
+        r = FakeRead(f"id-{i}", np.zeros(4, dtype=np.int16), number=(i if i % 5 else None))    # None: no `.number` (minknow-api >= v6)
+        if i % 7 == 0:
+            r.number = None                    # the attribute exists and is None: the reference still takes it
+        reads.append(r)
+    sel = np.sort(rng.choice(300, size=180, replace=False)).astype(np.int64)
+    chan = rng.integers(1, 513, size=180).astype(np.int64)
+    dec = rng.integers(0, 4, size=180).astype(np.uint8)
+    got = hp.decided(reads, sel, chan, dec, (2, 1, 3))
+    key = SequencerControl._client_key
+    for lst, code in zip(got, (2, 1, 3)):
+        assert lst == [(int(chan[k]), key(reads[int(sel[k])])) for k in np.flatnonzero(dec == code)]
+    assert hp.decided(reads, sel[:0], chan[:0], dec[:0], (2,)) == ([],)
+    with pytest.raises(ValueError):
+        hp.decided(reads, np.array([999], dtype=np.int64), chan[:1], np.array([2], dtype=np.uint8), (2,))

@@ -27,6 +27,8 @@ def many():                                                       # the persiste
     for _ in range(6): assert hp.gather(big, np.zeros(200, dtype=np.int64), o2) == o2.size
     assert np.array_equal(o2[:40000], np.frombuffer(big[0].raw_data, dtype=np.int16))
 ts = [threading.Thread(target=many) for _ in range(3)]; [t.start() for t in ts]; many(); [t.join() for t in ts]
+dl = hp.decided(reads, np.arange(len(reads), dtype=np.int64), np.arange(len(reads), dtype=np.int64), (np.arange(len(reads)) % 4).astype(np.uint8), (2, 1, 3))
+assert sum(map(len, dl)) == sum(1 for i in range(len(reads)) if i % 4) and dl[0][0] == (2, "id-2")
 assert hp.repr_double(0.1) == repr(0.1) and hp.repr_double(5e-324) == "5e-324" and hp.repr_double(float("nan")) == "nan"
 ids = np.empty(len(reads), dtype=object); ids[:] = hp.attrs(reads, "id")
 o = np.zeros(len(reads), dtype=np.int64)
