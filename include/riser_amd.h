@@ -329,6 +329,17 @@ RS_API int rs_seqnet_forward(rs_seqnet* m, const float* d_x /* fp32 [B, L] */, i
  * tolerance.  The head and unfused ops keep fp32.  RS_ERR_ARG for any other dtype, or for a program without a fused residual block.
  */
 RS_API int rs_seqnet_set_mode(rs_seqnet* m, int dtype /* rs_dtype */);
+/*
+ * ABI 2.4: RAGGED batches - the reads of a ReadUntil batch have their own lengths (riser/control.py:36-60: anything from the
+ * minimum to the kit's maximum), and rs_seqnet_forward takes one length per call.  Here read b is d_x[b * ld .. b * ld + d_len[b]):
+ * the rows of every read after every op are computed on the device from d_len, every kernel masks by them, the buffers keep the
+ * row pitches of an ld-sample read (rs_seqnet_workspace_bytes(m, B, ld)).  A read's probabilities are those of a uniform call on
+ * it alone, bit for bit.  Only for programs whose ops all run inside fused launches (stem + residual blocks: what
+ * riser/nets/resnet.py builds): rs_seqnet_ragged_ok(m) == 1; otherwise RS_ERR_ARG (group the reads by length instead).
+ */
+RS_API int rs_seqnet_ragged_ok(const rs_seqnet* m);
+RS_API int rs_seqnet_forward_ragged(rs_seqnet* m, const float* d_x /* fp32 [B, ld] */, const int32_t* d_len, int B, int ld, void* d_ws,
+                             size_t ws_bytes, float* d_probs, float* d_logits, void* stream);
 
 /*
  * Test hook: every following forward pass of `m` also copies the output buffer of conv layer `layer`

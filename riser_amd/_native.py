@@ -23,7 +23,7 @@ SYMBOLS = (
     "rs_workspace_bytes", "rs_max_batch", "rs_block_samples", "rs_normalise", "rs_normalise_float", "rs_forward", "rs_padded_length", "rs_classify",
     "rs_classify_ensemble", "rs_ensemble_workspace_bytes", "rs_autotune", "rs_decide", "rs_polya_end", "rs_copy_segments", "rs_model_layer_info", "rs_profile_enable", "rs_profile_read",
     "rs_debug_capture_layer", "rs_polya_end_resume",
-    "rs_seqnet_create", "rs_seqnet_destroy", "rs_seqnet_workspace_bytes", "rs_seqnet_forward", "rs_seqnet_set_mode",
+    "rs_seqnet_create", "rs_seqnet_destroy", "rs_seqnet_workspace_bytes", "rs_seqnet_forward", "rs_seqnet_set_mode", "rs_seqnet_ragged_ok", "rs_seqnet_forward_ragged",
 )
 
 
@@ -109,6 +109,10 @@ def lib():
     L.rs_seqnet_forward.argtypes = [vp, vp, i32, i32, vp, sz, vp, vp, vp]
     L.rs_seqnet_set_mode.restype = i32
     L.rs_seqnet_set_mode.argtypes = [vp, i32]
+    L.rs_seqnet_ragged_ok.restype = i32
+    L.rs_seqnet_ragged_ok.argtypes = [vp]
+    L.rs_seqnet_forward_ragged.restype = i32
+    L.rs_seqnet_forward_ragged.argtypes = [vp, vp, vp, i32, i32, vp, sz, vp, vp, vp]
     L.rs_polya_end_resume.restype = i32
     L.rs_polya_end_resume.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     L.rs_debug_capture_layer.restype = i32

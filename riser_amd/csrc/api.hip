@@ -391,7 +391,7 @@ extern "C" {
 
 const char* rs_last_error(void) { return g_err; }
 
-int rs_version(void) { return (2 << 16) | 3; }
+int rs_version(void) { return (2 << 16) | 4; }
 
 int rs_device_count(void) {
     int n = 0;

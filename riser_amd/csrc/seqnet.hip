@@ -250,7 +250,9 @@ template <int NT>
 __global__ __launch_bounds__(256) void seq_stem_pool_kernel(const float* __restrict__ x, unsigned x_bytes,
                                                             const float* __restrict__ wq, const float* __restrict__ bias,
                                                             float* __restrict__ y, int B, int L, int T_conv, int TP,
-                                                            int c_out, int K, int stride, int pad, int n_tiles) {
+                                                            int c_out, int K, int stride, int pad, int n_tiles,
+        const int32_t* __restrict__ rlen /* ragged batches: samples of read b (null: L) */,
+        const int32_t* __restrict__ rtconv /* ... and its conv positions (null: T_conv) */) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
     constexpr int NP = 16 * NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void seq_stem_pool_kernel(const float* __restr
                 ++b;
             }
         };
-        int off0[2], base[2];
+        int off0[2], base[2], Lr[2];
         bool ok[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -287,14 +289,18 @@ __global__ __launch_bounds__(256) void seq_stem_pool_kernel(const float* __restr
             int b, j;
             locate(g, b, j);
             const int tc = j - 1;
-            ok[m] = g < rows && tc >= 0 && tc < T_conv;
+            const int bq = min(b, B - 1);
+            Lr[m] = rlen ? rlen[bq] : L;
+            ok[m] = g < rows && tc >= 0 && tc < (rtconv ? rtconv[bq] : T_conv);
             off0[m] = tc * stride - pad;
             base[m] = b * L;
         }
         // a wave whose 32 rows and all their samples lie inside one read takes the loads without bounds tests
         const int jw = row0 - tb0 * rpr;                        // first row of the wave in read tb0 (or beyond: then not interior)
-        const bool interior = row0 + 32 <= rows && jw >= 1 && jw + 32 <= rpr - 2 && (jw - 1) * stride - pad >= 0 &&
-                              (jw + 31) * stride - pad + K16 + 3 < L;
+        const int bw = min(tb0, B - 1);                         // (wave-uniform: scalar loads)
+        const int Lw = rlen ? as_const_len(rlen)[bw] : L, Tw = rtconv ? as_const_len(rtconv)[bw] : T_conv;
+        const bool interior = row0 + 32 <= rows && jw >= 1 && jw + 32 <= rpr - 2 && jw + 31 <= Tw && (jw - 1) * stride - pad >= 0 &&
+                              (jw + 31) * stride - pad + K16 + 3 < Lw;
         f32x4 acc[2][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -306,12 +312,12 @@ __global__ __launch_bounds__(256) void seq_stem_pool_kernel(const float* __restr
             for (int m = 0; m < 2; ++m) {
                 const int o = off0[m] + kidx;
                 // (elements at K index >= K meet zero weights: inside the read they need no mask)
-                if (interior || (ok[m] && o >= 0 && o + 3 < L)) {
+                if (interior || (ok[m] && o >= 0 && o + 3 < Lr[m])) {
                     av[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(base[m] + o) * 4u, 0, 0));
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        av[m][i] = (ok[m] && kidx + i < K && o + i >= 0 && o + i < L) ? x[(int64_t)base[m] + o + i] : 0.0f;
+                        av[m][i] = (ok[m] && kidx + i < K && o + i >= 0 && o + i < Lr[m]) ? x[(int64_t)base[m] + o + i] : 0.0f;
                 }
             }
         };
@@ -342,7 +348,8 @@ __global__ __launch_bounds__(256) void seq_stem_pool_kernel(const float* __restr
                 int b, j0;
                 locate(g, b, j0);
                 const int ta = j0 - 1, tb = j0;                        // the window's conv positions (MaxPool pads with -inf)
-                const bool va = ta >= 0 && ta < T_conv, vb = tb < T_conv;
+                const int tcb = rtconv ? rtconv[min(b, B - 1)] : T_conv;
+                const bool va = ta >= 0 && ta < tcb, vb = tb < tcb;
                 float* yr = y + ((int64_t)b * TP + (j0 >> 1)) * c_out;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
@@ -370,6 +377,10 @@ struct BlockArgs {
     int B, T_in, T_out, c_in, c_out, Cp, stride;
     int K1, K2a, Ksc;         // 3 c_in; 3 Cp; c_in if the shortcut is a conv, else 0 (identity: c_in == c_out, stride 1)
     int tiles_per_read, n_tiles;
+    // RAGGED batches (rs_seqnet_forward_ragged): rows of read b valid in x / in y, or null = T_in / T_out for every read.  The
+    // buffers keep the uniform row pitches T_in / T_out (those of the longest read); a read's tiles behind its own end are skipped
+    const int32_t* tin;
+    const int32_t* tout;
 };
 
 template <int NT, int MTW, int WAVES>
@@ -392,7 +403,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
     for (int i = threadIdx.x; i < (R + 4) * a.Cp; i += kThr) tl[i] = 0.0f;
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-    const int lim = a.T_in * a.c_in;
+    const int lim_max = a.T_in * a.c_in;              // row pitch of a read in x (the longest read's)
     float b1c[NT], b2c[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -406,7 +417,9 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
         constexpr bool EDGE = decltype(EDGE_)::value;
         const int b = tile / a.tiles_per_read;
         const int to0 = (tile - b * a.tiles_per_read) * TO;
-        const int64_t xbase = (int64_t)b * lim;
+        const int64_t xbase = (int64_t)b * lim_max;
+        const int T_in = a.tin ? as_const_len(a.tin)[b] : a.T_in, T_out = a.tout ? as_const_len(a.tout)[b] : a.T_out;
+        const int lim = T_in * a.c_in;                     // elements of read b that hold data
         // ---- phase 1: the intermediate rows j = 0 .. R-1 (positions to0 - 1 + j) = relu(conv3(x; stride) + b1) -> LDS ----
         {
             int off0[MTW];
@@ -414,7 +427,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 const int p = to0 - 1 + (wave * MTW + m) * 16 + r;
-                ok[m] = !EDGE || (p >= 0 && p < a.T_out);
+                ok[m] = !EDGE || (p >= 0 && p < T_out);
                 off0[m] = (p * a.stride - 1) * a.c_in;
             }
             f32x4 acc[MTW][NT];
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
                 for (int e = 0; e < 4; ++e) {
                     const int jrow = (wave * MTW + m) * 16 + 4 * kq + e;
                     const int p = to0 - 1 + jrow;
-                    const bool okp = !EDGE || (p >= 0 && p < a.T_out);
+                    const bool okp = !EDGE || (p >= 0 && p < T_out);
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         const int col = 16 * j + r;
@@ -504,7 +517,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
 #pragma unroll
                 for (int m = 0; m < MTW; ++m) {
                     const int i = (wave * MTW + m) * 16 + r;
-                    ok[m] = i < TO && (!EDGE || to0 + i < a.T_out);
+                    ok[m] = i < TO && (!EDGE || to0 + i < T_out);
                     off0[m] = (to0 + i) * a.stride * a.c_in;
                 }
                 auto load_sc = [&](int k0, f32x4 (&av)[MTW]) {
@@ -546,7 +559,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
             // the tile's padding channels and rows is finite fp32 that meets zero weights), offset by `mis` floats so that image
             // and span share their 16-byte phase; an identity shortcut's residual is the same span of x, added in the copy-out.
             __syncthreads();
-            const int n_out = min(TO, a.T_out - to0);
+            const int n_out = min(TO, T_out - to0);
             const int64_t s0 = ((int64_t)b * a.T_out + to0) * a.c_out;
             const int mis = (int)(s0 & 3);
 #pragma unroll
@@ -592,7 +605,11 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int tt = tile % a.tiles_per_read;
         const int to0 = tt * TO;
-        const bool interior = to0 >= 2 && to0 + TO <= a.T_out && (to0 + R - 2) * a.stride + 6 <= a.T_in;
+        const int bb = tile / a.tiles_per_read;
+        const int T_in = a.tin ? as_const_len(a.tin)[bb] : a.T_in, T_out = a.tout ? as_const_len(a.tout)[bb] : a.T_out;
+        if (to0 >= T_out) continue;                            // ragged batch: this read ended before the tile
+        const int lim = T_in * a.c_in;
+        const bool interior = to0 >= 2 && to0 + TO <= T_out && (to0 + R - 2) * a.stride + 6 <= T_in;
         if (interior)
             do_tile(tile, std::false_type{});
         else
@@ -629,6 +646,8 @@ struct BlockX3Args {
     int K1, Ksc;               // 3 c_in; c_in if the shortcut is a conv, else 0
     int S1, S2a, Ssc;          // k-steps of 32: ceil(3 c_in / 32), ceil(3 Cp / 32), ceil(Ksc / 32)
     int tiles_per_read, n_tiles;
+    const int32_t* tin;        // ragged batches: see BlockArgs
+    const int32_t* tout;
 };
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -681,7 +700,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_x3_kernel(const Bl
     for (int i = threadIdx.x; i < 2 * (R + 4) * a.Cp / 2; i += kThr) reinterpret_cast<unsigned*>(tlh)[i] = 0u;
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-    const int lim = a.T_in * a.c_in;
+    const int lim_max = a.T_in * a.c_in;              // row pitch of a read in x (the longest read's)
     float b1c[NT], b2c[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -707,7 +726,9 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_x3_kernel(const Bl
         constexpr bool EDGE = decltype(EDGE_)::value;
         const int b = tile / a.tiles_per_read;
         const int to0 = (tile - b * a.tiles_per_read) * TO;
-        const int64_t xbase = (int64_t)b * lim;
+        const int64_t xbase = (int64_t)b * lim_max;
+        const int T_in = a.tin ? as_const_len(a.tin)[b] : a.T_in, T_out = a.tout ? as_const_len(a.tout)[b] : a.T_out;
+        const int lim = T_in * a.c_in;                     // elements of read b that hold data
         // eight consecutive floats of x from element offset o of read b (zeros outside the read; inside it every element is
         // real data - K indices behind the conv's own meet zero weights)
         auto load8 = [&](bool ok, int o, int klim, int kidx, f32x4& lo4, f32x4& hi4) {
@@ -729,7 +750,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_x3_kernel(const Bl
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 const int p = to0 - 1 + (wave * MTW + m) * 16 + r;
-                ok[m] = !EDGE || (p >= 0 && p < a.T_out);
+                ok[m] = !EDGE || (p >= 0 && p < T_out);
                 off0[m] = (p * a.stride - 1) * a.c_in;
             }
             f32x4 acc[MTW][NT];
@@ -771,7 +792,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_x3_kernel(const Bl
                 const int jrow0 = (wave * MTW + m) * 16 + 4 * kq;
                 bool okp[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) okp[e] = !EDGE || (to0 - 1 + jrow0 + e >= 0 && to0 - 1 + jrow0 + e < a.T_out);
+                for (int e = 0; e < 4; ++e) okp[e] = !EDGE || (to0 - 1 + jrow0 + e >= 0 && to0 - 1 + jrow0 + e < T_out);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int col = 16 * j + r;
@@ -825,7 +846,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_x3_kernel(const Bl
 #pragma unroll
                 for (int m = 0; m < MTW; ++m) {
                     const int i = (wave * MTW + m) * 16 + r;
-                    ok[m] = i < TO && (!EDGE || to0 + i < a.T_out);
+                    ok[m] = i < TO && (!EDGE || to0 + i < T_out);
                     off0[m] = (to0 + i) * a.stride * a.c_in;
                 }
                 for (int s = 0; s < a.Ssc; ++s) {
@@ -858,7 +879,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_x3_kernel(const Bl
             // residual is the same span of x (c_in == c_out, stride 1): it is added in the copy-out, from coalesced loads.
             __syncthreads();
             float* img = reinterpret_cast<float*>(tlh);
-            const int n_out = min(TO, a.T_out - to0);                                  // valid output rows of this tile
+            const int n_out = min(TO, T_out - to0);                                  // valid output rows of this tile
             const int64_t s0 = ((int64_t)b * a.T_out + to0) * a.c_out;                 // first float of the span in y
             const int mis = (int)(s0 & 3);
 #pragma unroll
@@ -922,9 +943,13 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_x3_kernel(const Bl
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int tt = tile % a.tiles_per_read;
         const int to0 = tt * TO;
+        const int bb = tile / a.tiles_per_read;
+        const int T_in = a.tin ? as_const_len(a.tin)[bb] : a.T_in, T_out = a.tout ? as_const_len(a.tout)[bb] : a.T_out;
+        if (to0 >= T_out) continue;                            // ragged batch: this read ended before the tile
+        const int lim = T_in * a.c_in;
         // interior: every intermediate row, output and x access (the k-steps' over-read of up to 31 elements included) lies
         // inside the read
-        const bool interior = to0 >= 2 && to0 + TO <= a.T_out && ((to0 + R - 2) * a.stride + 2) * a.c_in + 32 * (a.S1 + 1) <= lim;
+        const bool interior = to0 >= 2 && to0 + TO <= T_out && ((to0 + R - 2) * a.stride + 2) * a.c_in + 32 * (a.S1 + 1) <= lim;
         if (interior)
             do_tile(tile, std::false_type{});
         else
@@ -943,7 +968,9 @@ __global__ __launch_bounds__(256) void seq_stem_pool_x3_kernel(const float* __re
                                                                const unsigned short* __restrict__ wq /* planes [hi | lo] [S][4][16 NT][8] */,
                                                                const float* __restrict__ bias, float* __restrict__ y, int B, int L,
                                                                int T_conv, int TP, int c_out, int K, int S, int stride, int pad,
-                                                               int n_tiles) {
+                                                               int n_tiles,
+        const int32_t* __restrict__ rlen /* ragged batches: samples of read b (null: L) */,
+        const int32_t* __restrict__ rtconv /* ... and its conv positions (null: T_conv) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     constexpr int NP = 16 * NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -971,7 +998,7 @@ __global__ __launch_bounds__(256) void seq_stem_pool_x3_kernel(const float* __re
                 ++b;
             }
         };
-        int off0[2], base[2];
+        int off0[2], base[2], Lr[2];
         bool ok[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -979,13 +1006,17 @@ __global__ __launch_bounds__(256) void seq_stem_pool_x3_kernel(const float* __re
             int b, j;
             locate(g, b, j);
             const int tc = j - 1;
-            ok[m] = g < rows && tc >= 0 && tc < T_conv;
+            const int bq = min(b, B - 1);
+            Lr[m] = rlen ? rlen[bq] : L;
+            ok[m] = g < rows && tc >= 0 && tc < (rtconv ? rtconv[bq] : T_conv);
             off0[m] = tc * stride - pad;
             base[m] = b * L;
         }
         const int jw = row0 - tb0 * rpr;
-        const bool interior = row0 + 32 <= rows && jw >= 1 && jw + 32 <= rpr - 2 && (jw - 1) * stride - pad >= 0 &&
-                              (jw + 31) * stride - pad + 32 * S + 8 < L;
+        const int bw = min(tb0, B - 1);                         // (wave-uniform: scalar loads)
+        const int Lw = rlen ? as_const_len(rlen)[bw] : L, Tw = rtconv ? as_const_len(rtconv)[bw] : T_conv;
+        const bool interior = row0 + 32 <= rows && jw >= 1 && jw + 32 <= rpr - 2 && jw + 31 <= Tw && (jw - 1) * stride - pad >= 0 &&
+                              (jw + 31) * stride - pad + 32 * S + 8 < Lw;
         f32x4 acc[2][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -1005,14 +1036,14 @@ __global__ __launch_bounds__(256) void seq_stem_pool_x3_kernel(const float* __re
                 const int o = off0[m] + kidx;
                 f32x4 xa, xb;
                 // (samples at K index >= K meet zero weights: inside the read they need no mask)
-                if (interior || (ok[m] && o >= 0 && o + 7 < L)) {
+                if (interior || (ok[m] && o >= 0 && o + 7 < Lr[m])) {
                     xa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(base[m] + o) * 4u, 0, 0));
                     xb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(base[m] + o) * 4u + 16u, 0, 0));
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        xa[i] = (ok[m] && kidx + i < K && o + i >= 0 && o + i < L) ? x[(int64_t)base[m] + o + i] : 0.0f;
-                        xb[i] = (ok[m] && kidx + 4 + i < K && o + 4 + i >= 0 && o + 4 + i < L) ? x[(int64_t)base[m] + o + 4 + i] : 0.0f;
+                        xa[i] = (ok[m] && kidx + i < K && o + i >= 0 && o + i < Lr[m]) ? x[(int64_t)base[m] + o + i] : 0.0f;
+                        xb[i] = (ok[m] && kidx + 4 + i < K && o + 4 + i >= 0 && o + 4 + i < Lr[m]) ? x[(int64_t)base[m] + o + 4 + i] : 0.0f;
                     }
                 }
                 u32x4 ah, al;
@@ -1031,7 +1062,8 @@ __global__ __launch_bounds__(256) void seq_stem_pool_x3_kernel(const float* __re
                 int b, j0;
                 locate(g, b, j0);
                 const int ta = j0 - 1, tb = j0;                        // the window's conv positions (MaxPool pads with -inf)
-                const bool va = ta >= 0 && ta < T_conv, vb = tb < T_conv;
+                const int tcb = rtconv ? rtconv[min(b, B - 1)] : T_conv;
+                const bool va = ta >= 0 && ta < tcb, vb = tb < tcb;
                 float* ir = img + (8 * m + 2 * kq + (e >> 1)) * c_out;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
@@ -1075,6 +1107,8 @@ struct BneckArgs {
     int B, T_in, T_out, c_in, c_mid, c_out, Cmp, stride;
     int Ksc;                  // c_in if the shortcut is a conv, else 0
     int R2, tiles_per_read, n_tiles;
+    const int32_t* tin;       // ragged batches: rows of read b valid in x / in y (null: T_in / T_out); see BlockArgs
+    const int32_t* tout;
 };
 
 template <int NTM, int NTO>
@@ -1096,7 +1130,8 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_kernel(const BneckAr
     for (int i = threadIdx.x; i < 2 * (RA + 4) * a.Cmp; i += 256) t1[i] = 0.0f;
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-    const int lim = a.T_in * a.c_in;
+    const int lim_max = a.T_in * a.c_in;              // row pitch of a read in x (the longest read's)
+    int lim = lim_max, T_in = a.T_in, T_out = a.T_out;   // of the read a tile belongs to (set per tile)
     float b1c[NTM], b2c[NTM], b3c[NTO];
 #pragma unroll
     for (int j = 0; j < NTM; ++j) {
@@ -1121,7 +1156,13 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_kernel(const BneckAr
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int b = tile / a.tiles_per_read;
         const int to0 = (tile - b * a.tiles_per_read) * a.R2;
-        const int64_t xbase = (int64_t)b * lim;
+        const int64_t xbase = (int64_t)b * lim_max;
+        if (a.tin) {
+            T_in = as_const_len(a.tin)[b];
+            T_out = as_const_len(a.tout)[b];
+            lim = T_in * a.c_in;
+        }
+        if (to0 >= T_out) continue;                            // ragged batch: this read ended before the tile
         // ---- phase A: t1 rows j = 0 .. RA-1 <-> input positions q0 + j ------------------------------------------------
         {
             const int q0 = to0 * a.stride - 1;
@@ -1131,7 +1172,7 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_kernel(const BneckAr
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int q = q0 + (wave * 2 + m) * 16 + r;
-                ok[m] = q >= 0 && q < a.T_in;
+                ok[m] = q >= 0 && q < T_in;
                 off0[m] = q * a.c_in;
 #pragma unroll
                 for (int j = 0; j < NTM; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1156,7 +1197,7 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_kernel(const BneckAr
                 for (int e = 0; e < 4; ++e) {
                     const int jrow = (wave * 2 + m) * 16 + 4 * kq + e;
                     const int q = q0 + jrow;
-                    const bool okq = q >= 0 && q < a.T_in;
+                    const bool okq = q >= 0 && q < T_in;
 #pragma unroll
                     for (int j = 0; j < NTM; ++j) {
                         const int col = 16 * j + r;
@@ -1214,7 +1255,7 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_kernel(const BneckAr
             }
             if (a.Ksc) {
                 const int i_r = mt * 16 + r;
-                const bool okr = i_r < a.R2 && to0 + i_r < a.T_out;
+                const bool okr = i_r < a.R2 && to0 + i_r < T_out;
                 const int off0 = (to0 + i_r) * a.stride * a.c_in;
                 for (int k0 = 0; k0 < Ksc16; k0 += 16) {
                     const f32x4 av = xload(xbase, okr, off0 + k0 + 4 * kq, k0 + 4 * kq, a.Ksc);
@@ -1230,7 +1271,7 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_kernel(const BneckAr
             for (int e = 0; e < 4; ++e) {
                 const int i = mt * 16 + 4 * kq + e;
                 const int pos = to0 + i;
-                if (i >= a.R2 || pos >= a.T_out) continue;
+                if (i >= a.R2 || pos >= T_out) continue;
                 const int64_t orow = ((int64_t)b * a.T_out + pos) * a.c_out;
 #pragma unroll
                 for (int j = 0; j < NTO; ++j) {
@@ -1260,6 +1301,8 @@ struct BneckX3Args {
     int B, T_in, T_out, c_in, c_mid, c_out, Cmp, stride;
     int Ksc, S1, S2, S3, Ssc;
     int R2, tiles_per_read, n_tiles;
+    const int32_t* tin;       // ragged batches: see BlockArgs
+    const int32_t* tout;
 };
 
 template <int NTM, int NTO>
@@ -1283,7 +1326,8 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_x3_kernel(const Bnec
     for (int i = threadIdx.x; i < 4 * tplane / 2; i += 256) reinterpret_cast<unsigned*>(t1h)[i] = 0u;
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-    const int lim = a.T_in * a.c_in;
+    const int lim_max = a.T_in * a.c_in;              // row pitch of a read in x (the longest read's)
+    int lim = lim_max, T_in = a.T_in, T_out = a.T_out;   // of the read a tile belongs to (set per tile)
     float b1c[NTM], b2c[NTM], b3c[NTO];
 #pragma unroll
     for (int j = 0; j < NTM; ++j) {
@@ -1325,7 +1369,13 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_x3_kernel(const Bnec
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int b = tile / a.tiles_per_read;
         const int to0 = (tile - b * a.tiles_per_read) * a.R2;
-        const int64_t xbase = (int64_t)b * lim;
+        const int64_t xbase = (int64_t)b * lim_max;
+        if (a.tin) {
+            T_in = as_const_len(a.tin)[b];
+            T_out = as_const_len(a.tout)[b];
+            lim = T_in * a.c_in;
+        }
+        if (to0 >= T_out) continue;                            // ragged batch: this read ended before the tile
         // ---- phase A: t1 rows j = 0 .. RA-1 <-> input positions q0 + j ------------------------------------------------
         {
             const int q0 = to0 * a.stride - 1;
@@ -1335,7 +1385,7 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_x3_kernel(const Bnec
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int q = q0 + (wave * 2 + m) * 16 + r;
-                ok[m] = q >= 0 && q < a.T_in;
+                ok[m] = q >= 0 && q < T_in;
                 off0[m] = q * a.c_in;
 #pragma unroll
                 for (int j = 0; j < NTM; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1360,7 +1410,7 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_x3_kernel(const Bnec
                 for (int e = 0; e < 4; ++e) {
                     const int jrow = (wave * 2 + m) * 16 + 4 * kq + e;
                     const int q = q0 + jrow;
-                    const bool okq = q >= 0 && q < a.T_in;
+                    const bool okq = q >= 0 && q < T_in;
 #pragma unroll
                     for (int j = 0; j < NTM; ++j) {
                         const int col = 16 * j + r;
@@ -1420,7 +1470,7 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_x3_kernel(const Bnec
             }
             if (a.Ksc) {
                 const int i_r = mt * 16 + r;
-                const bool okr = i_r < a.R2 && to0 + i_r < a.T_out;
+                const bool okr = i_r < a.R2 && to0 + i_r < T_out;
                 const int off0 = (to0 + i_r) * a.stride * a.c_in;
                 for (int s = 0; s < a.Ssc; ++s) {
                     f32x4 xa, xb;
@@ -1439,7 +1489,7 @@ __global__ __launch_bounds__(256) void seq_bottleneck_block_x3_kernel(const Bnec
             for (int e = 0; e < 4; ++e) {
                 const int i = mt * 16 + 4 * kq + e;
                 const int pos = to0 + i;
-                if (i >= a.R2 || pos >= a.T_out) continue;
+                if (i >= a.R2 || pos >= T_out) continue;
                 const int64_t orow = ((int64_t)b * a.T_out + pos) * a.c_out;
 #pragma unroll
                 for (int j = 0; j < NTO; ++j) {
@@ -1473,18 +1523,20 @@ __global__ __launch_bounds__(256) void seq_maxpool_kernel(const float* __restric
 // GAP over T rows -> FC(c, 2) -> softmax; one 256-thread workgroup per read: wave w sums the rows t = w (mod 4) of
 // each channel (coalesced 256-byte row segments, four rows in flight per channel group), LDS combines the four partial
 // sums in a fixed order, wave 0 finishes
-__global__ __launch_bounds__(256) void seq_head_kernel(const float* __restrict__ x, int T, int c,
+__global__ __launch_bounds__(256) void seq_head_kernel(const float* __restrict__ x, int T_pitch, int c,
                                                        const float* __restrict__ fcw, const float* __restrict__ fcb,
-                                                       float* __restrict__ probs, float* __restrict__ logits) {
+                                                       float* __restrict__ probs, float* __restrict__ logits,
+                                                       const int32_t* __restrict__ rt /* ragged batches: rows of read b (null: T_pitch) */) {
     __shared__ float part[4][64];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = rt ? as_const_len(rt)[b] : T_pitch;
     float a0 = 0.f, a1 = 0.f;
     for (int c0 = 0; c0 < c; c0 += 64) {
         const int ch = c0 + lane;
         float s = 0.f;
         if (ch < c) {
             // eight rows in flight per lane (the loop is a chain of dependent-looking loads otherwise: T / 4 round trips)
-            const float* col = x + (int64_t)b * T * c + ch;
+            const float* col = x + (int64_t)b * T_pitch * c + ch;
             int t = wave;
             for (; t + 28 < T; t += 32) {
                 float v[8];
@@ -1520,6 +1572,29 @@ __global__ __launch_bounds__(256) void seq_head_kernel(const float* __restrict__
             logits[2 * b] = l0;
             logits[2 * b + 1] = l1;
         }
+    }
+}
+
+// Ragged batches (rs_seqnet_forward_ragged): table[k + 1][b] = rows of read b after op k, table[0][b] = its samples.  One thread per
+// read walks the program's ops (a conv: (T + 2 pad - k) / stride + 1, or 0 when the kernel does not fit; MaxPool1d(2, 2, pad)).
+struct LenRecipe {
+    int n_ops;
+    signed char kind[64], pad[64];
+    short k[64], stride[64], prod[64];        // prod: the op that wrote this op's input buffer, -1 = the program's input
+};
+__global__ __launch_bounds__(256) void seq_lengths_kernel(const int32_t* __restrict__ len, int B, const LenRecipe rc,
+                                                          int32_t* __restrict__ table) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    table[b] = len[b];
+    for (int i = 0; i < rc.n_ops; ++i) {
+        const int t = table[(size_t)(rc.prod[i] + 1) * B + b];
+        int o;
+        if (rc.kind[i] == 0)
+            o = t + 2 * rc.pad[i] < rc.k[i] ? 0 : (t + 2 * rc.pad[i] - rc.k[i]) / rc.stride[i] + 1;
+        else
+            o = t <= 0 ? 0 : (rc.pad[i] ? t / 2 + 1 : t / 2);
+        table[(size_t)(i + 1) * B + b] = o;
     }
 }
 
@@ -2059,13 +2134,49 @@ int rs_seqnet_set_mode(rs_seqnet* m, int dtype) {
 
 size_t rs_seqnet_workspace_bytes(const rs_seqnet* m, int B, int L) {
     if (!m || B < 1 || L < 1) return 0;
-    return buffer_bytes(m, B, L) * (size_t)(m->n_buffers - 1);
+    const size_t per = buffer_bytes(m, B, L);
+    if (!per) return 0;
+    // the activation buffers, then the per-read length table of a ragged forward ((ops + 1) x B)
+    return per * (size_t)(m->n_buffers - 1) + ((m->ops.size() + 1) * (size_t)B * 4 + 255) / 256 * 256;
 }
+
+static int seqnet_forward_impl(rs_seqnet* m, const float* d_x, const int32_t* d_len, int B, int L, void* d_ws, size_t ws_bytes,
+                               float* d_probs, float* d_logits, void* stream);
 
 int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, size_t ws_bytes, float* d_probs,
                       float* d_logits, void* stream) {
+    return seqnet_forward_impl(m, d_x, nullptr, B, L, d_ws, ws_bytes, d_probs, d_logits, stream);
+}
+
+int rs_seqnet_forward_ragged(rs_seqnet* m, const float* d_x, const int32_t* d_len, int B, int ld, void* d_ws, size_t ws_bytes,
+                             float* d_probs, float* d_logits, void* stream) {
+    if (!d_len) {
+        set_error("rs_seqnet_forward_ragged: null lengths");
+        return RS_ERR_ARG;
+    }
+    return seqnet_forward_impl(m, d_x, d_len, B, ld, d_ws, ws_bytes, d_probs, d_logits, stream);
+}
+
+// 1 when every op of the program runs inside a fused launch (stem, residual blocks): what a ragged forward needs
+int rs_seqnet_ragged_ok(const rs_seqnet* m) {
+    if (!m) return 0;
+    for (size_t k = 0; k < m->ops.size(); ++k) {
+        const OpDev& o = m->ops[k];
+        if (o.fuse < 1 || o.fuse > 3) return 0;
+        k += o.fuse_skip;
+    }
+    return m->ops.size() <= 63 ? 1 : 0;
+}
+
+static int seqnet_forward_impl(rs_seqnet* m, const float* d_x, const int32_t* d_len, int B, int L, void* d_ws, size_t ws_bytes,
+                               float* d_probs, float* d_logits, void* stream) {
     if (!m || !d_x || !d_ws || !d_probs || B < 1 || L < 1) {
         set_error("rs_seqnet_forward: bad argument");
+        return RS_ERR_ARG;
+    }
+    if (d_len && !rs_seqnet_ragged_ok(m)) {
+        set_error("rs_seqnet_forward_ragged: this program has ops outside its fused launches (stem, residual blocks): group the "
+                  "reads by length and call rs_seqnet_forward");
         return RS_ERR_ARG;
     }
     std::vector<int> T, C;
@@ -2075,7 +2186,7 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
         return RS_ERR_LENGTH;
     }
     const size_t per = buffer_bytes(m, B, L);
-    if (ws_bytes < per * (size_t)(m->n_buffers - 1)) {
+    if (ws_bytes < rs_seqnet_workspace_bytes(m, B, L)) {
         set_error("rs_seqnet_forward: workspace too small");
         return RS_ERR_WORKSPACE;
     }
@@ -2085,7 +2196,30 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
     auto buf = [&](int i) -> float* {
         return i == 0 ? const_cast<float*>(d_x) : reinterpret_cast<float*>(static_cast<char*>(d_ws) + per * (size_t)(i - 1));
     };
-    int last = 0;
+    // ragged batch: the rows of every read after every op, computed on the device from its length (no host copy needed);
+    // L is then the row pitch of d_x and every buffer keeps the pitches of an L-sample read
+    int32_t* table = nullptr;
+    std::vector<int> prod(m->ops.size(), -1);
+    if (d_len) {
+        table = reinterpret_cast<int32_t*>(static_cast<char*>(d_ws) + per * (size_t)(m->n_buffers - 1));
+        LenRecipe rc;
+        memset(&rc, 0, sizeof(rc));
+        rc.n_ops = (int)m->ops.size();
+        for (size_t k = 0; k < m->ops.size(); ++k) {
+            const OpDev& o = m->ops[k];
+            for (size_t j = 0; j < k; ++j)
+                if (m->ops[j].dst == o.src) prod[k] = (int)j;
+            rc.kind[k] = (signed char)o.kind;
+            rc.pad[k] = (signed char)o.pad;
+            rc.k[k] = (short)o.k;
+            rc.stride[k] = (short)(o.stride > 0 ? o.stride : 1);
+            rc.prod[k] = (short)prod[k];
+        }
+        hipLaunchKernelGGL(seq_lengths_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_len, B, rc, table);
+        RS_HIP(hipGetLastError());
+    }
+    auto rows_after = [&](int op) -> const int32_t* { return table ? table + (size_t)(op + 1) * B : nullptr; };   // op = -1: the input
+    int last = 0, last_op = -1;
     for (size_t k = 0; k < m->ops.size(); ++k) {
         const OpDev& o = m->ops[k];
         const OpShape& sh = shp[k];
@@ -2102,9 +2236,11 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                 const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
                 const int grid = std::min(n_tiles, m->num_cu * per_cu);
                 hipLaunchKernelGGL(fx, dim3(grid), dim3(256), lds, st, buf(o.f_src), (unsigned)((int64_t)B * sh.t_in * 4), o.d_x_w1, o.d_b,
-                                   buf(o.f_dst), B, sh.t_in, sh.t_out, ps.t_out, o.c_out, o.k * o.c_in, o.x_s1, o.stride, o.pad, n_tiles);
+                                   buf(o.f_dst), B, sh.t_in, sh.t_out, ps.t_out, o.c_out, o.k * o.c_in, o.x_s1, o.stride, o.pad, n_tiles,
+                                   rows_after(prod[k]), rows_after((int)k));
                 RS_HIP(hipGetLastError());
                 last = o.f_dst;
+                last_op = (int)(k + o.fuse_skip);
                 k += o.fuse_skip;
                 continue;
             }
@@ -2116,9 +2252,11 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1)));
             const int grid = std::min(n_tiles, m->num_cu * per_cu);
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, buf(o.f_src), (unsigned)((int64_t)B * sh.t_in * 4), o.d_wq, o.d_b,
-                               buf(o.f_dst), B, sh.t_in, sh.t_out, ps.t_out, o.c_out, K, o.stride, o.pad, n_tiles);
+                               buf(o.f_dst), B, sh.t_in, sh.t_out, ps.t_out, o.c_out, K, o.stride, o.pad, n_tiles, rows_after(prod[k]),
+                               rows_after((int)k));
             RS_HIP(hipGetLastError());
             last = o.f_dst;
+            last_op = (int)(k + o.fuse_skip);
             k += o.fuse_skip;
             continue;
         }
@@ -2149,6 +2287,8 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                 a.S1 = o.x_s1;
                 a.S2a = o.x_s2a;
                 a.Ssc = o.x_ssc;
+                a.tin = rows_after(prod[k + o.fuse_skip - 1]);
+                a.tout = rows_after((int)(k + o.fuse_skip - 1));
                 const size_t lds_cap = 160 * 1024;
                 auto lds_of = [&](int rows) { return o.x_wbytes + (size_t)(rows + 4) * o.x_cp * 4; };
                 auto waste = [&](int rows) {
@@ -2179,6 +2319,7 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                 hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), f_lds, st, a);
                 RS_HIP(hipGetLastError());
                 last = o.f_dst;
+                last_op = (int)(k + o.fuse_skip);
                 k += o.fuse_skip;
                 continue;
             }
@@ -2202,6 +2343,8 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                 a.K1 = 3 * o.f_cin;
                 a.K2a = 3 * o.f_cp;
                 a.Ksc = o.f_ksc;
+                a.tin = rows_after(prod[k + o.fuse_skip - 1]);
+                a.tout = rows_after((int)(k + o.fuse_skip - 1));
                 // tile = (row tiles per wave, waves): rows R = 16 * mtw * waves of the intermediate, R - 2 outputs.  More rows
                 // per wave = fewer halo rows, weight-fragment reads and set-up instructions per MFMA; candidates must fit the
                 // LDS next to the weights, should leave room for a second workgroup on the CU, and must not waste more than
@@ -2238,6 +2381,7 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                 hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), f_lds, st, a);
                 RS_HIP(hipGetLastError());
                 last = o.f_dst;
+                last_op = (int)(k + o.fuse_skip);
                 k += o.fuse_skip;
                 continue;
             }
@@ -2266,6 +2410,8 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                 a.stride = o.f_stride;
                 a.Ksc = o.f_ksc;
                 a.S1 = o.x_s1; a.S2 = o.x_s2a; a.S3 = o.x_s3; a.Ssc = o.x_ssc;
+                a.tin = rows_after(prod[k + o.fuse_skip - 2]);
+                a.tout = rows_after((int)(k + o.fuse_skip - 1));
                 a.R2 = (128 - 3) / o.f_stride + 1;
                 a.tiles_per_read = (s2.t_out + a.R2 - 1) / a.R2;
                 a.n_tiles = B * a.tiles_per_read;
@@ -2283,6 +2429,7 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                 hipLaunchKernelGGL(fx, dim3(grid), dim3(256), f_lds, st, a);
                 RS_HIP(hipGetLastError());
                 last = o.f_dst;
+                last_op = (int)(k + o.fuse_skip);
                 k += o.fuse_skip;
                 continue;
             }
@@ -2303,6 +2450,8 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                 a.Cmp = o.f_cp;
                 a.stride = o.f_stride;
                 a.Ksc = o.f_ksc;
+                a.tin = rows_after(prod[k + o.fuse_skip - 2]);
+                a.tout = rows_after((int)(k + o.fuse_skip - 1));
                 a.R2 = (128 - 3) / o.f_stride + 1;
                 a.tiles_per_read = (s2.t_out + a.R2 - 1) / a.R2;
                 a.n_tiles = B * a.tiles_per_read;
@@ -2320,6 +2469,7 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
                 hipLaunchKernelGGL(fn, dim3(grid), dim3(256), f_lds, st, a);
                 RS_HIP(hipGetLastError());
                 last = o.f_dst;
+                last_op = (int)(k + o.fuse_skip);
                 k += o.fuse_skip;
                 continue;
             }
@@ -2360,13 +2510,14 @@ int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, 
         }
         RS_HIP(hipGetLastError());
         last = o.dst;
+        last_op = (int)k;
     }
     if (C[last] != m->c_last) {
         set_error("rs_seqnet_forward: last buffer has %d channels, classifier expects %d", C[last], m->c_last);
         return RS_ERR_ARG;
     }
     hipLaunchKernelGGL(seq_head_kernel, dim3(B), dim3(256), 0, st, buf(last), T[last], m->c_last, m->d_fcw, m->d_fcb,
-                       d_probs, d_logits);
+                       d_probs, d_logits, rows_after(last_op));
     RS_HIP(hipGetLastError());
     return RS_OK;
 }

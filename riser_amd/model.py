@@ -211,10 +211,16 @@ class Model:
         if seq is not None:
             seq.close()
 
-    def _seq_forward(self, x: torch.Tensor, lens_host: np.ndarray, return_logits: bool, out):
-        """generic program: one uniform length per launch, so reads are grouped by length"""
+    def _seq_forward(self, x: torch.Tensor, lens_host: np.ndarray, return_logits: bool, out, lens_dev: torch.Tensor = None):
+        """generic program.  A ResNet (stem + residual blocks, all fused) takes the batch as it is - ragged lengths, one call
+        (rs_seqnet_forward_ragged: every kernel masks by the read's own rows); any other program runs one uniform length per
+        launch, so its reads are grouped by length"""
         B = x.shape[0]
         probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
+        if self._seq.ragged_ok and x.is_contiguous():
+            if lens_dev is None:
+                lens_dev = torch.from_numpy(np.ascontiguousarray(lens_host, dtype=np.int32)).to(self.device)
+            return self._seq.forward_ragged(x, lens_dev.to(torch.int32), return_logits, out=probs)
         logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
         for L in np.unique(lens_host):
             idx = torch.from_numpy(np.flatnonzero(lens_host == L)).to(self.device)
@@ -370,7 +376,7 @@ class Model:
         if lmax > ldx:
             raise ValueError("a length exceeds the row pitch")
         if self._seq is not None:
-            return self._seq_forward(x, np.asarray(lens_host), return_logits, out)
+            return self._seq_forward(x, np.asarray(lens_host), return_logits, out, lens_dev)
         mb = self.call_batch(B, lmax)
         if B > mb:                                                     # split: reads are independent
             probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
@@ -410,7 +416,7 @@ class Model:
             nv.check(nv.lib().rs_normalise(sig_dev.data_ptr(), off_dev.data_ptr(), len_dev.data_ptr(), B, lmax,
                                            xn.data_ptr(), lmax, lmax, None, 0, None, _stream_ptr(self.device)),
                      "rs_normalise")
-            return self._seq_forward(xn, np.asarray(lens_host), return_logits, out)
+            return self._seq_forward(xn, np.asarray(lens_host), return_logits, out, len_dev)
         mb = self.call_batch(B, lmax)
         if B > mb:                                                     # split: reads are independent
             probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)

@@ -198,6 +198,28 @@ class SeqNet:
                                        torch.cuda.current_stream(self.device).cuda_stream), "rs_seqnet_forward")
         return (probs, logits) if return_logits else probs
 
+    @property
+    def ragged_ok(self) -> bool:
+        """True when forward_ragged can run this program (all of its ops inside fused launches: a ResNet's stem and blocks)"""
+        return bool(nv.lib().rs_seqnet_ragged_ok(self._h))
+
+    def forward_ragged(self, x: torch.Tensor, lens_dev: torch.Tensor, return_logits: bool = False, out: torch.Tensor = None):
+        """x: fp32 device tensor [B, ld], read b = x[b, :lens_dev[b]] (int32 on the device) -> fp32 [B, 2] on the device; every
+        read's result is that of forward() on it alone."""
+        B, ld = x.shape
+        lib = nv.lib()
+        need = lib.rs_seqnet_workspace_bytes(self._h, B, ld)
+        if need == 0:
+            raise ValueError(f"a row pitch of {ld} samples is too short for this network")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
+        logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
+        nv.check(lib.rs_seqnet_forward_ragged(self._h, x.data_ptr(), lens_dev.data_ptr(), B, ld, self._ws.data_ptr(),
+                                              self._ws.numel(), probs.data_ptr(), logits.data_ptr() if return_logits else None,
+                                              torch.cuda.current_stream(self.device).cuda_stream), "rs_seqnet_forward_ragged")
+        return (probs, logits) if return_logits else probs
+
 
 def build_convnet_program(sd, cnn):
     """(ops, n_buffers, fc_w, fc_b, c_last) of a reference ConvNet (riser/nets/cnn.py:8-65) of ANY depth and odd kernel

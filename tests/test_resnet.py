@@ -272,3 +272,47 @@ def test_resnet_split_precision_over_other_shapes(cfg):
         assert np.abs(p3.cpu().numpy() - ro.softmax(want)).max() < 1e-3, L
     x3.close()
     f32.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block,dtype", [("basic", "f32"), ("basic", "bf16x3"), ("bottleneck", "f32"), ("bottleneck", "bf16x3")])
+def test_resnet_ragged_batch_equals_every_read_alone(block, dtype):
+    """rs_seqnet_forward_ragged: the reads of a ReadUntil batch have their own lengths.  One call over the ragged batch - every
+    kernel masks by the read's own rows, computed on the device from its length - gives every read the bits of a uniform call
+    on it alone: lengths from the program's minimum up, neighbours that differ by one sample, reads far shorter than the row
+    pitch (whole tiles skipped), a read that fills it."""
+    import torch
+    from riser_amd.resnet import ResNetModel
+    dev = torch.device("cuda", 0)
+    cfg = dict(synth.RESNET_BENCH_CFG) if block == "basic" else BOTTLENECK_WIDE_CFG
+    sd = synth.make_resnet_state_dict(7, cfg)
+    if block == "bottleneck" and dtype == "bf16x3":
+        os.environ["RS_SEQ_BNECK_X3"] = "1"
+    try:
+        m = ResNetModel(sd, types.SimpleNamespace(resnet=types.SimpleNamespace(**cfg)), None, "x", device=dev, dtype=dtype)
+    finally:
+        os.environ.pop("RS_SEQ_BNECK_X3", None)
+    net = m._net
+    assert net.ragged_ok
+    lens = [4096, 4097, 4098, 5000, 8615, 8614, 300, 12000, 6024, 16000, 333, 7999]
+    ld = 16000
+    base = _inputs(ld)
+    x = np.zeros((len(lens), ld), dtype=np.float32)
+    for i, n in enumerate(lens):
+        x[i, :n] = base[i % 3][:n]
+        x[i, n:] = np.nan                       # whatever lies behind a read in its row must never be read
+    xd = torch.from_numpy(x).to(dev)
+    ld_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+    probs, logits = net.forward_ragged(xd, ld_dev, return_logits=True)
+    probs, logits = probs.cpu().numpy(), logits.cpu().numpy()
+    assert np.isfinite(logits).all()
+    for i, n in enumerate(lens):
+        p1, l1 = net.forward(xd[i: i + 1, :n].contiguous(), return_logits=True)
+        assert np.array_equal(l1.cpu().numpy()[0], logits[i]), (i, n)
+        assert np.array_equal(p1.cpu().numpy()[0], probs[i]), (i, n)
+    # and again in another order with another pitch: a read's bits do not depend on its batch-mates
+    order = [9, 0, 7, 3]
+    x2 = torch.from_numpy(np.ascontiguousarray(x[order][:, :16000])).to(dev)
+    l2 = net.forward_ragged(x2, torch.tensor([lens[i] for i in order], dtype=torch.int32, device=dev), return_logits=True)[1].cpu().numpy()
+    assert np.array_equal(l2, logits[order])
+    m.close()
