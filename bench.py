@@ -533,6 +533,17 @@ def side_variants(args, device, wl, ref):
                              "(rs_seqnet_set_mode): three v_mfma_f32_16x16x32_bf16 per product, activations fp32 between launches; "
                              "frac over the 2.5 PF bf16 peak - the blocks are bound by the split's VALU work and their epilogues")
         variants["resnet_basic_" + rdt] = entry
+        if rdt == "bf16x3":
+            # a live ReadUntil batch through the ResNet: 357 reads, lengths anywhere in [4096, 8615] (riser/control.py:36-60),
+            # ONE ragged forward (rs_seqnet_forward_ragged) - against one forward per distinct length before round 5
+            rng = np.random.default_rng(3)
+            rl = rng.integers(4096, 8616, size=357).astype(np.int32)
+            xl = xr[:357, :8615].contiguous()
+            rl_dev = torch.from_numpy(rl).to(device)
+            dtl_ = timed(lambda: rm._net.forward_ragged(xl, rl_dev))
+            variants["resnet_live_ragged_357_bf16x3"] = {"reads_per_s": round(357 / dtl_, 1), "ms_per_step": round(dtl_ * 1e3, 4),
+                                                         "batch": 357, "samples_per_step": int(rl.sum()),
+                                                         "distinct_lengths": int(np.unique(rl).size)}
         rm.close()
     return variants
 
@@ -845,6 +856,7 @@ MODE_OF_VARIANT = {            # variants key -> (name in roofline.modes, BASELI
     "live_357x8615_f32": ("live_357x8615_f32", "the live ReadUntil batch shape"),
     "resnet_basic_f32": ("resnet_basic_f32", "riser/nets/resnet.py"),
     "resnet_basic_bf16x3": ("resnet_basic_bf16x3", "riser/nets/resnet.py on the bf16 MFMA"),
+    "resnet_live_ragged_357_bf16x3": ("resnet_live_ragged_357_bf16x3", "a live batch of ragged lengths through the ResNet"),
 }
 
 
@@ -882,6 +894,8 @@ def modes_object(detail, model, wl):
              "ms_per_step": ms}
         if name.startswith("resnet_basic"):
             m["frac"] = e.get("roofline_frac_mfma")
+        elif name.startswith("resnet_live"):
+            m["frac"] = None
         else:
             peak = PEAK_F32_MFMA_TF if name.endswith("f32") else PEAK_BF16_MFMA_TF
             m["frac"] = round(flops(lens_of[name]) / (ms * 1e-3) / 1e12 / peak, 4)
