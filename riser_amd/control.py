@@ -230,16 +230,25 @@ class _RowWriter:
             raise self._err
         self._q.put(job)
 
+    def write_now(self, *job):
+        """the same rows on the caller's thread, behind everything queued before them (row order is batch order)"""
+        if self._err is not None:
+            raise self._err
+        self._q.join()
+        self._sink.write(self._make_rows(*job))
+
     def _run(self):
         while True:
             job = self._q.get()
             if job is None:
+                self._q.task_done()
                 return
             if self._err is None:
                 try:
                     self._sink.write(self._make_rows(*job))
                 except BaseException as e:                      # noqa: BLE001 - re-raised on the loop's thread
                     self._err = e
+            self._q.task_done()
 
     def close(self):
         self._q.put(None)
@@ -522,6 +531,11 @@ class SequencerControl:
 
     SLICE_READS = 4096          # a batch of more than 1.5 x this many reads is assessed in slices of about this size
     FIRST_SLICE_HALF = True     # the first slice of a sliced batch is half a slice (the device idles until it is staged)
+    # batches with at least this many assessed reads hand their CSV rows to the writer thread, smaller ones write them inline:
+    # at 18 000 channels the thread takes 4.4 ms out of the loop; at 512 channels (tools/csv_thread_ab.py, alternating in one
+    # process) it trades 0.09 ms of loop time for 0.07 ms of decision latency (the writer shares the interpreter lock with the
+    # next batch's staging) with the same p99 / max - so a MinION-sized batch keeps its rows inline
+    CSV_THREAD_MIN_READS = 2048
     # slices k >= 1 staged on a second host thread instead of on the loop's thread one slice ahead.  Built and measured in
     # round 5 (tools/control_ab.py, variants interleaved in one process, 18 000 channels): 22.4 against 22.5 ms in bf16x3, 33.0
     # against 34.1 ms in fp32 - inside the run-to-run spread.  What the thread can overlap is the memcpy (it releases the
@@ -770,7 +784,10 @@ class SequencerControl:
             self.batch_latencies.append(time.monotonic() - t0)
         t, self._ph[5] = self._tick(t, 5)
         if res is not None:
-            writer.put(res, t0, mode, threshold)                 # formatted and written by the writer thread
+            if len(res) >= self.CSV_THREAD_MIN_READS:
+                writer.put(res, t0, mode, threshold)             # formatted and written by the writer thread
+            else:
+                writer.write_now(res, t0, mode, threshold)       # a MinION-sized batch: 0.1 ms inline
             t, self._ph[6] = self._tick(t, 6)
             self.batch_loop_times.append(time.monotonic() - t0)
             self.batch_phases.append(self._ph.copy())
