@@ -587,6 +587,13 @@ def control_loop_object(device, dtype):
         out[f"models_{n_models}_bf16x3"] = run_replay(models, proc, batches)
         for m in models:
             m.close()
+    # the reference's second architecture behind the same loop (riser/nets/resnet.py; `Model` with a `resnet:` config): ragged
+    # batches are one forward (rs_seqnet_forward_ragged), stem and residual blocks in split precision on the bf16 MFMA
+    import types
+    rcfg = types.SimpleNamespace(model="resnet", resnet=types.SimpleNamespace(**synth.RESNET_BENCH_CFG))
+    models = [Model(synth.make_resnet_state_dict(7), rcfg, None, "mRNA", dtype="bf16x3", device=device)]
+    out["models_1_resnet_bf16x3"] = run_replay(models, proc, batches)
+    models[0].close()
     del batches
     big = scripted_batches(60, 18000)
     models = [Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=dtype, device=device)]
