@@ -296,6 +296,7 @@ class _SignalStore:
         self.auto_off = False
         self._bad_streak = 0
         self._uploaded = None                                    # event: the last slice's staging has been read by its copy
+        self._stats3 = np.zeros(3, dtype=np.int64)               # store_slice's counters (re-seen, delta, mismatches)
 
     def reserve(self, rows: int, samples: int):
         """device rows / pinned staging for batches of up to `rows` reads carrying up to `samples` new samples"""
@@ -407,26 +408,45 @@ class _SignalStore:
         fits = lens <= self.pitch
         if self._dup_channels:
             fits = np.zeros(B, dtype=bool)
-        have = self.row_have[rows]
-        reseen = fits & (self.row_id[rows] == batch.ids) & (have > 0)
-        cand = reseen & (have <= lens) & (have >= T)
         stage = self._stage(presented)
-        windows = np.lib.stride_tricks.sliding_window_view(stage, T)      # windows[i] = stage[i: i + T], no copy
-        while True:
-            start = np.where(cand, have - T, 0)
+        if batch.native and _hp is not None and hasattr(_hp, "store_slice") and self.row_id.flags.c_contiguous:
+            # the whole slice as ONE C call (csrc/hostpack.c:store_slice): ids compared as objects, the overlap of every delta
+            # candidate checked in the read's own buffer BEFORE anything is staged, raw[start:] of every read copied by the
+            # copy-thread pool, the rows' lengths / tails / ids updated - the interpreter lock is held for the id work only
+            start = np.empty(B, dtype=np.int64)
+            cand_u8 = np.empty(B, dtype=np.uint8)
+            stats = self._stats3
+            total = int(_hp.store_slice(batch.reads, batch.ids, self.row_id, np.ascontiguousarray(rows),
+                                        np.ascontiguousarray(lens, dtype=np.int64), np.ascontiguousarray(fits, dtype=np.uint8),
+                                        self.row_have, self.row_tail, T, stage, start, cand_u8, stats))
+            cand = cand_u8.view(bool)
             seg_len = lens - start
             src = np.zeros(B, dtype=np.int64)
             np.cumsum(seg_len[:-1], out=src[1:])
-            total = batch.stage(start, stage)
-            ci = np.flatnonzero(cand)
-            if ci.size == 0:
-                break
-            ok = (windows[src[ci]] == self.row_tail[rows[ci]]).all(axis=1)
-            if ok.all():
-                break
-            cand[ci[~ok]] = False                                   # not the prefix the row holds: whole, and staged again
-            self.mismatches += int((~ok).sum())
-        n_reseen, n_delta = int(reseen.sum()), int(cand.sum())
+            n_reseen, n_delta = int(stats[0]), int(stats[1])
+            self.mismatches += int(stats[2])
+            rows_updated = True
+        else:
+            rows_updated = False
+            have = self.row_have[rows]
+            reseen = fits & (self.row_id[rows] == batch.ids) & (have > 0)
+            cand = reseen & (have <= lens) & (have >= T)
+            windows = np.lib.stride_tricks.sliding_window_view(stage, T)      # windows[i] = stage[i: i + T], no copy
+            while True:
+                start = np.where(cand, have - T, 0)
+                seg_len = lens - start
+                src = np.zeros(B, dtype=np.int64)
+                np.cumsum(seg_len[:-1], out=src[1:])
+                total = batch.stage(start, stage)
+                ci = np.flatnonzero(cand)
+                if ci.size == 0:
+                    break
+                ok = (windows[src[ci]] == self.row_tail[rows[ci]]).all(axis=1)
+                if ok.all():
+                    break
+                cand[ci[~ok]] = False                                   # not the prefix the row holds: whole, and staged again
+                self.mismatches += int((~ok).sum())
+            n_reseen, n_delta = int(reseen.sum()), int(cand.sum())
         self.delta_reads += n_delta
         if not self._dup_channels:                               # (two reads of one channel share a row: no per-row state then)
             self.last_rows, self.last_delta = rows, cand         # a delta read's prefix is what the row held: scans may resume
@@ -438,13 +458,14 @@ class _SignalStore:
         self._spill_at += int(spill_len.sum())
         spill_base = self.cap_rows * self.pitch
         dst = np.where(fits, rows * self.pitch + start, spill_base + spill_off)
-        fi = np.flatnonzero(fits)
-        self.row_id[rows[fi]] = batch.ids[fi]
-        self.row_have[rows[fi]] = lens[fi]
-        self.row_have[rows[~fits]] = 0
-        keep = fi[lens[fi] >= T]                                    # the new tails: the last T staged samples of each read
-        if keep.size:
-            self.row_tail[rows[keep]] = windows[src[keep] + seg_len[keep] - T]
+        if not rows_updated:
+            fi = np.flatnonzero(fits)
+            self.row_id[rows[fi]] = batch.ids[fi]
+            self.row_have[rows[fi]] = lens[fi]
+            self.row_have[rows[~fits]] = 0
+            keep = fi[lens[fi] >= T]                                # the new tails: the last T staged samples of each read
+            if keep.size:
+                self.row_tail[rows[keep]] = windows[src[keep] + seg_len[keep] - T]
         # ---- the new samples, compacted: one transfer, one scatter ------------------------------------------------
         self.samples_uploaded += total
         if total:

@@ -256,6 +256,192 @@ static PyObject* hp_gather(PyObject* self, PyObject* args) {
     return PyLong_FromSsize_t(at / 2);
 }
 
+/* store_slice(reads, ids_obj, row_ids_obj, rows_i64, lens_i64, fits_u8, row_have_i64, row_tail_i16, T, stage_i16,
+ *             start_i64_out, cand_u8_out, stats_i64_out[3]) -> samples staged
+ * One slice of a batch through the device-resident signal store's host side (riser_amd/control.py:_SignalStore.update), as ONE
+ * call.  Per read i with row r = rows[i]: it is RE-SEEN when it fits a row, the row holds the same id (the same object, or ==) and
+ * samples; a re-seen read that is not shorter than what the row holds is a CANDIDATE for the delta path, and it takes it when its
+ * samples [have - T, have) equal the T samples the row kept (row_tail) - checked in the read's own buffer, before anything is
+ * copied.  start[i] = have - T for a delta read, else 0; raw[start:] of every read goes to `stage` back to back (the copy-thread
+ * pool); then the rows learn their reads: row_have = the read's length (0 for a read too long for a row), row_tail = its last T
+ * samples (reads of at least T), row_ids = its id.  stats = (re-seen, delta, candidates whose overlap did not match).
+ * The id comparison and the row_ids update hold the interpreter lock; the overlap check, the copies and the tails do not. */
+static PyObject* hp_store_slice(PyObject* self, PyObject* args) {
+    PyObject *reads, *ids, *row_ids, *rows, *lens, *fits, *row_have, *row_tail, *stage, *start, *cand, *stats;
+    int T;
+    if (!PyArg_ParseTuple(args, "OOOOOOOOiOOOO", &reads, &ids, &row_ids, &rows, &lens, &fits, &row_have, &row_tail, &T, &stage, &start,
+                          &cand, &stats))
+        return NULL;
+    if (!PyList_Check(reads) || T < 1 || T > 4096) {
+        PyErr_SetString(PyExc_TypeError, "store_slice: reads must be a list, 1 <= T <= 4096");
+        return NULL;
+    }
+    const Py_ssize_t n = PyList_GET_SIZE(reads);
+    Py_buffer b[10];
+    PyObject* objs[10] = {ids, row_ids, rows, lens, fits, row_have, row_tail, stage, start, cand};
+    const int writable[10] = {0, 1, 0, 0, 0, 1, 1, 1, 1, 1};
+    const int as_objects[10] = {1, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+    int got = 0;
+    Py_buffer bst;
+    int have_bst = 0;
+    PyObject* result = NULL;
+    Py_buffer* views = NULL;
+    piece_t* pc = NULL;
+    unsigned char* same = NULL;
+    Py_ssize_t held = 0;
+    for (; got < 10; ++got) {
+        const int flags = (writable[got] ? PyBUF_WRITABLE : 0) | (as_objects[got] ? PyBUF_FORMAT : 0) | PyBUF_C_CONTIGUOUS;
+        if (PyObject_GetBuffer(objs[got], &b[got], flags) != 0) goto done;
+        if (as_objects[got] && !(b[got].format && strcmp(b[got].format, "O") == 0 && b[got].itemsize == (Py_ssize_t)sizeof(PyObject*))) {
+            ++got;
+            PyErr_SetString(PyExc_TypeError, "store_slice: ids / row_ids must be contiguous object arrays");
+            goto done;
+        }
+    }
+    if (get_wbuf(stats, &bst, "store_slice(stats)") != 0) goto done;
+    have_bst = 1;
+    {
+        const Py_ssize_t n_rows = b[5].len / (Py_ssize_t)sizeof(int64_t);
+        if (b[0].len < (Py_ssize_t)(n * sizeof(PyObject*)) || b[1].len < (Py_ssize_t)(n_rows * sizeof(PyObject*)) ||
+            b[2].len < (Py_ssize_t)(n * 8) || b[3].len < (Py_ssize_t)(n * 8) || b[4].len < n ||
+            b[6].len < (Py_ssize_t)(n_rows * T * 2) || b[8].len < (Py_ssize_t)(n * 8) || b[9].len < n || bst.len < 24) {
+            PyErr_SetString(PyExc_ValueError, "store_slice: an array is shorter than the slice / the row table");
+            goto done;
+        }
+        PyObject** id_ = (PyObject**)b[0].buf;
+        PyObject** rid_ = (PyObject**)b[1].buf;
+        const int64_t* row_ = (const int64_t*)b[2].buf;
+        const int64_t* len_ = (const int64_t*)b[3].buf;
+        const uint8_t* fit_ = (const uint8_t*)b[4].buf;
+        int64_t* have_ = (int64_t*)b[5].buf;
+        int16_t* tail_ = (int16_t*)b[6].buf;
+        char* stage_ = (char*)b[7].buf;
+        int64_t* start_ = (int64_t*)b[8].buf;
+        uint8_t* cand_ = (uint8_t*)b[9].buf;
+        int64_t* stats_ = (int64_t*)bst.buf;
+        views = (Py_buffer*)PyMem_Malloc((size_t)(n ? n : 1) * sizeof(Py_buffer));
+        pc = (piece_t*)PyMem_Malloc((size_t)(n ? n : 1) * sizeof(piece_t));
+        same = (unsigned char*)PyMem_Malloc((size_t)(n ? n : 1));
+        if (!views || !pc || !same) {
+            PyErr_NoMemory();
+            goto done;
+        }
+        /* ---- with the interpreter lock: the reads' buffers, "does the row hold this id" ---- */
+        for (Py_ssize_t i = 0; i < n; ++i) {
+            if (row_[i] < 0 || row_[i] >= n_rows) {
+                PyErr_SetString(PyExc_ValueError, "store_slice: row out of range");
+                goto done;
+            }
+            if (raw_view(PyList_GET_ITEM(reads, i), &views[i]) != 0) goto done;
+            ++held;
+            if (views[i].len / 2 != (Py_ssize_t)len_[i]) {
+                PyErr_SetString(PyExc_ValueError, "store_slice: a read's length changed under the batch");
+                goto done;
+            }
+            same[i] = 0;
+            if (fit_[i]) {
+                PyObject* r = rid_[row_[i]];
+                if (r == id_[i])
+                    same[i] = 1;
+                else if (r != NULL && r != Py_None) {
+                    const int eq = PyObject_RichCompareBool(r, id_[i], Py_EQ);
+                    if (eq < 0) goto done;
+                    same[i] = (unsigned char)eq;
+                }
+            }
+        }
+        /* ---- without it: overlap check, piece list, copies, the rows' new lengths and tails ---- */
+        Py_ssize_t at = 0;
+        int64_t n_reseen = 0, n_delta = 0, n_bad = 0;
+        int overflow = 0;
+        Py_BEGIN_ALLOW_THREADS
+        for (Py_ssize_t i = 0; i < n; ++i) {
+            const int64_t L = len_[i];
+            const char* raw = (const char*)views[i].buf;
+            int64_t st = 0;
+            uint8_t c = 0;
+            if (fit_[i]) {
+                const int64_t have = have_[row_[i]];
+                if (same[i] && have > 0) {
+                    ++n_reseen;
+                    if (have <= L && have >= T) {
+                        if (memcmp(raw + 2 * (have - T), tail_ + row_[i] * (int64_t)T, (size_t)T * 2) == 0) {
+                            c = 1;
+                            st = have - T;
+                            ++n_delta;
+                        } else {
+                            ++n_bad;
+                        }
+                    }
+                }
+            }
+            start_[i] = st;
+            cand_[i] = c;
+            const Py_ssize_t nb = (Py_ssize_t)(L - st) * 2;
+            if (at + nb > b[7].len) {
+                overflow = 1;
+                break;
+            }
+            pc[i].src = raw + 2 * st;
+            pc[i].dst = stage_ + at;
+            pc[i].nb = (size_t)nb;
+            at += nb;
+        }
+        if (!overflow) {
+            int nt = at > (8 << 20) ? HP_MAX_THREADS : at > (3 << 20) ? 4 : 1;
+            if (nt > hp_thread_cap) nt = hp_thread_cap;
+            if (nt > n) nt = (int)(n ? n : 1);
+            job_t jobs[HP_MAX_THREADS];
+            Py_ssize_t lo = 0;
+            size_t acc = 0;
+            for (int t = 0; t < nt; ++t) {
+                const size_t want = (size_t)at * (size_t)(t + 1) / (size_t)nt;
+                Py_ssize_t hi = lo;
+                while (hi < n && (t == nt - 1 || acc + pc[hi].nb <= want || hi == lo)) acc += pc[hi++].nb;
+                jobs[t].pc = pc;
+                jobs[t].lo = lo;
+                jobs[t].hi = hi;
+                lo = hi;
+            }
+            if (n) run_copy_jobs(jobs, nt);
+            for (Py_ssize_t i = 0; i < n; ++i) {
+                if (fit_[i]) {
+                    have_[row_[i]] = len_[i];
+                    if (len_[i] >= T)
+                        memcpy(tail_ + row_[i] * (int64_t)T, (const char*)views[i].buf + 2 * (len_[i] - T), (size_t)T * 2);
+                } else {
+                    have_[row_[i]] = 0;
+                }
+            }
+        }
+        Py_END_ALLOW_THREADS
+        if (overflow) {
+            PyErr_SetString(PyExc_ValueError, "store_slice: staging buffer too small");
+            goto done;
+        }
+        /* ---- with it again: the rows' ids ---- */
+        for (Py_ssize_t i = 0; i < n; ++i)
+            if (fit_[i] && rid_[row_[i]] != id_[i]) {
+                PyObject* old = rid_[row_[i]];
+                Py_INCREF(id_[i]);
+                rid_[row_[i]] = id_[i];
+                Py_XDECREF(old);
+            }
+        stats_[0] = n_reseen;
+        stats_[1] = n_delta;
+        stats_[2] = n_bad;
+        result = PyLong_FromSsize_t(at / 2);
+    }
+done:
+    for (Py_ssize_t i = 0; i < held; ++i) PyBuffer_Release(&views[i]);
+    PyMem_Free(views);
+    PyMem_Free(pc);
+    PyMem_Free(same);
+    if (have_bst) PyBuffer_Release(&bst);
+    for (int k = 0; k < got; ++k) PyBuffer_Release(&b[k]);
+    return result;
+}
+
 /* growable byte sink on the C heap: usable without the interpreter lock */
 typedef struct {
     char* p;
@@ -687,6 +873,7 @@ static PyMethodDef methods[] = {
     {"gather", hp_gather, METH_VARARGS, "gather(reads, start_int64, out_int16) -> samples written"},
     {"format_rows", hp_format_rows, METH_VARARGS, "CSV rows of one batch as one string (text built without the GIL)"},
     {"repr_double", hp_repr_double, METH_O, "repr(float) as format_rows writes it (test hook)"},
+    {"store_slice", hp_store_slice, METH_VARARGS, "one slice through the signal store's host side: delta candidates, staging, row state"},
     {"decided", hp_decided, METH_VARARGS, "decided(reads, sel, channels, dec, codes) -> per code a list of (channel, read key)"},
     {"unpack", hp_unpack, METH_VARARGS, "unpack(entries, channels_int64) -> reads: splits [(channel, read), ...]"},
     {"attrs", hp_attrs, METH_VARARGS, "attrs(reads, name) -> [getattr(r, name) for r in reads]"},

@@ -308,3 +308,72 @@ def test_hostpack_decided_lists(hp):
     assert hp.decided(reads, sel[:0], chan[:0], dec[:0], (2,)) == ([],)
     with pytest.raises(ValueError):
         hp.decided(reads, np.array([999], dtype=np.int64), chan[:1], np.array([2], dtype=np.uint8), (2,))
+
+
+def test_hostpack_store_slice_against_the_numpy_steps(hp):
+    """_hostpack.store_slice = the host side of _SignalStore.update for one slice, in one call: re-seen reads, delta candidates
+    verified on the overlap with the row's tail, raw[start:] staged back to back, the rows' lengths / tails / ids updated.
+    Against the numpy steps it replaces, over random traffic: new reads, extensions (delta path), same id with other samples
+    (a chunk client: overlap mismatch), shorter re-sends, reads too long for a row, reads shorter than the tail."""
+    rng = np.random.default_rng(12)
+    T, n_rows, pitch = 32, 40, 3000
+    row_id = np.full(n_rows, None, dtype=object)
+    row_have = np.zeros(n_rows, dtype=np.int64)
+    row_tail = np.zeros((n_rows, T), dtype=np.int16)
+    ref_id, ref_have, ref_tail = row_id.copy(), row_have.copy(), row_tail.copy()
+    held = {}                                                    # row -> the samples the row's read was built from
+    for step in range(30):
+        B = int(rng.integers(1, n_rows))
+        rows = rng.choice(n_rows, size=B, replace=False).astype(np.int64)
+        reads, ids = [], np.empty(B, dtype=object)
+        for i, r in enumerate(rows.tolist()):
+            kind = rng.integers(0, 6)
+            if r in held and kind <= 2:                          # the same read again, longer: delta path
+                rid, sig = held[r]
+                sig = np.concatenate([sig, rng.integers(-500, 3000, size=int(rng.integers(0, 400)), dtype=np.int16)])
+            elif r in held and kind == 3:                        # the same id, other samples of the same length or more
+                rid, old = held[r]
+                sig = rng.integers(-500, 3000, size=old.shape[0] + int(rng.integers(0, 50)), dtype=np.int16)
+            elif r in held and kind == 4:                        # the same id, shorter
+                rid, old = held[r]
+                sig = old[: max(1, old.shape[0] // 2)].copy()
+            else:
+                rid = f"read-{step}-{r}"
+                sig = rng.integers(-500, 3000, size=int(rng.choice([5, 20, 31, 32, 33, 700, 2500, 3500])), dtype=np.int16)
+            held[r] = (rid, sig)
+            ids[i] = "".join(rid)                                # an equal string, not the same object
+            reads.append(FakeRead(ids[i], sig))
+        lens = np.array([len(r.raw_data) // 2 for r in reads], dtype=np.int64)
+        fits = lens <= pitch
+        # ---- the numpy steps of _SignalStore.update ----
+        have = ref_have[rows]
+        reseen = fits & (ref_id[rows] == ids) & (have > 0)
+        cand = reseen & (have <= lens) & (have >= T)
+        bad = 0
+        for i in np.flatnonzero(cand):
+            sig = np.frombuffer(reads[i].raw_data, dtype=np.int16)
+            if not np.array_equal(sig[have[i] - T: have[i]], ref_tail[rows[i]]):
+                cand[i] = False
+                bad += 1
+        start_want = np.where(cand, have - T, 0)
+        stage_want = np.concatenate([np.frombuffer(r.raw_data, dtype=np.int16)[s:] for r, s in zip(reads, start_want.tolist())])
+        for i, r in enumerate(rows.tolist()):
+            if fits[i]:
+                ref_id[r], ref_have[r] = ids[i], lens[i]
+                if lens[i] >= T:
+                    ref_tail[r] = np.frombuffer(reads[i].raw_data, dtype=np.int16)[-T:]
+            else:
+                ref_have[r] = 0
+        # ---- the C call ----
+        stage = np.zeros(int(lens.sum()) + 8, dtype=np.int16)
+        start, cand_c, stats = np.empty(B, dtype=np.int64), np.empty(B, dtype=np.uint8), np.zeros(3, dtype=np.int64)
+        total = hp.store_slice(reads, ids, row_id, rows, lens, fits.astype(np.uint8), row_have, row_tail, T, stage, start, cand_c, stats)
+        assert total == stage_want.shape[0] and np.array_equal(stage[:total], stage_want)
+        assert np.array_equal(start, start_want) and np.array_equal(cand_c.astype(bool), cand)
+        assert stats.tolist() == [int(reseen.sum()), int(cand.sum()), bad]
+        assert np.array_equal(row_have, ref_have) and np.array_equal(row_tail, ref_tail) and list(row_id) == list(ref_id)
+        for r in rows[~fits].tolist():
+            held.pop(r, None)
+    with pytest.raises(ValueError):
+        hp.store_slice(reads, ids, row_id, rows, lens, fits.astype(np.uint8), row_have, row_tail, T, np.zeros(4, dtype=np.int16), start,
+                       cand_c, stats)

@@ -29,6 +29,22 @@ def many():                                                       # the persiste
 ts = [threading.Thread(target=many) for _ in range(3)]; [t.start() for t in ts]; many(); [t.join() for t in ts]
 dl = hp.decided(reads, np.arange(len(reads), dtype=np.int64), np.arange(len(reads), dtype=np.int64), (np.arange(len(reads)) % 4).astype(np.uint8), (2, 1, 3))
 assert sum(map(len, dl)) == sum(1 for i in range(len(reads)) if i % 4) and dl[0][0] == (2, "id-2")
+# store_slice: new reads, then the same reads 100 samples longer (delta path), then other samples under the same ids (mismatch)
+nr = 64; T = 32
+rid = np.full(nr, None, dtype=object); rhave = np.zeros(nr, dtype=np.int64); rtail = np.zeros((nr, T), dtype=np.int16)
+sigs = [rng.integers(-300, 4000, size=int(rng.integers(40, 3000)), dtype=np.int16) for _ in range(nr)]
+for turn in range(3):
+    if turn == 1: sigs = [np.concatenate([s_, rng.integers(0, 9, size=100, dtype=np.int16)]) for s_ in sigs]
+    if turn == 2: sigs = [rng.integers(0, 9, size=s_.size, dtype=np.int16) for s_ in sigs]
+    rr = [R(f"s{i}", s_) for i, s_ in enumerate(sigs)]
+    idsv = np.empty(nr, dtype=object); idsv[:] = [r_.id for r_ in rr]
+    ln = np.array([s_.size for s_ in sigs], dtype=np.int64)
+    st_, cd_, stt = np.empty(nr, dtype=np.int64), np.empty(nr, dtype=np.uint8), np.zeros(3, dtype=np.int64)
+    stg = np.empty(int(ln.sum()), dtype=np.int16)
+    tot = hp.store_slice(rr, idsv, rid, np.arange(nr, dtype=np.int64), ln, (ln <= 2900).astype(np.uint8), rhave, rtail, T, stg, st_, cd_, stt)
+    assert tot == int((ln - st_).sum())
+    assert (turn != 1) or stt[1] > 50, stt
+    assert (turn != 2) or (stt[1] == 0 and stt[2] > 50), stt
 assert hp.repr_double(0.1) == repr(0.1) and hp.repr_double(5e-324) == "5e-324" and hp.repr_double(float("nan")) == "nan"
 ids = np.empty(len(reads), dtype=object); ids[:] = hp.attrs(reads, "id")
 o = np.zeros(len(reads), dtype=np.int64)
