@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--batches", type=int, default=30)
     ap.add_argument("--dtype", default="bf16x3")
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--only", default="", help="comma list of variant indices (0 r4 order, 1 thread, 2 thread+half, 3 half)")
     args = ap.parse_args()
     from riser_amd import Model, SignalProcessor, Kit
     dev = torch.device("cuda", 0)
@@ -24,6 +25,9 @@ def main():
     batches = scripted_batches(args.batches, args.channels)
     variants = {"r4 order (one thread, equal slices)": (False, False), "stage thread": (True, False),
                 "stage thread + half first slice": (True, True), "half first slice only": (False, True)}
+    if args.only:
+        keep = {int(v) for v in args.only.split(",")}
+        variants = {k: v for i, (k, v) in enumerate(variants.items()) if i in keep}
     res = {k: [] for k in variants}
     for _ in range(args.rounds):
         for name, (thr, half) in variants.items():
