@@ -39,6 +39,7 @@ Hooks Hooks::from_env() {
     h.no_rect_order = flag("RS_NO_RECT_ORDER");
     h.no_tail_split = flag("RS_NO_TAIL_SPLIT");
     h.tail_debug = flag("RS_TAIL_DEBUG");
+    h.no_deep_staging = flag("RS_NO_DEEP_STAGING");
     h.ring_tail_split = flag("RS_RING_TAIL_SPLIT");
     h.no_fuse0 = flag("RS_NO_FUSE0");
     h.no_stream_f32 = flag("RS_NO_STREAM_F32");
@@ -887,10 +888,12 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                 // the launch planner's own estimate of the tiled kernel against the small kernel's (both in cycles, both
                 // rough): take the small kernel where it is clearly ahead
                 const int n16 = round_up(L.c_out, 16) / 16;
+                bool thin_fit = false;                               // the tiled estimate is the thin-launch fit (with its launch cost: like the small kernel's)
                 const double tiled = L.wino_m == 4
-                    ? conv_wino4_plan_cost((rows_in + 3) / 4, n16, L.plan.kc, L.plan.nch, m->num_cu)
+                    ? conv_wino4_launch_cost((rows_in + 3) / 4, n16, L.plan.kc, L.plan.nch, m->num_cu, &thin_fit)
                     : conv_wino_plan_cost(rows_in / 2, n16, L.plan.kc, L.plan.nch, m->num_cu);
-                small32 = conv_small_f32_waves(L, rows_in) <= 4096 && conv_small_f32_cost(L, rows_in, m->num_cu) < 0.8 * tiled;
+                small32 = conv_small_f32_waves(L, rows_in) <= 4096 &&
+                          conv_small_f32_cost(L, rows_in, m->num_cu) < (thin_fit ? 1.0 : 0.8) * tiled;
             }
         }
         const int kind = (stream32 || stream16 || wres || small32) ? 0 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)

@@ -55,6 +55,7 @@ struct DeviceGuard {
 // created (rs_model_create), never on the launch path.
 struct Hooks {
     bool no_rect_order = false;      // RS_NO_RECT_ORDER: n-major tile order instead of XCD rectangles
+    bool no_deep_staging = false;    // RS_NO_DEEP_STAGING: the thin fp32 Winograd shapes keep the default staging distance (A/B of the one-item-ahead loads)
     bool tail_debug = false;         // RS_TAIL_DEBUG: print every head / tail decision
     bool ring_tail_split = false;    // RS_RING_TAIL_SPLIT: head + tail launches for the 16-bit ring kernel too (measured: a wash)
     bool no_tail_split = false;      // RS_NO_TAIL_SPLIT: tiled conv layers (fp32 Winograd, 16-bit ring) always as ONE launch (tile_walk.hpp: plan_tail_split)
@@ -163,6 +164,7 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
                       int layer_index, int num_cu, int check_dead, hipStream_t st, int* bm_out, int* bn_out);
 int conv_wino4_max_bn();
 double conv_wino4_plan_cost(int64_t groups, int n16, int kc, int nch, int num_cu);
+double conv_wino4_launch_cost(int64_t groups, int n16, int kc, int nch, int num_cu, bool* thin_out);
 bool conv_wino_can_fuse0(const ConvLayerDev& L, int P_in);
 // fp32 Winograd, layers 0 + 1 of the shipped net as one LDS-free streaming kernel (conv_stream_f32.hip)
 bool conv_stream_f32_ok(const ConvLayerDev& L1, int c0, int P_in1);

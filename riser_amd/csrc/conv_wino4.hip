@@ -37,6 +37,15 @@
 #ifndef RS_UF_AHEAD
 #define RS_UF_AHEAD 1
 #endif
+#ifndef RS_UF_AHEAD_THIN          // slots of look-ahead x MFMAs per slot for the one- and two-MFMA slots of the thin shapes
+#define RS_UF_AHEAD_THIN 4
+#endif
+#ifndef RS_RD_THIN
+#define RS_RD_THIN 0
+#endif
+#ifndef RS_XF_THIN
+#define RS_XF_THIN 5
+#endif
 #ifndef RS_W4_DIST
 #define RS_W4_DIST 6
 #endif
@@ -80,11 +89,20 @@ struct Wino4Args {
     WalkArgs walk;         // tile grid, order and dead-tile flag (tile_walk.hpp)
 };
 
-template <int WM, int WN, int MT, int NT, int KCT>
-__global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
-    static_assert(WM * WN == 8, "8 waves per workgroup (2 per SIMD)");
+// DEEP: the staging loads of an item are issued ONE ITEM earlier (they stay in registers across the barrier and go to LDS
+// during the next item): a thin launch (a few dozen tiles of the smallest shapes) has ~1.5 k cycles of MFMAs per item, far
+// less than the trip to L2 / HBM that the six-slot distance of the default schedule covers.  Same MFMA sequence per
+// accumulator, so the bits do not change.
+template <int WM, int WN, int MT, int NT, int KCT, bool DEEP = false>
+__global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {   // 512 for the four-wave shapes too: a bound of 256 makes
+                                                                                  // the compiler keep the accumulators in AGPRs, with
+                                                                                  // a copy in and out per item
+    // 8 waves (2 per SIMD), or 4 (1 per SIMD) for launches with fewer tiles than CUs: the VALU work of a wave (input
+    // transform, staging, walk) and the f32-input MFMAs of its SIMD neighbour do not overlap, so a thin launch is faster
+    // with its waves spread over twice the CUs
+    static_assert(WM * WN == 8 || WM * WN == 4, "8 or 4 waves per workgroup");
     static_assert(KCT == 16 || KCT == 20, "channel chunk");
-    constexpr int kThreads = 512;
+    constexpr int kThreads = 64 * WM * WN;
     constexpr int NC = 6;                               // Winograd components
     constexpr int BG = WM * 16 * MT;                    // groups (of 4 conv rows = 2 pooled rows) per tile
     constexpr int BN = WN * 16 * NT;
@@ -236,6 +254,21 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
     item_offsets(m0, n0, 0, true);
     static_for<A_PER + B_PER>([&](auto U) { load_unit(U); });
     static_for<A_PER + B_PER>([&](auto U) { store_unit(U, lds); });
+    // the item after (oo, cc) of this workgroup's walk; oo >= tiles: none
+    auto advance = [&](int& oo, int& cc, int& mm, int& nn) {
+        if (oo >= tiles) return;
+        if (++cc == a.nch) {
+            cc = 0;
+            oo = next_live();
+            if (oo < tiles) tile_origin(oo, mm, nn);
+        }
+    };
+    int o1 = o, c1 = 0, m1 = m0, n1 = n0;              // DEEP: the next item, already on its way in ra / rb
+    if constexpr (DEEP) {
+        advance(o1, c1, m1, n1);
+        item_offsets(m1, n1, c1, o1 < tiles);
+        static_for<A_PER + B_PER>([&](auto U) { load_unit(U); });
+    }
     __syncthreads();
     int buf = 0;
 
@@ -244,24 +277,37 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
 
     while (true) {
         int nc = c + 1, no = o;
-        if (nc == a.nch) {
+        int nm0 = m0, nn0 = n0;
+        int o2 = o1, c2 = c1, m2 = m1, n2 = n1;
+        if constexpr (DEEP) {
+            nc = c1, no = o1, nm0 = m1, nn0 = n1;
+            advance(o2, c2, m2, n2);
+        } else if (nc == a.nch) {
             nc = 0;
             no = next_live();
         }
         const bool has_next = no < tiles;
-        int nm0 = m0, nn0 = n0;
-        if (has_next && nc == 0) tile_origin(no, nm0, nn0);
+        if constexpr (!DEEP)
+            if (has_next && nc == 0) tile_origin(no, nm0, nn0);
         const float* Ab = lds + buf * BUF + a_rd;
         const float* Bb = lds + buf * BUF + b_rd;
         float* nbuf = lds + (buf ^ 1) * BUF;
-        item_offsets(nm0, nn0, nc, has_next);
+        if constexpr (DEEP)
+            item_offsets(m2, n2, c2, o2 < tiles);
+        else
+            item_offsets(nm0, nn0, nc, has_next);
 
         constexpr int NSLOTS = NC * KQ;                // slot = (k-step, component): MT * NT MFMAs
         constexpr int UNITS = A_PER + B_PER;
         constexpr int DIST = RS_W4_DIST;               // slots between a unit's load and its LDS write
         constexpr int SPAN = NSLOTS - DIST;
         float dr[MT][6];                               // raw inputs d0..d5 of the lane's groups (next k-step)
-        constexpr int AH = RS_UF_AHEAD;                // slots of look-ahead of the weight-fragment reads
+        // a slot of the thin shapes is one or two MFMAs (32 / 64 cycles): an LDS read issued one slot ahead is not back
+        // in time, so their weight fragments are read four (two) slots ahead, the raw rows at the first slot of a
+        // k-step and transformed behind its last
+        constexpr bool THIN = MT * NT <= 2;
+        constexpr int AH = THIN ? (RS_UF_AHEAD_THIN + MT * NT - 1) / (MT * NT) : RS_UF_AHEAD;   // slots of look-ahead of the weight-fragment reads
+        constexpr int RD = THIN ? RS_RD_THIN : 1, XF0 = THIN ? RS_XF_THIN : 3;
         float uf[AH + 1][NT];                          // weight fragments, ring over the slots in flight
         float v[2][MT][NC];                            // transformed inputs: this k-step / the next one
         auto xform = [&](float (&o)[NC], const float (&d)[6]) {   // V = B^T d
@@ -303,8 +349,8 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
             constexpr int st = sl / NC, comp = sl % NC;
             // the raw rows of the next k-step are read in slot 1 and transformed in slots 3 (+ 4 for MT = 2),
             // one VALU group behind each MFMA, so that the transform hides in the MFMA shadow
-            constexpr bool rd_next = comp == 1 && st + 1 < KQ;
-            constexpr bool xf_next = comp >= 3 && comp - 3 < MT && st + 1 < KQ;
+            constexpr bool rd_next = comp == RD && st + 1 < KQ;
+            constexpr bool xf_next = comp >= XF0 && comp - XF0 < MT && st + 1 < KQ;
             if constexpr (rd_next) {
                 constexpr int c0 = 4 * (st + 1);
 #pragma unroll
@@ -312,7 +358,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) RS_FRAG_A(dr[i][k], Ab[(k & 3) * PL + (i * 16 + (k >> 2)) * S + c0]);
             }
-            if constexpr (xf_next) xform(v[(st + 1) & 1][comp - 3], dr[comp - 3]);
+            if constexpr (xf_next) xform(v[(st + 1) & 1][comp - XF0], dr[comp - XF0]);
             if constexpr (sl + AH < NSLOTS) {
                 constexpr int nst = (sl + AH) / NC, ncomp = (sl + AH) % NC;
 #pragma unroll
@@ -344,14 +390,22 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
                 });
             }
             if constexpr (xf_next) {                   // pin the transformed values to this slot (they are pure
-                float(&o)[NC] = v[(st + 1) & 1][comp - 3];   // functions of dr: the compiler would sink them to their use)
+                float(&o)[NC] = v[(st + 1) & 1][comp - XF0];   // functions of dr: the compiler would sink them to their use)
                 asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]));
             }
             __builtin_amdgcn_sched_barrier(0);
             static_for<UNITS>([&](auto U) {
                 constexpr int u = decltype(U)::value;
-                if constexpr ((u * SPAN) / UNITS == sl) load_unit(U);
-                if constexpr ((u * SPAN) / UNITS + DIST == sl) {
+                if constexpr (DEEP) {
+                    // the unit loaded during the previous item goes to the next item's buffer, and its registers
+                    // leave again for the item after that
+                    if constexpr ((u * NSLOTS) / UNITS == sl) {
+                        store_unit(U, nbuf);
+                        load_unit(U);
+                    }
+                } else if constexpr ((u * SPAN) / UNITS == sl)
+                    load_unit(U);
+                if constexpr (!DEEP && (u * SPAN) / UNITS + DIST == sl) {
 #if RS_W4_STORE_ALWAYS                                  // unconditional: after the last item the writes land in the idle buffer
                                                         // (nobody reads it any more); saves a branch per unit: -1.2 % (clock-normalised A/B)
                     store_unit(U, nbuf);
@@ -422,6 +476,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const Wino4Args a) {
         c = nc;
         m0 = nm0;
         n0 = nn0;
+        if constexpr (DEEP) o1 = o2, c1 = c2, m1 = m2, n1 = n2;
     }
 }
 
@@ -430,18 +485,27 @@ using KernelFn = void (*)(const Wino4Args);
 struct Shape {
     int wm, wn, mt, nt;
     KernelFn fn[2];        // chunk = 16, 20
+    KernelFn deep[2];      // the same tile with staging loads one item ahead (thin launches), or null
 };
 
 #define RS_SHAPE(WM, WN, MT, NT) \
-    {WM, WN, MT, NT, {conv_wino4_kernel<WM, WN, MT, NT, 16>, conv_wino4_kernel<WM, WN, MT, NT, 20>}}
+    {WM, WN, MT, NT, {conv_wino4_kernel<WM, WN, MT, NT, 16>, conv_wino4_kernel<WM, WN, MT, NT, 20>}, {nullptr, nullptr}}
+#define RS_SHAPE_D(WM, WN, MT, NT)                                                                     \
+    {WM, WN, MT, NT, {conv_wino4_kernel<WM, WN, MT, NT, 16>, conv_wino4_kernel<WM, WN, MT, NT, 20>}, \
+     {conv_wino4_kernel<WM, WN, MT, NT, 16, true>, conv_wino4_kernel<WM, WN, MT, NT, 20, true>}}
 const Shape kShapes[] = {
-    RS_SHAPE(8, 1, 1, 2), RS_SHAPE(8, 1, 1, 3), RS_SHAPE(8, 1, 1, 4), RS_SHAPE(8, 1, 1, 5),
-    RS_SHAPE(4, 2, 1, 2), RS_SHAPE(4, 2, 1, 3), RS_SHAPE(4, 2, 1, 4), RS_SHAPE(4, 2, 2, 2),
-    RS_SHAPE(2, 4, 1, 2), RS_SHAPE(2, 4, 1, 3), RS_SHAPE(2, 4, 1, 4), RS_SHAPE(2, 4, 2, 2),
+    RS_SHAPE_D(8, 1, 1, 2), RS_SHAPE(8, 1, 1, 3), RS_SHAPE(8, 1, 1, 4), RS_SHAPE(8, 1, 1, 5),
+    RS_SHAPE_D(4, 2, 1, 2), RS_SHAPE(4, 2, 1, 3), RS_SHAPE(4, 2, 1, 4), RS_SHAPE(4, 2, 2, 2),
+    RS_SHAPE_D(2, 4, 1, 2), RS_SHAPE(2, 4, 1, 3), RS_SHAPE(2, 4, 1, 4), RS_SHAPE(2, 4, 2, 2),
     // small tiles (round 4): a batch of 32 ... 200 reads leaves the late layers a few dozen tiles of the shapes above
-    RS_SHAPE(4, 2, 1, 1), RS_SHAPE(2, 4, 1, 1),
+    RS_SHAPE_D(4, 2, 1, 1), RS_SHAPE_D(2, 4, 1, 1),
+    // four-wave workgroups (round 5): one wave per SIMD, for launches of fewer tiles than CUs
+    RS_SHAPE_D(4, 1, 1, 1), RS_SHAPE_D(2, 2, 1, 1), RS_SHAPE_D(1, 4, 1, 1),
+    RS_SHAPE_D(4, 1, 1, 2), RS_SHAPE_D(2, 2, 1, 2), RS_SHAPE_D(1, 4, 1, 2),
+    RS_SHAPE_D(4, 1, 1, 3), RS_SHAPE_D(2, 2, 1, 3),
 };
 #undef RS_SHAPE
+#undef RS_SHAPE_D
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
 size_t lds_bytes(const Shape& s, int kc) {
@@ -449,11 +513,11 @@ size_t lds_bytes(const Shape& s, int kc) {
     return 2 * (size_t)(4 * (bg + 1) + 6 * bn) * (kc + 2) * sizeof(float);
 }
 
-// per slot: MFMAs of the two waves of a SIMD, fragment reads, 1/6 of the k-step's input transform (12 VALU
-// per MT, not hidden behind the MFMAs); per item: fixed cost, staging, and the activation slab's trip from
-// L2 / Infinity Cache (the weight slab is an L2 hit).  Calibrated on tools/shape_sweep.py (B = 512).
+// Full launches (at least one tile per CU): per slot the MFMAs of the two waves of a SIMD, fragment reads, 1/6 of the k-step's
+// input transform (12 VALU per MT, not hidden behind the MFMAs); per item: fixed cost, staging, and the activation slab's trip
+// from L2 / Infinity Cache (the weight slab is an L2 hit).  Calibrated on tools/shape_sweep.py (B = 512); eight-wave shapes.
 double tile_cost(const Shape& s, int kc, int nch) {
-    if (lds_bytes(s, kc) > 160 * 1024) return -1.0;
+    if (lds_bytes(s, kc) > 160 * 1024 || s.wm * s.wn != 8) return -1.0;
     const int bg = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
     const double slots = 6.0 * kc / 4.0;
     const double staged = ((4.0 * bg + 2) + 6.0 * bnt * 16) * kc * 4.0;
@@ -463,25 +527,68 @@ double tile_cost(const Shape& s, int kc, int nch) {
     return nch * item + 1500.0 + 90.0 * s.mt * s.nt;
 }
 
-const Shape* choose_shape(int64_t groups, int n16, int kc, int nch, int num_cu, double* cost_out) {
+// THIN launches (fewer tiles than CUs: 16 ... 100 reads in the late layers): a least-squares fit over tools/shape_sweep.py at
+// 16 ... 512 reads, every shape, layers 5 - 10 (4 % rms, 15 % worst).  Per slot the MFMAs of a SIMD's waves add up; the
+// other instructions of a slot do not depend on the waves per SIMD; staged bytes cost more the more CUs stream (fill).
+// per_cu: workgroups of a four-wave shape resident on one CU (two: their waves share the SIMDs like an eight-wave
+// workgroup's).  kThinLaunch: launch + first / last tile effects of the same fit (for the comparison with conv_small_f32).
+constexpr double kThinLaunch = 23500.0;
+double thin_tile_cost(const Shape& s, int kc, int nch, int per_cu, double fill) {
+    if (lds_bytes(s, kc) * per_cu > 160 * 1024) return -1.0;
+    const int bg = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
+    const double slots = 6.0 * kc / 4.0;
+    const double staged = ((4.0 * bg + 2) + 6.0 * bnt * 16) * kc * 4.0 * per_cu;
+    const double wps = s.wm * s.wn * per_cu / 4.0;
+    const double item = slots * (wps * s.mt * s.nt * 32.0 + 71.6 + 4.25 * (s.mt + s.nt)) - 920.0 + staged * (0.0062 + 0.0124 * fill);
+    return nch * item - 467.0 + 554.0 * s.mt * s.nt;
+}
+
+// best shape for a launch over `groups` row units: the B = 512 calibration over the eight-wave shapes; when that launch
+// leaves CUs idle (and thin is allowed), the thin-launch fit over every shape, four-wave ones at one or two per CU.
+// *thin_out: which model *cost_out is in (their scales differ by up to 25 %: compare like with like).
+const Shape* choose_shape(int64_t groups, int n16, int kc, int nch, int num_cu, double* cost_out, int* per_cu_out = nullptr,
+                          bool allow_thin = true, bool* thin_out = nullptr) {
     const Shape* best = nullptr;
     double best_cost = 1e300;
+    int best_per_cu = 1;
+    int64_t best_tiles = 0;
     for (int k = 0; k < kNumShapes; ++k) {
         const Shape& s = kShapes[k];
         const double tile = tile_cost(s, kc, nch);
         if (tile < 0) continue;
         const int bg = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
-        const int64_t mtiles = (groups + bg - 1) / bg;
-        const int64_t ntiles = (n16 + bnt - 1) / bnt;
-        const int64_t tiles = mtiles * ntiles;
-        const int64_t rounds = (tiles + num_cu - 1) / num_cu;
-        const double cost = (double)rounds * tile;
+        const int64_t tiles = ((groups + bg - 1) / bg) * ((n16 + bnt - 1) / bnt);
+        const double cost = (double)((tiles + num_cu - 1) / num_cu) * tile;
         if (cost < best_cost) {
             best_cost = cost;
             best = &s;
+            best_tiles = tiles;
+        }
+    }
+    const bool thin = allow_thin && best && best_tiles < num_cu;
+    if (thin) {
+        best_cost = 1e300;
+        for (int k = 0; k < kNumShapes; ++k) {
+            const Shape& s = kShapes[k];
+            const int bg = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
+            const int64_t tiles = ((groups + bg - 1) / bg) * ((n16 + bnt - 1) / bnt);
+            const double fill = std::min(1.0, (double)tiles / num_cu);
+            for (int per_cu = 1; per_cu <= (s.wm * s.wn == 4 ? 2 : 1); ++per_cu) {
+                const double tile = thin_tile_cost(s, kc, nch, per_cu, fill);
+                if (tile < 0) continue;
+                const int64_t slots_ = (int64_t)num_cu * per_cu;
+                const double cost = (double)((tiles + slots_ - 1) / slots_) * tile;
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best = &s;
+                    best_per_cu = per_cu;
+                }
+            }
         }
     }
     if (cost_out) *cost_out = best_cost;
+    if (per_cu_out) *per_cu_out = best_per_cu;
+    if (thin_out) *thin_out = thin;
     return best;
 }
 
@@ -497,8 +604,18 @@ bool conv_wino4_shape_ok(const ConvLayerDev& L, int k) {
 // rs_model_create pick the channel chunk (which fixes the weight packing) with the tile shapes it enables in mind
 double conv_wino4_plan_cost(int64_t groups, int n16, int kc, int nch, int num_cu) {
     double cost = 1e300;
-    choose_shape(groups, n16, kc, nch, num_cu, &cost);
+    choose_shape(groups, n16, kc, nch, num_cu, &cost, nullptr, false);
     return cost;
+}
+
+// estimate of one launch INCLUDING its launch cost where the thin-launch fit applies (*thin_out), for the choice between
+// this kernel and conv_small_f32 (whose fit includes its launch as well)
+double conv_wino4_launch_cost(int64_t groups, int n16, int kc, int nch, int num_cu, bool* thin_out) {
+    double cost = 1e300;
+    bool thin = false;
+    choose_shape(groups, n16, kc, nch, num_cu, &cost, nullptr, true, &thin);
+    if (thin_out) *thin_out = thin;
+    return thin ? cost + kThinLaunch : cost;
 }
 
 int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
@@ -518,7 +635,8 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
     const int n16 = round_up(L.c_out, 16) / 16;
     const int64_t groups = (rows64 + 3) / 4;
     double single_cost = 0.0;
-    const Shape* s = choose_shape(groups, n16, p.kc, p.nch, num_cu, &single_cost);
+    int per_cu = 1;
+    const Shape* s = choose_shape(groups, n16, p.kc, p.nch, num_cu, &single_cost, &per_cu);
     bool pinned = false;                                          // a forced or tuned shape runs as one launch
     if (const char* force = L.hooks->force_wino4; *force) {       // tuning aid: "layer:wm,wn,mt,nt;..."
         int l, wm, wn, mt, nt;
@@ -529,11 +647,13 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
                         lds_bytes(kShapes[k], p.kc) <= 160 * 1024) {
                         s = &kShapes[k];
                         pinned = true;
+                        per_cu = 1;
                     }
     }
     if (const int k = tuned_shape(L, rows64); k >= 0 && conv_wino4_shape_ok(L, k)) {
         s = &kShapes[k];
         pinned = true;
+        per_cu = 1;
     }
     if (!s) {
         set_error("conv_wino4: no tile shape fits (kc=%d)", p.kc);
@@ -561,18 +681,20 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
     a.nch = p.nch;
     a.shift_out = layer_index + 1;
     // one launch over the row tiles [m_base, m_base + n_mtiles x BG) of shape sh
-    auto launch_part = [&](const Shape& sh, int m_base, int n_mtiles) -> int {
+    auto launch_part = [&](const Shape& sh, int m_base, int n_mtiles, int wg_per_cu) -> int {
         const int BN = sh.wn * 16 * sh.nt;
         const int n_ntiles = (n16 * 16 + BN - 1) / BN;
         const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
-        const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-        a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 4.0 * sh.wm * 16 * sh.mt, 6.0 * BN, check_dead,
+        const int slots_ = num_cu * wg_per_cu;
+        const unsigned grid = (unsigned)std::min<int64_t>(tiles, slots_);
+        a.walk = plan_walk(n_mtiles, n_ntiles, grid, slots_, 4.0 * sh.wm * 16 * sh.mt, 6.0 * BN, check_dead,
                            !L.hooks->no_rect_order);
         a.walk.m_base = m_base;
         KernelFn fn = sh.fn[p.kc == 16 ? 0 : 1];
+        if (KernelFn d = sh.deep[p.kc == 16 ? 0 : 1]; d && !L.hooks->no_deep_staging) fn = d;
         RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds_bytes(sh, p.kc), st, a);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * sh.wm * sh.wn), lds_bytes(sh, p.kc), st, a);
         RS_HIP(hipGetLastError());
         return RS_OK;
     };
@@ -583,26 +705,32 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
             [&](int k) { return kShapes[k].wm * 16 * kShapes[k].mt; },
             [&](int k) { return (n16 + kShapes[k].wn * kShapes[k].nt - 1) / (kShapes[k].wn * kShapes[k].nt); },
             [&](int64_t g, double* c) {
-                const Shape* t = choose_shape(g, n16, p.kc, p.nch, num_cu, c);
+                // priced with the full-launch calibration like the head (one scale); the tail itself runs the shape the
+                // thin-launch fit picks for its rows (never slower than this one)
+                const Shape* t = choose_shape(g, n16, p.kc, p.nch, num_cu, c, nullptr, false);
                 return t ? (int)(t - kShapes) : -1;
             });
     int BG, BN;
     if (split.head_shape >= 0) {
-        const Shape &h = kShapes[split.head_shape], &t = kShapes[split.tail_shape];
-        if (L.hooks->tail_debug)
-            fprintf(stderr, "[tail-split] layer %d: head %dx%dx%dx%d x %d row tiles, tail %dx%dx%dx%d; planned %.0f vs %.0f cycles\n",
-                    layer_index, h.wm, h.wn, h.mt, h.nt, split.head_mtiles, t.wm, t.wn, t.mt, t.nt, split.cost, single_cost);
+        const Shape& h = kShapes[split.head_shape];
         BG = h.wm * 16 * h.mt;
         BN = h.wn * 16 * h.nt;
-        int rc = launch_part(h, 0, split.head_mtiles);
+        const int m_base = split.head_mtiles * BG;
+        int tail_per_cu = 1;
+        const Shape* tp = choose_shape(groups - m_base, n16, p.kc, p.nch, num_cu, nullptr, &tail_per_cu);
+        const Shape& t = tp ? *tp : kShapes[split.tail_shape];
+        if (L.hooks->tail_debug)
+            fprintf(stderr, "[tail-split] layer %d: head %dx%dx%dx%d x %d row tiles, tail %dx%dx%dx%d (%d per CU); planned %.0f vs %.0f cycles\n",
+                    layer_index, h.wm, h.wn, h.mt, h.nt, split.head_mtiles, t.wm, t.wn, t.mt, t.nt, tail_per_cu, split.cost, single_cost);
+        int rc = launch_part(h, 0, split.head_mtiles, 1);
         if (rc != RS_OK) return rc;
-        const int m_base = split.head_mtiles * BG, tbg = t.wm * 16 * t.mt;
-        rc = launch_part(t, m_base, (int)((groups - m_base + tbg - 1) / tbg));
+        const int tbg = t.wm * 16 * t.mt;
+        rc = launch_part(t, m_base, (int)((groups - m_base + tbg - 1) / tbg), tail_per_cu);
         if (rc != RS_OK) return rc;
     } else {
         BG = s->wm * 16 * s->mt;
         BN = s->wn * 16 * s->nt;
-        const int rc = launch_part(*s, 0, (a.n_groups + BG - 1) / BG);
+        const int rc = launch_part(*s, 0, (a.n_groups + BG - 1) / BG, per_cu);
         if (rc != RS_OK) return rc;
     }
     if (bm_out) *bm_out = 4 * BG;           // reported in conv rows, like the other kernels

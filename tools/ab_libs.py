@@ -1,4 +1,5 @@
-"""A/B two builds of the library in one process launch sequence (alternating), per-step time of dtype $RS_DT (default f32)."""
+"""A/B two builds of the library in one process launch sequence (alternating), per-step time of dtype $RS_DT (default f32) at
+$RS_B x $RS_L (default 512 x 16000)."""
 import sys, os, subprocess, json
 libs = sys.argv[1:]
 code = r'''
@@ -8,7 +9,7 @@ import numpy as np, torch
 from riser_amd import synth
 from riser_amd.model import Model
 from riser_amd.preprocess import pack_reads
-B, L = 512, 16000
+B, L = int(os.environ.get("RS_B", 512)), int(os.environ.get("RS_L", 16000))
 sigs = synth.make_signals(20260103, B, L)
 dev = torch.device("cuda", 0)
 sig, off, ln, lens = pack_reads(list(sigs), dev)
@@ -16,8 +17,9 @@ m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=os.envir
 out = torch.empty((B, 2), device=dev)
 for _ in range(5): m.classify_raw(sig, off, ln, lens, out=out)
 torch.cuda.synchronize(); t = time.perf_counter()
-for _ in range(30): m.classify_raw(sig, off, ln, lens, out=out)
-torch.cuda.synchronize(); print("%.4f" % ((time.perf_counter() - t) / 30 * 1e3))
+N = 30 if B >= 256 else 200
+for _ in range(N): m.classify_raw(sig, off, ln, lens, out=out)
+torch.cuda.synchronize(); print("%.4f" % ((time.perf_counter() - t) / N * 1e3))
 '''
 res = {l: [] for l in libs}
 for rnd in range(3):
