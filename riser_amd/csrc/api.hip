@@ -879,7 +879,9 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         const bool wres = ring && conv_wres_h16_ok(L, x3);
         // fp32 Winograd layers of a launch with only a handful of rows (Model.classify at batch 1, a thin ReadUntil batch):
         // one wave per 16 x 16 tile instead of 256-row tiles that are mostly padding (conv_small_f32.hip; same bits)
-        bool small32 = m->dtype == RS_F32W && !stream32 && !m->tuning && m->hooks.small_f32_waves != 0 && conv_small_f32_ok(L);
+        // (not layer 1 when layer 0 is folded into its staging: nothing has written that layer's input)
+        bool small32 = m->dtype == RS_F32W && !stream32 && !(fuse0 && i == 1) && !m->tuning && m->hooks.small_f32_waves != 0 &&
+                       conv_small_f32_ok(L);
         if (small32) {
             const int64_t rows_in = (int64_t)NB * P_in;
             if (m->hooks.small_f32_waves > 0)                           // forced limit (tests, A/B runs)
@@ -891,9 +893,13 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                 bool thin_fit = false;                               // the tiled estimate is the thin-launch fit (with its launch cost: like the small kernel's)
                 const double tiled = L.wino_m == 4
                     ? conv_wino4_launch_cost((rows_in + 3) / 4, n16, L.plan.kc, L.plan.nch, m->num_cu, &thin_fit)
-                    : conv_wino_plan_cost(rows_in / 2, n16, L.plan.kc, L.plan.nch, m->num_cu);
+                    : conv_wino_launch_cost(rows_in / 2, n16, L.plan.kc, L.plan.nch, m->num_cu, &thin_fit);
                 small32 = conv_small_f32_waves(L, rows_in) <= 4096 &&
                           conv_small_f32_cost(L, rows_in, m->num_cu) < (thin_fit ? 1.0 : 0.8) * tiled;
+                if (m->hooks.tail_debug)
+                    fprintf(stderr, "[small-or-tiled] layer %d: rows %lld, small %.0f (%lld workgroups), tiled %.0f (%s) -> %s\n", i,
+                            (long long)rows_in, conv_small_f32_cost(L, rows_in, m->num_cu), (long long)conv_small_f32_waves(L, rows_in),
+                            tiled, thin_fit ? "thin fit + launch" : "full-launch model", small32 ? "small" : "tiled");
             }
         }
         const int kind = (stream32 || stream16 || wres || small32) ? 0 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)

@@ -177,6 +177,7 @@ bool conv_small_f32_ok(const ConvLayerDev& L);
 int64_t conv_small_f32_waves(const ConvLayerDev& L, int64_t rows_in);        // workgroups (16 x 16 tiles) of such a launch
 double conv_small_f32_cost(const ConvLayerDev& L, int64_t rows_in, int num_cu);   // estimate, shader cycles
 double conv_wino_plan_cost(int64_t rows_out, int n16, int kc, int nch, int num_cu);
+double conv_wino_launch_cost(int64_t rows_out, int n16, int kc, int nch, int num_cu, bool* thin_out);
 int launch_conv_small_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
                           int layer_index, hipStream_t st, int* bm_out, int* bn_out);
 // narrow 16-bit layers (C_in <= 32, C_out <= 48): per-wave streaming kernel, optionally with ConvNet

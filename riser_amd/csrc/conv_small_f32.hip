@@ -347,7 +347,10 @@ double conv_small_f32_cost(const ConvLayerDev& L, int64_t rows_in, int num_cu) {
     const double per_step = L.wino_m == 4 ? 350.0 : 200.0;
     const int64_t per_cu = (conv_small_f32_waves(L, rows_in) + num_cu - 1) / num_cu;
     const double chains = 1.0 + (L.wino_m == 4 ? 1.0 : 0.65) * (double)(per_cu > 1 ? per_cu - 1 : 0);
-    return ksteps * per_step * chains + 6000.0;
+    // + launch, prologue and the timing events' own cost, like the tiled kernels' thin-launch fit it is compared with
+    // (round 5: with 6000 the early layers of an 8-read batch - 12-18 k-steps, 5-7 workgroups per CU - went to this kernel
+    // at 23 us where the tiled one takes 13-18)
+    return ksteps * per_step * chains + 20000.0;
 }
 
 bool conv_small_f32_ok(const ConvLayerDev& L) { return pick(L.wino_m == 4 ? 6 : 4, L.plan.kc) != nullptr; }

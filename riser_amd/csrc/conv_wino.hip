@@ -42,6 +42,19 @@
 #include <algorithm>
 #include <utility>
 
+// thin-launch fit of the planner (thin_tile_cost below): layer 11 at 16 ... 64 reads, every shape (tools/shape_sweep.py;
+// profiles/r05_wino_shape_sweep_16_to_512_reads.txt).  Launch, byte and per-tile terms are conv_wino4.hip's.
+#ifndef RS_WINO_THIN_LAUNCH
+#define RS_WINO_THIN_LAUNCH 23500.0
+#define RS_WINO_THIN_SLOT 60.0
+#define RS_WINO_THIN_SLOT_MN 4.25
+#define RS_WINO_THIN_ITEM (-250.0)
+#define RS_WINO_THIN_BYTE 0.0062
+#define RS_WINO_THIN_BYTE_FILL 0.0124
+#define RS_WINO_THIN_TILE (-467.0)
+#define RS_WINO_THIN_TILE_MN 554.0
+#endif
+
 namespace rs {
 namespace {
 
@@ -88,11 +101,16 @@ struct WinoArgs {
     int n_reads;
 };
 
-template <int WM, int WN, int MT, int NT, int KCT, bool FUSE0 = false>
+// DEEP (thin launches, see conv_wino4.hip): the staging loads of an item are issued ONE ITEM earlier and stay in registers
+// across the barrier.  Four-wave workgroups (one wave per SIMD) for launches of fewer tiles than CUs.  Same MFMA sequence
+// per accumulator: same bits.  (The launch bound stays 512 for the four-wave shapes: a bound of 256 makes the compiler
+// keep the accumulators in AGPRs, with a copy in and out per item.)
+template <int WM, int WN, int MT, int NT, int KCT, bool FUSE0 = false, bool DEEP = false>
 __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
-    static_assert(WM * WN == 8, "8 waves per workgroup (2 per SIMD)");
+    static_assert(WM * WN == 8 || WM * WN == 4, "8 or 4 waves per workgroup");
     static_assert(KCT % 4 == 0 && KCT >= 8, "channel chunk");
-    constexpr int kThreads = 512;
+    static_assert(!(FUSE0 && DEEP), "the fused layer-0 staging keeps the default schedule");
+    constexpr int kThreads = 64 * WM * WN;
     constexpr int BMP = WM * 16 * MT;                  // pooled rows per tile
     constexpr int BN = WN * 16 * NT;
     constexpr int S = KCT + 2;
@@ -299,6 +317,21 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
     item_offsets(m0, n0, 0, true);
     static_for<A_PER + B_PER>([&](auto U) { load_unit(U); });
     static_for<A_PER + B_PER>([&](auto U) { store_unit(U, lds); });
+    // the item after (oo, cc) of this workgroup's walk; oo >= tiles: none
+    auto advance = [&](int& oo, int& cc, int& mm, int& nn) {
+        if (oo >= tiles) return;
+        if (++cc == a.nch) {
+            cc = 0;
+            oo = next_live();
+            if (oo < tiles) tile_origin(oo, mm, nn);
+        }
+    };
+    int o1 = o, c1 = 0, m1 = m0, n1 = n0;              // DEEP: the next item, already on its way in ra / rb
+    if constexpr (DEEP) {
+        advance(o1, c1, m1, n1);
+        item_offsets(m1, n1, c1, o1 < tiles);
+        static_for<A_PER + B_PER>([&](auto U) { load_unit(U); });
+    }
     __syncthreads();
     int buf = 0;
 
@@ -307,17 +340,25 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
 
     while (true) {
         int nc = c + 1, no = o;
-        if (nc == a.nch) {
+        int nm0 = m0, nn0 = n0;
+        int o2 = o1, c2 = c1, m2 = m1, n2 = n1;
+        if constexpr (DEEP) {
+            nc = c1, no = o1, nm0 = m1, nn0 = n1;
+            advance(o2, c2, m2, n2);
+        } else if (nc == a.nch) {
             nc = 0;
             no = next_live();
         }
         const bool has_next = no < tiles;
-        int nm0 = m0, nn0 = n0;
-        if (has_next && nc == 0) tile_origin(no, nm0, nn0);
+        if constexpr (!DEEP)
+            if (has_next && nc == 0) tile_origin(no, nm0, nn0);
         const float* Ab = lds + buf * BUF + a_rd;
         const float* Bb = lds + buf * BUF + b_rd;
         float* nbuf = lds + (buf ^ 1) * BUF;
-        item_offsets(nm0, nn0, nc, has_next);
+        if constexpr (DEEP)
+            item_offsets(m2, n2, c2, o2 < tiles);
+        else
+            item_offsets(nm0, nn0, nc, has_next);
 
         constexpr int NSLOTS = 4 * KQ;                 // slot = (k-step, component): MT * NT MFMAs
         constexpr int UNITS = A_PER + B_PER;
@@ -344,8 +385,13 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
         u32x4 bi_[NT];
         auto run_item = [&](auto FIRST) {
             constexpr bool first = decltype(FIRST)::value;     // first item of a tile: accumulate onto zero
+            // a slot of the thin shapes is one or two MFMAs (32 / 64 cycles): an LDS read issued one slot ahead is not back
+            // in time - their weight fragments are read four (two) slots ahead, the raw rows right behind the transform
+            constexpr bool THIN = MT * NT <= 2;
+            constexpr int AH = THIN ? 4 / (MT * NT) : 1;   // slots of look-ahead of the weight-fragment reads
+            constexpr int RD = THIN ? 0 : 1;               // component slot that reads the raw rows of the next k-step
             float dr[MT][4];                           // raw inputs d0..d3 of the lane's pooled rows (next k-step)
-            float uf[2][NT];                           // weight fragments, double-buffered per slot
+            float uf[AH + 1][NT];                      // weight fragments, a ring over the slots in flight
             float v[MT][4];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -354,8 +400,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
                 dr[i][1] = Ab[PL + i * 16 * S];
                 dr[i][3] = Ab[PL + i * 16 * S + S];
             }
+            static_for<AH>([&](auto SL) {
+                constexpr int sl = decltype(SL)::value;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) uf[0][j] = Bb[j * 16 * S];
+                for (int j = 0; j < NT; ++j) uf[sl][j] = Bb[((sl & 3) * BN + j * 16) * S + 4 * (sl >> 2)];
+            });
             static_for<NSLOTS>([&](auto SL) {
                 constexpr int sl = decltype(SL)::value;
                 constexpr int st = sl >> 2, comp = sl & 3;
@@ -376,7 +425,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
 #endif
                     }
                 }
-                if constexpr (comp == 1 && st + 1 < KQ) {
+                if constexpr (comp == RD && st + 1 < KQ) {
                     constexpr int c0 = 4 * (st + 1);
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
@@ -386,10 +435,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
                         dr[i][3] = Ab[PL + i * 16 * S + S + c0];
                     }
                 }
-                if constexpr (sl + 1 < NSLOTS) {
-                    constexpr int nst = (sl + 1) >> 2, ncomp = (sl + 1) & 3;
+                if constexpr (sl + AH < NSLOTS) {
+                    constexpr int nst = (sl + AH) >> 2, ncomp = (sl + AH) & 3;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) uf[(sl + 1) & 1][j] = Bb[(ncomp * BN + j * 16) * S + 4 * nst];
+                    for (int j = 0; j < NT; ++j) uf[(sl + AH) % (AH + 1)][j] = Bb[(ncomp * BN + j * 16) * S + 4 * nst];
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -397,15 +446,15 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
                     for (int j = 0; j < NT; ++j) {
                         if constexpr (first && st == 0)
                             acc[i][j][comp] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                uf[sl & 1][j], v[i][comp], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                                uf[sl % (AH + 1)][j], v[i][comp], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                         else
-                            acc[i][j][comp] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl & 1][j], v[i][comp],
+                            acc[i][j][comp] = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[sl % (AH + 1)][j], v[i][comp],
                                                                                    acc[i][j][comp], 0, 0, 0);
                     }
 #ifndef RS_WINO_NO_SGB2
                 {   // one LDS read in the shadow of each of the first MFMAs, so the next slot's fragments are
                     // in flight early without a read burst ahead of the MFMAs
-                    constexpr int n_rd = (sl + 1 < NSLOTS ? NT : 0) + ((comp == 1 && st + 1 < KQ) ? 2 * MT : 0);
+                    constexpr int n_rd = (sl + AH < NSLOTS ? NT : 0) + ((comp == RD && st + 1 < KQ) ? 2 * MT : 0);
                     constexpr int n_pair = n_rd < MT * NT ? n_rd : MT * NT;
                     static_for<n_pair>([&](auto) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -417,9 +466,18 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<UNITS>([&](auto U) {
                     constexpr int u = decltype(U)::value;
-                    if constexpr ((u * SPAN) / UNITS == sl) load_unit(U);
-                    if constexpr ((u * SPAN) / UNITS + DIST == sl) {
-                        if (has_next) store_unit(U, nbuf);
+                    if constexpr (DEEP) {
+                        // the unit loaded during the previous item goes to the next item's buffer, and its registers
+                        // leave again for the item after that
+                        if constexpr ((u * NSLOTS) / UNITS == sl) {
+                            if (has_next) store_unit(U, nbuf);
+                            load_unit(U);
+                        }
+                    } else {
+                        if constexpr ((u * SPAN) / UNITS == sl) load_unit(U);
+                        if constexpr ((u * SPAN) / UNITS + DIST == sl) {
+                            if (has_next) store_unit(U, nbuf);
+                        }
                     }
                 });
                 if constexpr (HOIST && sl == EPI_SLOT) {
@@ -511,6 +569,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoArgs a) {
         c = nc;
         m0 = nm0;
         n0 = nn0;
+        if constexpr (DEEP) o1 = o2, c1 = c2, m1 = m2, n1 = n2;
     }
 }
 
@@ -519,6 +578,7 @@ using KernelFn = void (*)(const WinoArgs);
 struct Shape {
     int wm, wn, mt, nt;
     KernelFn fn[3];        // chunk = 16, 20, 24
+    KernelFn deep[3];      // the same tile with staging loads one item ahead (thin launches), or null
 };
 // layer 1 of the shipped net (20 -> 30 channels) with layer 0 folded into its staging
 const KernelFn kFusedL1 = conv_wino_kernel<8, 1, 2, 2, 20, true>;
@@ -526,7 +586,16 @@ constexpr int kFusedBMP = 8 * 16 * 2, kFusedBN = 32;
 
 #define RS_SHAPE(WM, WN, MT, NT)                                                                       \
     {WM, WN, MT, NT, {conv_wino_kernel<WM, WN, MT, NT, 16>, conv_wino_kernel<WM, WN, MT, NT, 20>,     \
-                      conv_wino_kernel<WM, WN, MT, NT, 24>}}
+                      conv_wino_kernel<WM, WN, MT, NT, 24>}, {nullptr, nullptr, nullptr}}
+#define RS_SHAPE_D(WM, WN, MT, NT)                                                                                 \
+    {WM, WN, MT, NT, {conv_wino_kernel<WM, WN, MT, NT, 16>, conv_wino_kernel<WM, WN, MT, NT, 20>,                 \
+                      conv_wino_kernel<WM, WN, MT, NT, 24>},                                                      \
+     {conv_wino_kernel<WM, WN, MT, NT, 16, false, true>, conv_wino_kernel<WM, WN, MT, NT, 20, false, true>,       \
+      conv_wino_kernel<WM, WN, MT, NT, 24, false, true>}}
+// four-wave shapes exist in the one-item-ahead form only
+#define RS_SHAPE_4(WM, WN, MT, NT)                                                                                        \
+    {WM, WN, MT, NT, {conv_wino_kernel<WM, WN, MT, NT, 16, false, true>, conv_wino_kernel<WM, WN, MT, NT, 20, false, true>, \
+                      conv_wino_kernel<WM, WN, MT, NT, 24, false, true>}, {nullptr, nullptr, nullptr}}
 const Shape kShapes[] = {
     // all 8 waves stacked along pooled rows
     RS_SHAPE(8, 1, 2, 2), RS_SHAPE(8, 1, 2, 3), RS_SHAPE(8, 1, 2, 4), RS_SHAPE(8, 1, 1, 5), RS_SHAPE(8, 1, 1, 6),
@@ -536,10 +605,15 @@ const Shape kShapes[] = {
     // 2 x 4 waves (few rows)
     RS_SHAPE(2, 4, 2, 2), RS_SHAPE(2, 4, 2, 3), RS_SHAPE(2, 4, 1, 4),
     // small tiles (round 4): a batch of 32 ... 200 reads leaves the late layers a few dozen tiles of the shapes above
-    RS_SHAPE(8, 1, 1, 2), RS_SHAPE(8, 1, 1, 3), RS_SHAPE(8, 1, 1, 4), RS_SHAPE(4, 2, 1, 2), RS_SHAPE(4, 2, 1, 3),
-    RS_SHAPE(4, 2, 1, 4), RS_SHAPE(2, 4, 1, 2), RS_SHAPE(2, 4, 1, 1),
+    RS_SHAPE_D(8, 1, 1, 2), RS_SHAPE(8, 1, 1, 3), RS_SHAPE(8, 1, 1, 4), RS_SHAPE_D(4, 2, 1, 2), RS_SHAPE(4, 2, 1, 3),
+    RS_SHAPE(4, 2, 1, 4), RS_SHAPE_D(2, 4, 1, 2), RS_SHAPE_D(2, 4, 1, 1),
+    // four-wave workgroups (round 5): one wave per SIMD, for launches of fewer tiles than CUs
+    RS_SHAPE_4(4, 1, 1, 1), RS_SHAPE_4(2, 2, 1, 1), RS_SHAPE_4(4, 1, 1, 2), RS_SHAPE_4(2, 2, 1, 2), RS_SHAPE_4(1, 4, 1, 2),
+    RS_SHAPE_4(4, 1, 1, 3), RS_SHAPE_4(2, 2, 1, 3),
 };
 #undef RS_SHAPE
+#undef RS_SHAPE_D
+#undef RS_SHAPE_4
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
 size_t lds_bytes(const Shape& s, int kc) {
@@ -548,9 +622,10 @@ size_t lds_bytes(const Shape& s, int kc) {
 }
 
 // Tile shape for a layer launch.  Model: one persistent workgroup per CU; time = rounds x (MFMA
-// issue of a tile + per-item staging and barrier + per-tile epilogue), in SIMD cycles.
+// issue of a tile + per-item staging and barrier + per-tile epilogue), in SIMD cycles.  Full launches (at least one tile
+// per CU), eight-wave shapes; calibrated at B = 512.
 double tile_cost(const Shape& s, int kc, int nch) {
-    if (lds_bytes(s, kc) > 160 * 1024) return -1.0;
+    if (lds_bytes(s, kc) > 160 * 1024 || s.wm * s.wn != 8) return -1.0;
     const int bmp = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
     const double slots = kc;                                    // 4 components x kc / 4 k-steps
     const double staged = ((2.0 * bmp + 2) + 4.0 * bnt * 16) * kc * 4.0;   // bytes per item
@@ -558,25 +633,66 @@ double tile_cost(const Shape& s, int kc, int nch) {
     return nch * item + 1500.0 + 60.0 * s.mt * s.nt;
 }
 
-const Shape* choose_shape(int64_t rows_out, int n16, int kc, int nch, int num_cu, double* cost_out) {
+// THIN launches (fewer tiles than CUs): least-squares fit over tools/shape_sweep.py at 16 ... 512 reads, layers 4 and 11,
+// every shape (see conv_wino4.hip: the MFMAs of a SIMD's waves add up, the rest of a slot does not depend on the waves per
+// SIMD, staged bytes cost more the more CUs stream).  per_cu: workgroups of a four-wave shape resident on one CU.
+constexpr double kThinLaunch = RS_WINO_THIN_LAUNCH;
+double thin_tile_cost(const Shape& s, int kc, int nch, int per_cu, double fill) {
+    if (lds_bytes(s, kc) * per_cu > 160 * 1024) return -1.0;
+    const int bmp = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
+    const double slots = kc;
+    const double staged = ((2.0 * bmp + 2) + 4.0 * bnt * 16) * kc * 4.0 * per_cu;
+    const double wps = s.wm * s.wn * per_cu / 4.0;
+    const double item = slots * (wps * s.mt * s.nt * 32.0 + RS_WINO_THIN_SLOT + RS_WINO_THIN_SLOT_MN * (s.mt + s.nt)) + RS_WINO_THIN_ITEM +
+                        staged * (RS_WINO_THIN_BYTE + RS_WINO_THIN_BYTE_FILL * fill);
+    return nch * item + RS_WINO_THIN_TILE + RS_WINO_THIN_TILE_MN * s.mt * s.nt;
+}
+
+// best shape for a launch over `rows_out` pooled rows: the B = 512 calibration over the eight-wave shapes; when that launch
+// leaves CUs idle (and thin is allowed), the thin-launch fit over every shape, four-wave ones at one or two per CU.
+const Shape* choose_shape(int64_t rows_out, int n16, int kc, int nch, int num_cu, double* cost_out, int* per_cu_out = nullptr,
+                          bool allow_thin = true, bool* thin_out = nullptr) {
     const Shape* best = nullptr;
     double best_cost = 1e300;
+    int best_per_cu = 1;
+    int64_t best_tiles = 0;
     for (int k = 0; k < kNumShapes; ++k) {
         const Shape& s = kShapes[k];
         const double tile = tile_cost(s, kc, nch);
         if (tile < 0) continue;
         const int bmp = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
-        const int64_t mtiles = (rows_out + bmp - 1) / bmp;
-        const int64_t ntiles = (n16 + bnt - 1) / bnt;
-        const int64_t tiles = mtiles * ntiles;
-        const int64_t rounds = (tiles + num_cu - 1) / num_cu;
-        const double cost = (double)rounds * tile;
+        const int64_t tiles = ((rows_out + bmp - 1) / bmp) * ((n16 + bnt - 1) / bnt);
+        const double cost = (double)((tiles + num_cu - 1) / num_cu) * tile;
         if (cost < best_cost) {
             best_cost = cost;
             best = &s;
+            best_tiles = tiles;
+        }
+    }
+    const bool thin = allow_thin && best && best_tiles < num_cu;
+    if (thin) {
+        best_cost = 1e300;
+        for (int k = 0; k < kNumShapes; ++k) {
+            const Shape& s = kShapes[k];
+            const int bmp = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
+            const int64_t tiles = ((rows_out + bmp - 1) / bmp) * ((n16 + bnt - 1) / bnt);
+            const double fill = std::min(1.0, (double)tiles / num_cu);
+            for (int per_cu = 1; per_cu <= (s.wm * s.wn == 4 ? 2 : 1); ++per_cu) {
+                const double tile = thin_tile_cost(s, kc, nch, per_cu, fill);
+                if (tile < 0) continue;
+                const int64_t slots_ = (int64_t)num_cu * per_cu;
+                const double cost = (double)((tiles + slots_ - 1) / slots_) * tile;
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best = &s;
+                    best_per_cu = per_cu;
+                }
+            }
         }
     }
     if (cost_out) *cost_out = best_cost;
+    if (per_cu_out) *per_cu_out = best_per_cu;
+    if (thin_out) *thin_out = thin;
     return best;
 }
 
@@ -586,8 +702,17 @@ int conv_wino_max_bn() { return 256; }
 // planner's estimate (SIMD cycles) of one launch with the best tile shape (compared with the small-batch kernel's in api.hip)
 double conv_wino_plan_cost(int64_t rows_out, int n16, int kc, int nch, int num_cu) {
     double cost = 1e300;
-    choose_shape(rows_out, n16, kc, nch, num_cu, &cost);
+    choose_shape(rows_out, n16, kc, nch, num_cu, &cost, nullptr, false);
     return cost;
+}
+// estimate of one launch INCLUDING its launch cost where the thin-launch fit applies (*thin_out): for the choice between
+// this kernel and conv_small_f32 (whose fit includes its launch as well)
+double conv_wino_launch_cost(int64_t rows_out, int n16, int kc, int nch, int num_cu, bool* thin_out) {
+    double cost = 1e300;
+    bool thin = false;
+    choose_shape(rows_out, n16, kc, nch, num_cu, &cost, nullptr, true, &thin);
+    if (thin_out) *thin_out = thin;
+    return thin ? cost + kThinLaunch : cost;
 }
 int conv_wino_num_shapes() { return kNumShapes; }
 bool conv_wino_shape_ok(const ConvLayerDev& L, int k) {
@@ -617,7 +742,8 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
     }
     const int n16 = round_up(L.c_out, 16) / 16;
     double single_cost = 0.0;
-    const Shape* s = choose_shape(rows64 / 2, n16, p.kc, p.nch, num_cu, &single_cost);
+    int per_cu = 1;
+    const Shape* s = choose_shape(rows64 / 2, n16, p.kc, p.nch, num_cu, &single_cost, &per_cu);
     bool pinned = false;                                          // a forced, fused or tuned shape runs as one launch
     if (const char* force = L.hooks->force_wino; *force) {        // tuning aid: "layer:wm,wn,mt,nt;..."
         int l, wm, wn, mt, nt;
@@ -628,11 +754,13 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
                         lds_bytes(kShapes[k], p.kc) <= 160 * 1024) {
                         s = &kShapes[k];
                         pinned = true;
+                        per_cu = 1;
                     }
     }
     const bool fused = fuse_xs != nullptr;
     if (fused) {
         pinned = true;
+        per_cu = 1;
         if (!conv_wino_can_fuse0(L, P_in) || !fuse_w0) {
             set_error("conv_wino: layer cannot take the fused layer-0 path");
             return RS_ERR_ARG;
@@ -643,6 +771,7 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
     if (const int k = tuned_shape(L, rows64); k >= 0 && conv_wino_shape_ok(L, k)) {
         s = &kShapes[k];
         pinned = true;
+        per_cu = 1;
     }
     if (!s) {
         set_error("conv_wino: no tile shape fits (kc=%d)", p.kc);
@@ -687,18 +816,21 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
     a.nch = p.nch;
     a.shift_out = layer_index + 1;
     // one launch over the row tiles [m_base, m_base + n_mtiles x BMP) of shape sh
-    auto launch_part = [&](const Shape& sh, int m_base, int n_mtiles) -> int {
+    auto launch_part = [&](const Shape& sh, int m_base, int n_mtiles, int wg_per_cu) -> int {
         const int BN_ = sh.wn * 16 * sh.nt;
-        KernelFn fn = fused ? kFusedL1 : sh.fn[p.kc == 16 ? 0 : p.kc == 20 ? 1 : 2];
+        const int ki = p.kc == 16 ? 0 : p.kc == 20 ? 1 : 2;
+        KernelFn fn = fused ? kFusedL1 : sh.fn[ki];
+        if (KernelFn d = sh.deep[ki]; d && !fused && !L.hooks->no_deep_staging) fn = d;
         RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
         const int n_ntiles = (n16 * 16 + BN_ - 1) / BN_;
         const int64_t tiles = (int64_t)n_mtiles * n_ntiles;
-        const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
-        a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, 2.0 * sh.wm * 16 * sh.mt, 4.0 * BN_, check_dead,
+        const int slots_ = num_cu * wg_per_cu;
+        const unsigned grid = (unsigned)std::min<int64_t>(tiles, slots_);
+        a.walk = plan_walk(n_mtiles, n_ntiles, grid, slots_, 2.0 * sh.wm * 16 * sh.mt, 4.0 * BN_, check_dead,
                            !L.hooks->no_rect_order);
         a.walk.m_base = m_base;
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds_bytes(sh, p.kc), st, a);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(fused ? 512 : 64 * sh.wm * sh.wn), lds_bytes(sh, p.kc), st, a);
         RS_HIP(hipGetLastError());
         return RS_OK;
     };
@@ -709,26 +841,32 @@ int launch_conv_wino(const ConvLayerDev& L, const float* d_x, float* d_y, const 
             [&](int k) { return kShapes[k].wm * 16 * kShapes[k].mt; },
             [&](int k) { return (n16 + kShapes[k].wn * kShapes[k].nt - 1) / (kShapes[k].wn * kShapes[k].nt); },
             [&](int64_t r, double* c) {
-                const Shape* t = choose_shape(r, n16, p.kc, p.nch, num_cu, c);
+                // priced with the full-launch calibration like the head (one scale); the tail itself runs the shape the
+                // thin-launch fit picks for its rows
+                const Shape* t = choose_shape(r, n16, p.kc, p.nch, num_cu, c, nullptr, false);
                 return t ? (int)(t - kShapes) : -1;
             });
     int BMP, BN;
     if (split.head_shape >= 0) {
-        const Shape &h = kShapes[split.head_shape], &t = kShapes[split.tail_shape];
-        if (L.hooks->tail_debug)
-            fprintf(stderr, "[tail-split] layer %d: head %dx%dx%dx%d x %d row tiles, tail %dx%dx%dx%d; planned %.0f vs %.0f cycles\n",
-                    layer_index, h.wm, h.wn, h.mt, h.nt, split.head_mtiles, t.wm, t.wn, t.mt, t.nt, split.cost, single_cost);
+        const Shape& h = kShapes[split.head_shape];
         BMP = h.wm * 16 * h.mt;
         BN = h.wn * 16 * h.nt;
-        int rc = launch_part(h, 0, split.head_mtiles);
+        const int m_base = split.head_mtiles * BMP;
+        int tail_per_cu = 1;
+        const Shape* tp = choose_shape(a.rows_out - m_base, n16, p.kc, p.nch, num_cu, nullptr, &tail_per_cu);
+        const Shape& t = tp ? *tp : kShapes[split.tail_shape];
+        if (L.hooks->tail_debug)
+            fprintf(stderr, "[tail-split] layer %d: head %dx%dx%dx%d x %d row tiles, tail %dx%dx%dx%d (%d per CU); planned %.0f vs %.0f cycles\n",
+                    layer_index, h.wm, h.wn, h.mt, h.nt, split.head_mtiles, t.wm, t.wn, t.mt, t.nt, tail_per_cu, split.cost, single_cost);
+        int rc = launch_part(h, 0, split.head_mtiles, 1);
         if (rc != RS_OK) return rc;
-        const int m_base = split.head_mtiles * BMP, tbm = t.wm * 16 * t.mt;
-        rc = launch_part(t, m_base, (a.rows_out - m_base + tbm - 1) / tbm);
+        const int tbm = t.wm * 16 * t.mt;
+        rc = launch_part(t, m_base, (a.rows_out - m_base + tbm - 1) / tbm, tail_per_cu);
         if (rc != RS_OK) return rc;
     } else {
         BMP = s->wm * 16 * s->mt;
         BN = s->wn * 16 * s->nt;
-        const int rc = launch_part(*s, 0, (a.rows_out + BMP - 1) / BMP);
+        const int rc = launch_part(*s, 0, (a.rows_out + BMP - 1) / BMP, per_cu);
         if (rc != RS_OK) return rc;
     }
     if (bm_out) *bm_out = 2 * BMP;          // reported in conv rows, like the direct kernels

@@ -493,6 +493,9 @@ struct Shape {
 #define RS_SHAPE_D(WM, WN, MT, NT)                                                                     \
     {WM, WN, MT, NT, {conv_wino4_kernel<WM, WN, MT, NT, 16>, conv_wino4_kernel<WM, WN, MT, NT, 20>}, \
      {conv_wino4_kernel<WM, WN, MT, NT, 16, true>, conv_wino4_kernel<WM, WN, MT, NT, 20, true>}}
+// four-wave shapes exist in the one-item-ahead form only
+#define RS_SHAPE_4(WM, WN, MT, NT) \
+    {WM, WN, MT, NT, {conv_wino4_kernel<WM, WN, MT, NT, 16, true>, conv_wino4_kernel<WM, WN, MT, NT, 20, true>}, {nullptr, nullptr}}
 const Shape kShapes[] = {
     RS_SHAPE_D(8, 1, 1, 2), RS_SHAPE(8, 1, 1, 3), RS_SHAPE(8, 1, 1, 4), RS_SHAPE(8, 1, 1, 5),
     RS_SHAPE_D(4, 2, 1, 2), RS_SHAPE(4, 2, 1, 3), RS_SHAPE(4, 2, 1, 4), RS_SHAPE(4, 2, 2, 2),
@@ -500,12 +503,13 @@ const Shape kShapes[] = {
     // small tiles (round 4): a batch of 32 ... 200 reads leaves the late layers a few dozen tiles of the shapes above
     RS_SHAPE_D(4, 2, 1, 1), RS_SHAPE_D(2, 4, 1, 1),
     // four-wave workgroups (round 5): one wave per SIMD, for launches of fewer tiles than CUs
-    RS_SHAPE_D(4, 1, 1, 1), RS_SHAPE_D(2, 2, 1, 1), RS_SHAPE_D(1, 4, 1, 1),
-    RS_SHAPE_D(4, 1, 1, 2), RS_SHAPE_D(2, 2, 1, 2), RS_SHAPE_D(1, 4, 1, 2),
-    RS_SHAPE_D(4, 1, 1, 3), RS_SHAPE_D(2, 2, 1, 3),
+    RS_SHAPE_4(4, 1, 1, 1), RS_SHAPE_4(2, 2, 1, 1), RS_SHAPE_4(1, 4, 1, 1),
+    RS_SHAPE_4(4, 1, 1, 2), RS_SHAPE_4(2, 2, 1, 2), RS_SHAPE_4(1, 4, 1, 2),
+    RS_SHAPE_4(4, 1, 1, 3), RS_SHAPE_4(2, 2, 1, 3),
 };
 #undef RS_SHAPE
 #undef RS_SHAPE_D
+#undef RS_SHAPE_4
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
 size_t lds_bytes(const Shape& s, int kc) {
