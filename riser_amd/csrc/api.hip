@@ -40,6 +40,7 @@ Hooks Hooks::from_env() {
     h.no_tail_split = flag("RS_NO_TAIL_SPLIT");
     h.tail_debug = flag("RS_TAIL_DEBUG");
     h.no_deep_staging = flag("RS_NO_DEEP_STAGING");
+    if (const char* e = getenv("RS_SMALL_SHARED")) h.small_shared = atoi(e);
     h.ring_tail_split = flag("RS_RING_TAIL_SPLIT");
     h.no_fuse0 = flag("RS_NO_FUSE0");
     h.no_stream_f32 = flag("RS_NO_STREAM_F32");

@@ -87,8 +87,12 @@ struct SmallGeom {
 
 // the reduction of ONE component (COMP, a compile-time constant: the row of B^T a wave applies is straight-line code) of
 // one tile; returns the wave's accumulator
-template <int NC, int KC, int COMP>
-__device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, int lane, int u0, int n0) {
+// SH (round 5, the default): the tile's input rows are staged ONCE per workgroup - every wave
+// loads 1 / NC of them into an image the NC waves share (three buffers, one barrier per chunk: a wave is never more than a
+// chunk ahead of the slowest) - instead of once per wave: a workgroup pulls (AR + 16 NC) instead of NC (AR + 16) rows per
+// chunk from L2, a third of the bytes that bound a 16-read launch of layer 10 (430 MB at 9 TB/s).  Weights stay private.
+template <int NC, int KC, int COMP, bool SH>
+__device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, float* lds_sh, int lane, int u0, int n0) {
     constexpr int comp = COMP;
     constexpr int kDepth = 3;                      // chunks in flight per wave
     using G = SmallGeom<NC, KC>;
@@ -96,7 +100,9 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, int
                   BUF = G::BUF;
     (void)R;
     constexpr int A_UNITS = AR * KQ, W_UNITS = 16 * KQ;
-    constexpr int A_PER = (A_UNITS + 63) / 64, W_PER = (W_UNITS + 63) / 64;
+    constexpr int A_LANES = SH ? 64 * NC : 64;     // lanes that share the loads of one input image
+    constexpr int A_PER = (A_UNITS + A_LANES - 1) / A_LANES, W_PER = (W_UNITS + 63) / 64;
+    constexpr int ASH = A_LDS + 8;                 // one shared image (+ a dump slot)
     const int r = lane & 15, kq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
@@ -111,13 +117,13 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, int
     int a_st[A_PER], w_st[W_PER];                  // LDS float offsets
 #pragma unroll
     for (int j = 0; j < A_PER; ++j) {
-        const int q = lane + 64 * j;
+        const int q = (SH ? comp * 64 : 0) + lane + A_LANES * j;
         const int row = q / KQ, c4 = q - row * KQ;
         const int g = g0 + row;
         const bool ok = q < A_UNITS && g >= 0 && g < a.rows_in;
         a_off[j] = ok ? (unsigned)(g * a.cp_in + 4 * c4) * 4u : kOob;
         a_off_last[j] = (ok && 4 * c4 < last_kc) ? a_off[j] : kOob;
-        a_st[j] = q < A_UNITS ? ((row % STRIDE) * PLROWS + row / STRIDE) * S + 4 * c4 : BUF - 8;
+        a_st[j] = q < A_UNITS ? ((row % STRIDE) * PLROWS + row / STRIDE) * S + 4 * c4 : (SH ? A_LDS : BUF - 8);
     }
 #pragma unroll
     for (int j = 0; j < W_PER; ++j) {
@@ -141,11 +147,11 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, int
 #pragma unroll
         for (int j = 0; j < W_PER; ++j) rw[dd][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[j], wc, 0);
     };
-    auto store_chunk = [&](auto D_, float* buf) {  // registers -> this wave's LDS image (8-byte stores: the pitch is even)
+    auto store_chunk = [&](auto D_, float* buf, float* abuf) {  // registers -> LDS images (8-byte stores: the pitch is even)
         constexpr int dd = decltype(D_)::value;
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
-            uint2* p = reinterpret_cast<uint2*>(buf + a_st[j]);
+            uint2* p = reinterpret_cast<uint2*>(abuf + a_st[j]);
             p[0] = make_uint2(ra[dd][j].x, ra[dd][j].y);
             p[1] = make_uint2(ra[dd][j].z, ra[dd][j].w);
         }
@@ -167,9 +173,9 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, int
     struct Frag {
         float e[4], uf;
     };
-    auto read_frag = [&](Frag& f, const float* buf, auto ST_) {
+    auto read_frag = [&](Frag& f, const float* buf, const float* abuf, auto ST_) {
         constexpr int st = decltype(ST_)::value;
-        auto row = [&](int k) { return buf[a_rd + ((k % STRIDE) * PLROWS + k / STRIDE) * S + 4 * st]; };
+        auto row = [&](int k) { return abuf[a_rd + ((k % STRIDE) * PLROWS + k / STRIDE) * S + 4 * st]; };
         if constexpr (NC == 4) {                   // comp 0: d0, d2 | 1: d1, d2 | 2: d2, d1 | 3: d1, d3
             constexpr int k0 = comp == 0 ? 0 : comp == 2 ? 2 : 1, k1 = comp == 0 ? 2 : comp == 1 ? 2 : comp == 2 ? 1 : 3;
             f.e[0] = row(k0);
@@ -213,16 +219,19 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, int
     // chunk c lives in register set c % kDepth and LDS buffer c & 1.  A wave has nobody to hide its LDS latency behind,
     // so the fragments of k-step s + 1 (the first of the next chunk, whose image is written at the START of this chunk's
     // step, behind nothing but the in-order LDS queue) are read before the MFMA of k-step s.
+    // image of chunk c: weights in this wave's buffer c & 1; input rows there too, or (SH) in shared buffer c % 3
+    auto a_img = [&](int c) -> float* { return SH ? lds_sh + (c % 3) * ASH : lds + (c & 1) * BUF; };
     static_for<kDepth>([&](auto D_) { load_chunk(D_, decltype(D_)::value); });
-    store_chunk(std::integral_constant<int, 0>{}, lds);
+    store_chunk(std::integral_constant<int, 0>{}, lds, a_img(0));
     load_chunk(std::integral_constant<int, 0>{}, kDepth);
+    if constexpr (SH) __syncthreads();
     // fragments are read kAhead k-steps before their MFMA (a ring of kAhead + 1 register sets, indexed statically: the body
     // unrolled below holds kDepth * KQ k-steps, a multiple of kAhead + 1)
     constexpr int kAhead = 2;
     static_assert((kDepth * KQ) % (kAhead + 1) == 0 && KQ > kAhead, "static fragment ring");
     Frag fr[kAhead + 1];
-    read_frag(fr[0], lds, std::integral_constant<int, 0>{});
-    read_frag(fr[1], lds, std::integral_constant<int, 1>{});
+    read_frag(fr[0], lds, a_img(0), std::integral_constant<int, 0>{});
+    read_frag(fr[1], lds, a_img(0), std::integral_constant<int, 1>{});
     for (int c = 0; c < a.nch; c += kDepth) {
         static_for<kDepth>([&](auto D_) {
             constexpr int dd = decltype(D_)::value;
@@ -230,19 +239,23 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, int
             const int cc = c + dd;                                     // chunk computed in this step
             const float* here = lds + (cc & 1) * BUF;
             float* next = lds + ((cc + 1) & 1) * BUF;
+            const float* here_a = a_img(cc);
+            float* next_a = a_img(cc + 1);
             // chunk cc + 1: its registers (loaded kDepth - 1 steps ago) -> the other LDS buffer, then the set is free for
             // chunk cc + 1 + kDepth.  (Every fragment read of chunk cc - 1, whose image this overwrites, was issued during
-            // chunk cc - 1's own k-steps: the look-ahead never reaches back.)
-            store_chunk(std::integral_constant<int, nx>{}, next);
+            // chunk cc - 1's own k-steps: the look-ahead never reaches back.  SH: the shared image of chunk cc + 1 is the
+            // one of chunk cc - 2, which every wave left before the barrier of step cc - 1.)
+            store_chunk(std::integral_constant<int, nx>{}, next, next_a);
             load_chunk(std::integral_constant<int, nx>{}, cc + 1 + kDepth);
-            if (cc < a.nch) {                                          // wave-uniform
+            if constexpr (SH) __syncthreads();                         // chunk cc + 1's shared image is complete
+            if (cc < a.nch) {                                          // wave-uniform, and the same in every wave
                 static_for<KQ>([&](auto ST_) {
                     constexpr int st = decltype(ST_)::value;
                     constexpr int i = dd * KQ + st;                    // k-step of the unrolled body
                     if constexpr (st + kAhead < KQ)
-                        read_frag(fr[(i + kAhead) % (kAhead + 1)], here, std::integral_constant<int, st + kAhead>{});
+                        read_frag(fr[(i + kAhead) % (kAhead + 1)], here, here_a, std::integral_constant<int, st + kAhead>{});
                     else
-                        read_frag(fr[(i + kAhead) % (kAhead + 1)], next, std::integral_constant<int, st + kAhead - KQ>{});
+                        read_frag(fr[(i + kAhead) % (kAhead + 1)], next, next_a, std::integral_constant<int, st + kAhead - KQ>{});
                     kstep(fr[i % (kAhead + 1)]);
                 });
             }
@@ -251,25 +264,26 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, int
     return acc;
 }
 
-template <int NC, int KC>
+template <int NC, int KC, bool SH = false>
 __global__ __launch_bounds__(64 * NC) void conv_small_f32_kernel(const SmallArgs a) {
     using G = SmallGeom<NC, KC>;
-    __shared__ __attribute__((aligned(16))) float lds_all[NC * 2 * G::BUF];
+    __shared__ __attribute__((aligned(16))) float lds_all[NC * 2 * G::BUF + (SH ? 3 * (G::A_LDS + 8) : 0)];
     const int lane = threadIdx.x & 63;
     const int comp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // this wave's component
     float* lds = lds_all + comp * 2 * G::BUF;
+    float* lds_sh = lds_all + NC * 2 * G::BUF;
     const int r = lane & 15, kq = lane >> 4;
     const int tile = blockIdx.x;
     const int mi = tile / a.n_ntiles, ni = tile - mi * a.n_ntiles;
     const int u0 = mi * 16, n0 = ni * 16;
     f32x4 acc;
     switch (comp) {                                                    // wave-uniform: one scalar branch per wave
-        case 0: acc = small_chain<NC, KC, 0>(a, lds, lane, u0, n0); break;
-        case 1: acc = small_chain<NC, KC, 1>(a, lds, lane, u0, n0); break;
-        case 2: acc = small_chain<NC, KC, 2>(a, lds, lane, u0, n0); break;
-        case 3: acc = small_chain<NC, KC, 3>(a, lds, lane, u0, n0); break;
-        case 4: acc = small_chain<NC, KC, (NC > 4 ? 4 : 0)>(a, lds, lane, u0, n0); break;
-        default: acc = small_chain<NC, KC, (NC > 4 ? 5 : 0)>(a, lds, lane, u0, n0); break;
+        case 0: acc = small_chain<NC, KC, 0, SH>(a, lds, lds_sh, lane, u0, n0); break;
+        case 1: acc = small_chain<NC, KC, 1, SH>(a, lds, lds_sh, lane, u0, n0); break;
+        case 2: acc = small_chain<NC, KC, 2, SH>(a, lds, lds_sh, lane, u0, n0); break;
+        case 3: acc = small_chain<NC, KC, 3, SH>(a, lds, lds_sh, lane, u0, n0); break;
+        case 4: acc = small_chain<NC, KC, (NC > 4 ? 4 : 0), SH>(a, lds, lds_sh, lane, u0, n0); break;
+        default: acc = small_chain<NC, KC, (NC > 4 ? 5 : 0), SH>(a, lds, lds_sh, lane, u0, n0); break;
     }
 
     // ---- the components meet: [comp][lane] x 4 floats in LDS (the staging images are dead), one barrier, then wave h of
@@ -322,7 +336,12 @@ __global__ __launch_bounds__(64 * NC) void conv_small_f32_kernel(const SmallArgs
 
 using KernelFn = void (*)(const SmallArgs);
 
-KernelFn pick(int nc, int kc) {
+KernelFn pick(int nc, int kc, bool shared = false) {
+    if (shared) {
+        if (nc == 4) return kc == 16 ? conv_small_f32_kernel<4, 16, true> : kc == 20 ? conv_small_f32_kernel<4, 20, true>
+                          : kc == 24 ? conv_small_f32_kernel<4, 24, true> : nullptr;
+        return kc == 16 ? conv_small_f32_kernel<6, 16, true> : kc == 20 ? conv_small_f32_kernel<6, 20, true> : nullptr;
+    }
     if (nc == 4) return kc == 16 ? conv_small_f32_kernel<4, 16> : kc == 20 ? conv_small_f32_kernel<4, 20>
                       : kc == 24 ? conv_small_f32_kernel<4, 24> : nullptr;
     return kc == 16 ? conv_small_f32_kernel<6, 16> : kc == 20 ? conv_small_f32_kernel<6, 20> : nullptr;
@@ -336,21 +355,18 @@ int64_t conv_small_f32_waves(const ConvLayerDev& L, int64_t rows_in) {
     return ((units + 15) / 16) * (int64_t)(round_up(L.c_out, 16) / 16);
 }
 
-// Estimate in shader cycles, fitted to tools/layer_times.py at 1 ... 48 reads: a wave's chain is C_in / 4 k-steps of ~200
-// cycles (F(2,3): four waves on four SIMDs; fragment reads, transform and MFMA of a k-step are one dependent sequence) or
-// ~350 (F(4,3): six waves on four SIMDs).  A launch lasts as long as its most loaded CU: ceil(workgroups / CUs) chains,
-// of which the second and later overlap with the first only where they find an idle SIMD - not at all for the six waves
-// of F(4,3) (layer 10: 28 / 58 / 87 / 114 us at 71 / 284 / 568 / 852 workgroups), by a third for the four of F(2,3)
-// (layer 11: 24 / 39 / 56 / 72 us at 107 / 428 / 642 / 856).
+// Estimate in shader cycles, fitted to tools/layer_times.py at 1 ... 32 reads (round 5: the shared-input form, every layer
+// forced onto this kernel - profiles/r05_small_kernel_shared_input_rows.txt): a wave's chain is C_in / 4 k-steps of ~145 cycles
+// (F(4,3): six waves on four SIMDs) or ~75 (F(2,3): four waves) plus ~2500 of prologue and output transform; a launch lasts
+// as long as its most loaded CU, whose second and later workgroups cost 1.6 (1.2) chains each (layer 10: 21 / 21 / 39 / 56 us
+// at 71 / 142 / 284 / 568 workgroups; layer 11: 18 / 20 / 27 / 49 us at 107 / 214 / 428 / 856); + launch, prologue and the
+// timing events' own cost, like the tiled kernels' thin-launch fit it is compared with.
 double conv_small_f32_cost(const ConvLayerDev& L, int64_t rows_in, int num_cu) {
     const double ksteps = (L.cp_in + 3) / 4;
-    const double per_step = L.wino_m == 4 ? 350.0 : 200.0;
+    const double per_step = L.wino_m == 4 ? 145.0 : 75.0;
     const int64_t per_cu = (conv_small_f32_waves(L, rows_in) + num_cu - 1) / num_cu;
-    const double chains = 1.0 + (L.wino_m == 4 ? 1.0 : 0.65) * (double)(per_cu > 1 ? per_cu - 1 : 0);
-    // + launch, prologue and the timing events' own cost, like the tiled kernels' thin-launch fit it is compared with
-    // (round 5: with 6000 the early layers of an 8-read batch - 12-18 k-steps, 5-7 workgroups per CU - went to this kernel
-    // at 23 us where the tiled one takes 13-18)
-    return ksteps * per_step * chains + 20000.0;
+    const double chains = 1.0 + (L.wino_m == 4 ? 1.6 : 1.2) * (double)(per_cu > 1 ? per_cu - 1 : 0);
+    return (ksteps * per_step + 2500.0) * chains + 23000.0;
 }
 
 bool conv_small_f32_ok(const ConvLayerDev& L) { return pick(L.wino_m == 4 ? 6 : 4, L.plan.kc) != nullptr; }
@@ -358,7 +374,10 @@ bool conv_small_f32_ok(const ConvLayerDev& L) { return pick(L.wino_m == 4 ? 6 : 
 int launch_conv_small_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
                           int layer_index, hipStream_t st, int* bm_out, int* bn_out) {
     const int nc = L.wino_m == 4 ? 6 : 4;
-    KernelFn fn = pick(nc, L.plan.kc);
+    // the input rows of a tile are staged once per workgroup (RS_SMALL_SHARED=0: once per wave, the round-4 form, kept as a
+    // cross-check: 20-35 % slower at every launch size)
+    const bool shared = L.hooks->small_shared != 0;
+    KernelFn fn = pick(nc, L.plan.kc, shared);
     if (!fn) {
         set_error("conv_small_f32: unsupported channel chunk %d", L.plan.kc);
         return RS_ERR_ARG;
