@@ -41,6 +41,7 @@ Hooks Hooks::from_env() {
     h.tail_debug = flag("RS_TAIL_DEBUG");
     h.no_deep_staging = flag("RS_NO_DEEP_STAGING");
     if (const char* e = getenv("RS_SMALL_SHARED")) h.small_shared = atoi(e);
+    if (const char* e = getenv("RS_SF32_MIN_RUN")) h.sf32_min_run = atoi(e) > 0 ? atoi(e) : 1;
     h.ring_tail_split = flag("RS_RING_TAIL_SPLIT");
     h.no_fuse0 = flag("RS_NO_FUSE0");
     h.no_stream_f32 = flag("RS_NO_STREAM_F32");

@@ -55,6 +55,7 @@ struct DeviceGuard {
 // created (rs_model_create), never on the launch path.
 struct Hooks {
     bool no_rect_order = false;      // RS_NO_RECT_ORDER: n-major tile order instead of XCD rectangles
+    int sf32_min_run = 0;            // RS_SF32_MIN_RUN: shortest run of 16-row sub-blocks a wave of the fp32 streaming kernel (layers 0 + 1) takes (0: by launch size)
     int small_shared = 1;            // RS_SMALL_SHARED=0: conv_small_f32 stages the input rows once per wave (round 4) instead of once per workgroup
     bool no_deep_staging = false;    // RS_NO_DEEP_STAGING: the thin fp32 Winograd shapes keep the default staging distance (A/B of the one-item-ahead loads)
     bool tail_debug = false;         // RS_TAIL_DEBUG: print every head / tail decision

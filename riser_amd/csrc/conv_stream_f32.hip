@@ -269,7 +269,11 @@ int launch_conv_stream_f32(const ConvLayerDev& L1, const float* d_xs, const floa
     a.cp_out = L1.cp_out;
     a.n_sub = (int)((rows_out + 15) / 16);
     const int waves = num_cu * RS_SF32_WAVES * kWaves;                       // 3 workgroups of 4 waves per CU (153 VGPRs: 3 waves per SIMD)
-    a.sub_per_wave = std::max(8, (a.n_sub + waves - 1) / waves);
+    // a wave's run: eight sub-blocks or more once every SIMD has a wave; a thin launch (a read or a few) spreads runs of two
+    // over more waves (1 / 8 reads: 21 / 22 -> 13 us); RS_SF32_MIN_RUN forces the floor
+    const int simds = num_cu * 4;
+    const int floor_run = L1.hooks->sf32_min_run > 0 ? L1.hooks->sf32_min_run : std::min(8, std::max(2, (a.n_sub + simds - 1) / simds));
+    a.sub_per_wave = std::max(floor_run, (a.n_sub + waves - 1) / waves);
     const int n_waves = (a.n_sub + a.sub_per_wave - 1) / a.sub_per_wave;
     const int grid = (n_waves + kWaves - 1) / kWaves;
     KernelFn fn = round_up(L1.c_out, 16) / 16 <= 1 ? conv_stream_f32_kernel<1> : conv_stream_f32_kernel<2>;
