@@ -90,6 +90,41 @@ def test_hand_over_between_the_kernels(dev, models, B):
     assert all(info[i]["bn"] == 16 for i in range(2, 12))
 
 
+@pytest.mark.parametrize("B", [5, 16, 40, 72, 130])
+def test_thin_launch_forms_keep_the_bits(dev, models, B):
+    """round 5: launches with fewer tiles than CUs run four-wave workgroups (one or two per CU) with their staging loads one
+    item ahead, the small kernel shares a tile's input rows inside the workgroup, the streaming kernel shortens its runs -
+    against the round-4 forms (eight-wave shapes of a 512-read batch forced onto every tiled layer, default staging distance,
+    private input rows, runs of eight) and against each intermediate form: the same bits"""
+    from riser_amd.preprocess import pack_reads
+    small, tiled, _ = models
+    sd = synth.make_state_dict(1)
+    big4 = ";".join("%d:8,1,1,4" % i for i in range(2, 12))            # F(4,3) layers: 512 x 64 tiles
+    big2 = ";".join("%d:8,1,2,2" % i for i in range(2, 12))            # F(2,3) layers: 512 x 32 tiles
+    variants = {
+        "round 4": {"RS_SMALL_F32_WAVES": "0", "RS_FORCE_SHAPE_WINO4": big4, "RS_FORCE_SHAPE_WINO": big2, "RS_SF32_MIN_RUN": "8"},
+        "default staging": {"RS_NO_DEEP_STAGING": "1", "RS_SMALL_F32_WAVES": "0"},
+        "private rows": {"RS_SMALL_SHARED": "0"},
+        "runs of one": {"RS_SF32_MIN_RUN": "1"},
+    }
+    rng = np.random.default_rng(100 + B)
+    lens = rng.integers(4096, 16001, size=B)
+    sigs = _reads(lens, first=31000 + B)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    want = small.classify_raw(sig, off, ln, lh, return_logits=True)
+    assert torch.equal(tiled.classify_raw(sig, off, ln, lh, return_logits=True)[0], want[0])
+    for name, env in variants.items():
+        m = hooked_model(env, sd, "f32w", dev)
+        got = m.classify_raw(sig, off, ln, lh, return_logits=True)
+        if name == "round 4":
+            info = m.layer_info()
+            assert all(info[i]["bm"] == 512 for i in range(2, 12)), info
+        m.close()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), name
+    oracle = ro.classify_reads(sd, sigs[:6])
+    assert np.abs(want[0].cpu().numpy()[:6] - oracle).max() < 1e-4
+
+
 def test_forward_path_and_uniform_layout(dev, models):
     """rs_forward (signals that arrive normalised: layer 1 is a Winograd launch of its own) and the layout without host
     lengths (every read in the blocks of the longest)"""
