@@ -479,6 +479,16 @@ def side_variants(args, device, wl, ref):
     dtl = timed(lambda: ml.classify_raw(sig, live_off, live_len, live_lens, out=pl))
     variants["live_357x8615_f32"] = {"reads_per_s": round(lb / dtl, 1), "ms_per_step": round(dtl * 1e3, 4), "batch": lb,
                                      "samples_per_read": ll}
+    # thin batches (a chunk client delivers ~20 assessable reads per batch, riser/control.py:31-93; Model.classify is batch 1,
+    # riser/model.py:22-28): whole-step time of 1 / 16 / 32 / 64 reads of 16000 samples
+    thin = {}
+    for tb in (1, 16, 32, 64):
+        t_lens = np.full(tb, L, dtype=np.int32)
+        t_off = torch.from_numpy(np.arange(tb, dtype=np.int64) * L).to(device)
+        t_len = torch.from_numpy(t_lens).to(device)
+        pt = torch.empty((tb, 2), dtype=torch.float32, device=device)
+        thin[str(tb)] = round(timed(lambda: ml.classify_raw(sig, t_off, t_len, t_lens, out=pt)) * 1e3, 4)
+    variants["thin_batches_f32"] = {"ms_per_step_by_reads": thin, "chunk_samples": L}
     # the same shape on the signals the control-loop replay carries (synth.make_raw_read: adapter + poly(A) plateau + squiggle,
     # trimmed as riser/control.py:36-60 trims: behind the poly(A) end, or at the fixed offset when none is found - which leaves a
     # plateau of ~3000 consecutive outliers in front of the squiggle).  Data-dependent only through the normalise kernel's walk
@@ -952,6 +962,9 @@ def compact_line(detail, args, model, wl):
             if "max_dp_vs_f32" in m:
                 roof[f"{name}_max_dp"] = m["max_dp_vs_f32"]
                 roof[f"{name}_flips"] = m["flips"]
+    thin = (detail.get("variants") or {}).get("thin_batches_f32")
+    if thin:
+        roof["thin_batch_ms_f32"] = thin["ms_per_step_by_reads"]      # reads of 16000 samples per call -> ms per call
     line["roofline"] = roof
     cb = detail.get("cpu_baseline")
     if cb:

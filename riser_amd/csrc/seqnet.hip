@@ -679,7 +679,9 @@ __device__ __forceinline__ f32x4 mfma_x3(const u32x4& ah, const u32x4& al, const
 }
 
 template <int NT, int MTW, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void seq_basic_block_x3_kernel(const BlockX3Args a) {
+// (launch bound 512 also for the four-wave form: with 256 the compiler keeps MFMA accumulators in AGPRs and copies them in
+// and out - 192 extra instructions around the 72 MFMAs of a <2, 2, 4> tile; worth 1 % here, 17 % in conv_wino4.hip's thin shapes)
+__global__ __launch_bounds__(512) void seq_basic_block_x3_kernel(const BlockX3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int NP = a.NPs;
     constexpr int R = 16 * MTW * WAVES;
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_x3_kernel(const Bl
 // reads: g / 2 = b TP + p), always 64-byte aligned, stored 16 bytes per lane; LDS operations of one wave execute in order, so
 // the image needs no barrier.
 template <int NT>
-__global__ __launch_bounds__(256) void seq_stem_pool_x3_kernel(const float* __restrict__ x, unsigned x_bytes,
+__global__ __launch_bounds__(512) void seq_stem_pool_x3_kernel(const float* __restrict__ x, unsigned x_bytes,
                                                                const unsigned short* __restrict__ wq /* planes [hi | lo] [S][4][16 NT][8] */,
                                                                const float* __restrict__ bias, float* __restrict__ y, int B, int L,
                                                                int T_conv, int TP, int c_out, int K, int S, int stride, int pad,
