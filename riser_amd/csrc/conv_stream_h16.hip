@@ -935,7 +935,11 @@ int launch_conv_stream012_h16(const ConvLayerDev& L1, const ConvLayerDev& L2, co
     a.n_sub = (int)(rows2 / 32);
     const int nw = x3 ? 8 : 4;
     const int waves = num_cu * (x3 ? 8 : 12);                   // one workgroup of 8 waves, or three of 4, per CU
-    a.sub_per_wave = round_up(std::max(8, (a.n_sub + waves - 1) / waves), 2);
+    // runs of eight blocks or more once every SIMD has a wave; a thin launch (a read or a few) spreads runs of two over more
+    // waves (conv_stream_f32.hip; RS_SF32_MIN_RUN forces the floor)
+    const int simds = num_cu * 4;
+    const int floor_run = L1.hooks->sf32_min_run > 0 ? L1.hooks->sf32_min_run : std::min(8, std::max(2, (a.n_sub + simds - 1) / simds));
+    a.sub_per_wave = round_up(std::max(floor_run, (a.n_sub + waves - 1) / waves), 2);
     const int n_waves = (a.n_sub + a.sub_per_wave - 1) / a.sub_per_wave;
     const int grid = (n_waves + nw - 1) / nw;
     const int nt2 = round_up(L2.c_out, 16) / 16;
