@@ -125,6 +125,22 @@ def test_thin_launch_forms_keep_the_bits(dev, models, B):
     assert np.abs(want[0].cpu().numpy()[:6] - oracle).max() < 1e-4
 
 
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3", "f16"])
+def test_streaming_run_length_keeps_the_bits_16bit(dev, dtype):
+    """the 16-bit streaming launch (layers 0-2) spreads a thin batch over runs of two blocks: the same bits as runs of eight"""
+    from riser_amd.preprocess import pack_reads
+    sd = synth.make_state_dict(1)
+    a = hooked_model({}, sd, dtype, dev)
+    b = hooked_model({"RS_SF32_MIN_RUN": "8"}, sd, dtype, dev)
+    for B in (1, 7, 40):
+        lens = np.random.default_rng(B).integers(4096, 16001, size=B)
+        sig, off, ln, lh = pack_reads(_reads(lens, first=52000 + B), dev)
+        ga, gb = a.classify_raw(sig, off, ln, lh, return_logits=True), b.classify_raw(sig, off, ln, lh, return_logits=True)
+        assert torch.equal(ga[0], gb[0]) and torch.equal(ga[1], gb[1]), (dtype, B)
+    a.close()
+    b.close()
+
+
 def test_forward_path_and_uniform_layout(dev, models):
     """rs_forward (signals that arrive normalised: layer 1 is a Winograd launch of its own) and the layout without host
     lengths (every read in the blocks of the longest)"""
