@@ -41,6 +41,7 @@ Hooks Hooks::from_env() {
     h.tail_debug = flag("RS_TAIL_DEBUG");
     h.no_deep_staging = flag("RS_NO_DEEP_STAGING");
     if (const char* e = getenv("RS_SMALL_SHARED")) h.small_shared = atoi(e);
+    if (const char* e = getenv("RS_SMALL_NW")) h.small_nw = atoi(e);
     if (const char* e = getenv("RS_SF32_MIN_RUN")) h.sf32_min_run = atoi(e) > 0 ? atoi(e) : 1;
     h.ring_tail_split = flag("RS_RING_TAIL_SPLIT");
     h.no_fuse0 = flag("RS_NO_FUSE0");
@@ -916,7 +917,7 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                 m->last_bn[i] = round_up(L.c_out, 16);
             } else if (small32)
                 rc = launch_conv_small_f32(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_blen, NB, P_in,
-                                           i, st, &m->last_bm[i], &m->last_bn[i]);
+                                           i, m->num_cu, st, &m->last_bm[i], &m->last_bn[i]);
             else if (m->dtype == RS_F32W && L.wino_m == 4)
                 rc = launch_conv_wino4(L, static_cast<const float*>(buf[cur]), static_cast<float*>(buf[cur ^ 1]), d_blen, NB,
                                        P_in, i, m->num_cu, check_dead, st, &m->last_bm[i], &m->last_bn[i]);

@@ -56,6 +56,7 @@ struct DeviceGuard {
 struct Hooks {
     bool no_rect_order = false;      // RS_NO_RECT_ORDER: n-major tile order instead of XCD rectangles
     int sf32_min_run = 0;            // RS_SF32_MIN_RUN: shortest run of 16-row sub-blocks a wave of the fp32 streaming kernel (layers 0 + 1) takes (0: by launch size)
+    int small_nw = 0;                // RS_SMALL_NW: 1 / 2 = channel sub-tiles per wave of conv_small_f32 (0: by launch size)
     int small_shared = 1;            // RS_SMALL_SHARED=0: conv_small_f32 stages the input rows once per wave (round 4) instead of once per workgroup
     bool no_deep_staging = false;    // RS_NO_DEEP_STAGING: the thin fp32 Winograd shapes keep the default staging distance (A/B of the one-item-ahead loads)
     bool tail_debug = false;         // RS_TAIL_DEBUG: print every head / tail decision
@@ -177,11 +178,11 @@ int conv_wino_max_bn();
 // bit-identical to conv_wino.hip / conv_wino4.hip
 bool conv_small_f32_ok(const ConvLayerDev& L);
 int64_t conv_small_f32_waves(const ConvLayerDev& L, int64_t rows_in);        // workgroups (16 x 16 tiles) of such a launch
-double conv_small_f32_cost(const ConvLayerDev& L, int64_t rows_in, int num_cu);   // estimate, shader cycles
+double conv_small_f32_cost(const ConvLayerDev& L, int64_t rows_in, int num_cu, int* nw_out = nullptr);   // estimate, shader cycles; the channel sub-tiles per wave it assumes
 double conv_wino_plan_cost(int64_t rows_out, int n16, int kc, int nch, int num_cu);
 double conv_wino_launch_cost(int64_t rows_out, int n16, int kc, int nch, int num_cu, bool* thin_out);
 int launch_conv_small_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
-                          int layer_index, hipStream_t st, int* bm_out, int* bn_out);
+                          int layer_index, int num_cu, hipStream_t st, int* bm_out, int* bn_out);
 // narrow 16-bit layers (C_in <= 32, C_out <= 48): per-wave streaming kernel, optionally with ConvNet
 // layer 0 folded in (fuse_xs = normalised signals at the padded pitch behind 16 zero bytes)
 bool conv_stream_h16_ok(const ConvLayerDev& L, int P_in);

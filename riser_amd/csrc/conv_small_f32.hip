@@ -22,6 +22,7 @@
 // launch has at most kSmallMaxWaves tiles (api.hip); layers 0 + 1 keep the streaming kernel.
 #include "common.hpp"
 
+#include <algorithm>
 #include <utility>
 
 namespace rs {
@@ -73,7 +74,7 @@ struct SmallArgs {
 // plane).  The chunk's byte offset is a SCALAR operand of the buffer loads: no per-lane address arithmetic in the loop.
 // LDS operations of one wave execute in order and no other wave touches its image: no barrier in the loop; ONE at the end,
 // where the component accumulators meet in LDS for the output transform.
-template <int NC, int KC>
+template <int NC, int KC, int NW = 1>
 struct SmallGeom {
     static constexpr int R = NC == 4 ? 4 : 6;             // input rows of a unit
     static constexpr int STRIDE = NC == 4 ? 2 : 4;        // input rows between consecutive units
@@ -82,7 +83,9 @@ struct SmallGeom {
     static constexpr int S = KC + 2;                      // LDS pitch of a row (input and weight)
     static constexpr int PLROWS = 17;                     // rows per plane: index (slab row / STRIDE) <= 16
     static constexpr int A_LDS = STRIDE * PLROWS * S;     // floats
-    static constexpr int BUF = A_LDS + 16 * S + 8;        // + a dump slot for the lanes of a pass that hold no unit
+    static constexpr int WR = 16 * NW;                    // weight rows of a wave: NW channel sub-tiles
+    static constexpr int BUF = A_LDS + WR * S + 8;        // a wave's private image: input rows + weights + a dump slot for the lanes of a pass that hold no unit
+    static constexpr int WBUF = WR * S + 8;               // ... weights only, when the input rows are shared
 };
 
 // the reduction of ONE component (COMP, a compile-time constant: the row of B^T a wave applies is straight-line code) of
@@ -91,15 +94,17 @@ struct SmallGeom {
 // loads 1 / NC of them into an image the NC waves share (three buffers, one barrier per chunk: a wave is never more than a
 // chunk ahead of the slowest) - instead of once per wave: a workgroup pulls (AR + 16 NC) instead of NC (AR + 16) rows per
 // chunk from L2, a third of the bytes that bound a 16-read launch of layer 10 (430 MB at 9 TB/s).  Weights stay private.
-template <int NC, int KC, int COMP, bool SH>
-__device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, float* lds_sh, int lane, int u0, int n0) {
+// NW (round 5): channel sub-tiles per wave - a workgroup covers 16 units x 16 NW channels, a wave issues NW MFMAs per k-step
+// on one transformed input fragment (launches of several workgroups per CU: half the workgroups, each 1.3 x as long).
+template <int NC, int KC, int COMP, bool SH, int NW>
+__device__ __forceinline__ void small_chain(const SmallArgs& a, float* lds, float* lds_sh, int lane, int u0, int n0, f32x4 (&acc)[NW]) {
     constexpr int comp = COMP;
     constexpr int kDepth = 3;                      // chunks in flight per wave
-    using G = SmallGeom<NC, KC>;
+    using G = SmallGeom<NC, KC, NW>;
     constexpr int R = G::R, STRIDE = G::STRIDE, KQ = G::KQ, AR = G::AR, S = G::S, PLROWS = G::PLROWS, A_LDS = G::A_LDS,
-                  BUF = G::BUF;
+                  BUF = SH ? G::WBUF : G::BUF, W0 = SH ? 0 : A_LDS;   // private image and where its weights start
     (void)R;
-    constexpr int A_UNITS = AR * KQ, W_UNITS = 16 * KQ;
+    constexpr int A_UNITS = AR * KQ, W_UNITS = G::WR * KQ;
     constexpr int A_LANES = SH ? 64 * NC : 64;     // lanes that share the loads of one input image
     constexpr int A_PER = (A_UNITS + A_LANES - 1) / A_LANES, W_PER = (W_UNITS + 63) / 64;
     constexpr int ASH = A_LDS + 8;                 // one shared image (+ a dump slot)
@@ -130,7 +135,7 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, flo
         const int q = lane + 64 * j;
         const int row = q / KQ, c4 = q - row * KQ;
         w_off[j] = q < W_UNITS ? (unsigned)(((n0 + row) * a.nch * NC + comp) * KC + 4 * c4) * 4u : kOob;
-        w_st[j] = q < W_UNITS ? A_LDS + row * S + 4 * c4 : BUF - 8;
+        w_st[j] = q < W_UNITS ? W0 + row * S + 4 * c4 : BUF - 8;
     }
 
     u32x4 ra[kDepth][A_PER], rw[kDepth][W_PER];
@@ -166,12 +171,12 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, flo
     // fragment addresses: activation operand (MFMA "B"): column r = unit u0 + r, k = kq -> channel 4 st + kq of the unit's
     // input rows; weight operand (MFMA "A"): row r = output channel n0 + r, k = kq
     const int a_rd = r * S + kq;                   // + ((k % STRIDE) * PLROWS + k / STRIDE) * S + 4 st
-    const int w_rd = A_LDS + r * S + kq;           // + 4 st
+    const int w_rd = W0 + r * S + kq;              // + 4 st
     // the input rows d_k this wave's component needs: V = B^T d, one row of B^T per wave.  Which rows, and the expression,
     // depend on the component - wave-uniform, so the selection is a scalar branch around a few VALU instructions; the
     // expressions (and their roundings) are those of conv_wino.hip / conv_wino4.hip: xform()
     struct Frag {
-        float e[4], uf;
+        float e[4], uf[NW];
     };
     auto read_frag = [&](Frag& f, const float* buf, const float* abuf, auto ST_) {
         constexpr int st = decltype(ST_)::value;
@@ -195,9 +200,11 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, flo
                 f.e[3] = row(4);
             }
         }
-        f.uf = buf[w_rd + 4 * st];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) f.uf[j] = buf[w_rd + j * 16 * S + 4 * st];
     };
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto kstep = [&](const Frag& f) {
         float v;
         if constexpr (NC == 4) {                   // conv_wino.hip: v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3
@@ -213,7 +220,8 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, flo
                 v = fmaf(comp == 3 ? 2.0f : -2.0f, t2, s2);
             }
         }
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.uf, v, acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.uf[j], v, acc[j], 0, 0, 0);
     };
 
     // chunk c lives in register set c % kDepth and LDS buffer c & 1.  A wave has nobody to hide its LDS latency behind,
@@ -261,29 +269,31 @@ __device__ __forceinline__ f32x4 small_chain(const SmallArgs& a, float* lds, flo
             }
         });
     }
-    return acc;
 }
 
-template <int NC, int KC, bool SH = false>
+template <int NC, int KC, bool SH = false, int NW = 1>
 __global__ __launch_bounds__(64 * NC) void conv_small_f32_kernel(const SmallArgs a) {
-    using G = SmallGeom<NC, KC>;
-    __shared__ __attribute__((aligned(16))) float lds_all[NC * 2 * G::BUF + (SH ? 3 * (G::A_LDS + 8) : 0)];
+    using G = SmallGeom<NC, KC, NW>;
+    constexpr int PB = SH ? G::WBUF : G::BUF;      // a wave's private image (two buffers)
+    constexpr int LDS_FLOATS = NC * 2 * PB + (SH ? 3 * (G::A_LDS + 8) : 0);
+    static_assert(LDS_FLOATS >= NW * NC * 64 * 4, "the components' meeting place reuses the staging images");
+    __shared__ __attribute__((aligned(16))) float lds_all[LDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int comp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // this wave's component
-    float* lds = lds_all + comp * 2 * G::BUF;
-    float* lds_sh = lds_all + NC * 2 * G::BUF;
+    float* lds = lds_all + comp * 2 * PB;
+    float* lds_sh = lds_all + NC * 2 * PB;
     const int r = lane & 15, kq = lane >> 4;
     const int tile = blockIdx.x;
     const int mi = tile / a.n_ntiles, ni = tile - mi * a.n_ntiles;
-    const int u0 = mi * 16, n0 = ni * 16;
-    f32x4 acc;
+    const int u0 = mi * 16, n0 = ni * 16 * NW;
+    f32x4 acc[NW];
     switch (comp) {                                                    // wave-uniform: one scalar branch per wave
-        case 0: acc = small_chain<NC, KC, 0, SH>(a, lds, lds_sh, lane, u0, n0); break;
-        case 1: acc = small_chain<NC, KC, 1, SH>(a, lds, lds_sh, lane, u0, n0); break;
-        case 2: acc = small_chain<NC, KC, 2, SH>(a, lds, lds_sh, lane, u0, n0); break;
-        case 3: acc = small_chain<NC, KC, 3, SH>(a, lds, lds_sh, lane, u0, n0); break;
-        case 4: acc = small_chain<NC, KC, (NC > 4 ? 4 : 0), SH>(a, lds, lds_sh, lane, u0, n0); break;
-        default: acc = small_chain<NC, KC, (NC > 4 ? 5 : 0), SH>(a, lds, lds_sh, lane, u0, n0); break;
+        case 0: small_chain<NC, KC, 0, SH, NW>(a, lds, lds_sh, lane, u0, n0, acc); break;
+        case 1: small_chain<NC, KC, 1, SH, NW>(a, lds, lds_sh, lane, u0, n0, acc); break;
+        case 2: small_chain<NC, KC, 2, SH, NW>(a, lds, lds_sh, lane, u0, n0, acc); break;
+        case 3: small_chain<NC, KC, 3, SH, NW>(a, lds, lds_sh, lane, u0, n0, acc); break;
+        case 4: small_chain<NC, KC, (NC > 4 ? 4 : 0), SH, NW>(a, lds, lds_sh, lane, u0, n0, acc); break;
+        default: small_chain<NC, KC, (NC > 4 ? 5 : 0), SH, NW>(a, lds, lds_sh, lane, u0, n0, acc); break;
     }
 
     // ---- the components meet: [comp][lane] x 4 floats in LDS (the staging images are dead), one barrier, then wave h of
@@ -293,50 +303,59 @@ __global__ __launch_bounds__(64 * NC) void conv_small_f32_kernel(const SmallArgs
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias_bytes, 0x00020000);
     __syncthreads();                                                   // every wave is done with its staging image
     f32x4* meet = reinterpret_cast<f32x4*>(lds_all);
-    meet[comp * 64 + lane] = acc;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) meet[(j * NC + comp) * 64 + lane] = acc[j];
     __syncthreads();
     constexpr int PR = NC == 4 ? 1 : 2;            // pooled rows per unit
     if (comp >= PR) return;
     const int h = comp;
-    f32x4 m[NC];
-#pragma unroll
-    for (int q = 0; q < NC; ++q) m[q] = meet[q * 64 + lane];
-    const int col = n0 + 4 * kq;
-    const f32x4 bi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (unsigned)col * 4u, 0, 0));
-    const unsigned coloff = col < a.cp_out ? (unsigned)col * 4u : kOob;
     const int pr = PR * (u0 + r) + h;              // pooled row of the launch
     const int b = pr / a.P_out;
     const int pin = pr - b * a.P_out;
     const bool in_range = pr < a.rows_out && b < a.n_blocks;
     const bool valid = in_range && pin < (a.len[in_range ? b : 0] >> a.shift_out);
-    f32x4 o;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float y0, y1;
-        if constexpr (NC == 4) {
-            const float m1 = m[0][q], m2 = m[1][q], m3 = m[2][q], m4 = m[3][q];
-            y0 = (m1 + m2) + m3;
-            y1 = (m2 - m3) - m4;
-        } else {
-            const float m0_ = m[0][q], m1 = m[1][q], m2 = m[2][q], m3 = m[3][q], m4 = m[4][q], m5 = m[5][q];
-            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-            if (h == 0) {
-                y0 = (m0_ + s12) + s34;
-                y1 = fmaf(2.0f, d34, d12);
+    for (int j = 0; j < NW; ++j) {
+        f32x4 m[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) m[q] = meet[(j * NC + q) * 64 + lane];
+        const int col = n0 + 16 * j + 4 * kq;
+        const f32x4 bi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (unsigned)col * 4u, 0, 0));
+        const unsigned coloff = col < a.cp_out ? (unsigned)col * 4u : kOob;
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float y0, y1;
+            if constexpr (NC == 4) {
+                const float m1 = m[0][q], m2 = m[1][q], m3 = m[2][q], m4 = m[3][q];
+                y0 = (m1 + m2) + m3;
+                y1 = (m2 - m3) - m4;
             } else {
-                y0 = fmaf(4.0f, s34, s12);
-                y1 = fmaf(8.0f, d34, d12) + m5;
+                const float m0_ = m[0][q], m1 = m[1][q], m2 = m[2][q], m3 = m[3][q], m4 = m[4][q], m5 = m[5][q];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                if (h == 0) {
+                    y0 = (m0_ + s12) + s34;
+                    y1 = fmaf(2.0f, d34, d12);
+                } else {
+                    y0 = fmaf(4.0f, s34, s12);
+                    y1 = fmaf(8.0f, d34, d12) + m5;
+                }
             }
+            o[q] = valid ? fmaxf(fmaxf(y0, y1) + bi[q], 0.0f) : 0.0f;
         }
-        o[q] = valid ? fmaxf(fmaxf(y0, y1) + bi[q], 0.0f) : 0.0f;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_y,
+                                               in_range ? (unsigned)pr * (unsigned)(a.cp_out * 4) + coloff : kOob, 0, 0);
     }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_y,
-                                           in_range ? (unsigned)pr * (unsigned)(a.cp_out * 4) + coloff : kOob, 0, 0);
 }
 
 using KernelFn = void (*)(const SmallArgs);
 
-KernelFn pick(int nc, int kc, bool shared = false) {
+KernelFn pick(int nc, int kc, bool shared = false, int nw = 1) {
+    if (shared && nw == 2) {
+        if (nc == 4) return kc == 16 ? conv_small_f32_kernel<4, 16, true, 2> : kc == 20 ? conv_small_f32_kernel<4, 20, true, 2>
+                          : kc == 24 ? conv_small_f32_kernel<4, 24, true, 2> : nullptr;
+        return kc == 16 ? conv_small_f32_kernel<6, 16, true, 2> : kc == 20 ? conv_small_f32_kernel<6, 20, true, 2> : nullptr;
+    }
     if (shared) {
         if (nc == 4) return kc == 16 ? conv_small_f32_kernel<4, 16, true> : kc == 20 ? conv_small_f32_kernel<4, 20, true>
                           : kc == 24 ? conv_small_f32_kernel<4, 24, true> : nullptr;
@@ -355,29 +374,47 @@ int64_t conv_small_f32_waves(const ConvLayerDev& L, int64_t rows_in) {
     return ((units + 15) / 16) * (int64_t)(round_up(L.c_out, 16) / 16);
 }
 
-// Estimate in shader cycles, fitted to tools/layer_times.py at 1 ... 32 reads (round 5: the shared-input form, every layer
-// forced onto this kernel - profiles/r05_small_kernel_shared_input_rows.txt): a wave's chain is C_in / 4 k-steps of ~145 cycles
-// (F(4,3): six waves on four SIMDs) or ~75 (F(2,3): four waves) plus ~2500 of prologue and output transform; a launch lasts
-// as long as its most loaded CU, whose second and later workgroups cost 1.6 (1.2) chains each (layer 10: 21 / 21 / 39 / 56 us
-// at 71 / 142 / 284 / 568 workgroups; layer 11: 18 / 20 / 27 / 49 us at 107 / 214 / 428 / 856); + launch, prologue and the
-// timing events' own cost, like the tiled kernels' thin-launch fit it is compared with.
-double conv_small_f32_cost(const ConvLayerDev& L, int64_t rows_in, int num_cu) {
+// Estimate in shader cycles, fitted to tools/layer_times.py at 1 ... 64 reads with every layer forced onto this kernel
+// (profiles/r05_small_kernel_shared_input_rows.txt, r05_small_kernel_two_channel_subtiles.txt): a wave's chain is C_in / 4
+// k-steps of ~131 cycles (F(4,3): six waves on four SIMDs; 210 with two channel sub-tiles per wave) or ~70 (F(2,3): four waves;
+// 121) plus ~2500 of prologue and output transform; several workgroups share a CU (35-50 KB of LDS each) and a launch lasts
+// 0.75 + 1.15 W (F(4,3)) resp. 0.35 + 1.1 W (F(2,3)) chains for W workgroups per CU (layer 10, one sub-tile: 21 / 21 / 31 / 46 /
+// 76 us at 71 / 142 / 284 / 568 / 1136 workgroups; two: 27 / 28 / 28 / 44 / 65 at half as many); + launch, prologue and the timing
+// events' own cost, like the tiled kernels' thin-launch fit it is compared with.  *nw_out: the cheaper number of sub-tiles.
+double conv_small_f32_cost(const ConvLayerDev& L, int64_t rows_in, int num_cu, int* nw_out) {
     const double ksteps = (L.cp_in + 3) / 4;
-    const double per_step = L.wino_m == 4 ? 145.0 : 75.0;
-    const int64_t per_cu = (conv_small_f32_waves(L, rows_in) + num_cu - 1) / num_cu;
-    const double chains = 1.0 + (L.wino_m == 4 ? 1.6 : 1.2) * (double)(per_cu > 1 ? per_cu - 1 : 0);
-    return (ksteps * per_step + 2500.0) * chains + 23000.0;
+    const bool f43 = L.wino_m == 4;
+    const int64_t wgs1 = conv_small_f32_waves(L, rows_in);
+    const int64_t n16 = round_up(L.c_out, 16) / 16;
+    double best = 1e300;
+    for (int nw = 1; nw <= 2; ++nw) {
+        const int64_t wgs = wgs1 / n16 * ((n16 + nw - 1) / nw);
+        const double per_step = f43 ? (nw == 1 ? 131.0 : 210.0) : (nw == 1 ? 70.0 : 121.0);
+        const double w = (double)wgs / num_cu;
+        const double chains = std::max(1.0, f43 ? 0.75 + 1.15 * w : 0.35 + 1.1 * w);
+        const double cost = (ksteps * per_step + 2500.0) * chains + 23000.0;
+        if (cost < best) {
+            best = cost;
+            if (nw_out) *nw_out = nw;
+        }
+    }
+    return best;
 }
 
 bool conv_small_f32_ok(const ConvLayerDev& L) { return pick(L.wino_m == 4 ? 6 : 4, L.plan.kc) != nullptr; }
 
 int launch_conv_small_f32(const ConvLayerDev& L, const float* d_x, float* d_y, const int32_t* d_len, int B, int P_in,
-                          int layer_index, hipStream_t st, int* bm_out, int* bn_out) {
+                          int layer_index, int num_cu, hipStream_t st, int* bm_out, int* bn_out) {
     const int nc = L.wino_m == 4 ? 6 : 4;
     // the input rows of a tile are staged once per workgroup (RS_SMALL_SHARED=0: once per wave, the round-4 form, kept as a
     // cross-check: 20-35 % slower at every launch size)
     const bool shared = L.hooks->small_shared != 0;
-    KernelFn fn = pick(nc, L.plan.kc, shared);
+    // one or two channel sub-tiles per wave: the cost model's choice (RS_SMALL_NW forces 1 / 2)
+    int nw = 1;
+    conv_small_f32_cost(L, (int64_t)B * P_in, num_cu, &nw);
+    if (!shared) nw = 1;
+    else if (L.hooks->small_nw > 0) nw = std::min(2, L.hooks->small_nw);
+    KernelFn fn = pick(nc, L.plan.kc, shared, nw);
     if (!fn) {
         set_error("conv_small_f32: unsupported channel chunk %d", L.plan.kc);
         return RS_ERR_ARG;
@@ -407,13 +444,13 @@ int launch_conv_small_f32(const ConvLayerDev& L, const float* d_x, float* d_y, c
     a.cp_out = L.cp_out;
     a.nch = L.plan.nch;
     a.shift_out = layer_index + 1;
-    a.n_ntiles = round_up(L.c_out, 16) / 16;
+    a.n_ntiles = (round_up(L.c_out, 16) / 16 + nw - 1) / nw;
     a.n_blocks = B;
     const int n_mtiles = (a.units + 15) / 16;
     hipLaunchKernelGGL(fn, dim3((unsigned)(n_mtiles * a.n_ntiles)), dim3(64 * nc), 0, st, a);
     RS_HIP(hipGetLastError());
     if (bm_out) *bm_out = 16 * (nc == 6 ? 4 : 2);      // conv rows per tile, as the tiled kernels report them
-    if (bn_out) *bn_out = 16;
+    if (bn_out) *bn_out = 16 * nw;
     return RS_OK;
 }
 

@@ -46,8 +46,9 @@ def test_small_batches_equal_the_tiled_kernels_bitwise(dev, models, lens):
     want = tiled.classify_raw(sig, off, ln, lh, return_logits=True)
     got = small.classify_raw(sig, off, ln, lh, return_logits=True)
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
-    # the small kernel really ran: its tile report for the last layer is 16 channels wide
-    assert small.layer_info()[11]["bn"] == 16 and tiled.layer_info()[11]["bn"] > 16
+    # the small kernel really ran: its tile report for the last layer is 16 pooled rows (32 conv rows) tall - the smallest
+    # tiled shape is 32 pooled rows
+    assert small.layer_info()[11]["bm"] == 32 and tiled.layer_info()[11]["bm"] > 32
     oracle = ro.classify_reads(synth.make_state_dict(1), sigs)
     assert np.abs(got[0].cpu().numpy() - oracle).max() < 1e-4
 
@@ -62,7 +63,7 @@ def test_a_read_alone_equals_its_row_of_a_large_batch(dev, models):
     sigs = _reads(lens, first=9000)
     sig, off, ln, lh = pack_reads(sigs, dev)
     big = small.classify_raw(sig, off, ln, lh).cpu().numpy()
-    assert small.layer_info()[11]["bn"] > 16                      # the large batch stayed on the tiled kernels
+    assert small.layer_info()[11]["bm"] > 32                      # the large batch stayed on the tiled kernels
     for k in (0, 17, 151, 299):
         s1, o1, l1, h1 = pack_reads([sigs[k]], dev)
         assert np.array_equal(small.classify_raw(s1, o1, l1, h1).cpu().numpy()[0], big[k])
@@ -87,7 +88,7 @@ def test_hand_over_between_the_kernels(dev, models, B):
     assert torch.equal(small.classify_raw(sig, off, ln, lh), want)
     assert torch.equal(always.classify_raw(sig, off, ln, lh), want)
     info = always.layer_info()
-    assert all(info[i]["bn"] == 16 for i in range(2, 12))
+    assert all(info[i]["bn"] in (16, 32) and info[i]["bm"] in (32, 64) for i in range(2, 12))   # 16 units x 16 or 32 channels
 
 
 @pytest.mark.parametrize("B", [5, 16, 40, 72, 130])
@@ -105,6 +106,8 @@ def test_thin_launch_forms_keep_the_bits(dev, models, B):
         "round 4": {"RS_SMALL_F32_WAVES": "0", "RS_FORCE_SHAPE_WINO4": big4, "RS_FORCE_SHAPE_WINO": big2, "RS_SF32_MIN_RUN": "8"},
         "default staging": {"RS_NO_DEEP_STAGING": "1", "RS_SMALL_F32_WAVES": "0"},
         "private rows": {"RS_SMALL_SHARED": "0"},
+        "one channel sub-tile": {"RS_SMALL_NW": "1"},
+        "two channel sub-tiles": {"RS_SMALL_NW": "2", "RS_SMALL_F32_WAVES": "100000000"},
         "runs of one": {"RS_SF32_MIN_RUN": "1"},
     }
     rng = np.random.default_rng(100 + B)
