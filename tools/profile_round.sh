@@ -13,6 +13,7 @@ ARGS="--dtype $DT --steps 20 --warmup 3 --no-cpu-baseline --no-latency --no-vari
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench.json" 2> "$OUT/trace.err" || { tail -5 "$OUT/trace.err"; exit 1; }
 cp "$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
+cp "$ROOT"/gpurun_out/bench_detail_*_"$DT".json "$OUT/bench_detail.json" 2>/dev/null   # the traced run's verbose objects (per-layer tile shapes)
 echo "[profile] trace done" 
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_mfma" -- python3 "$ROOT/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_mfma.err" || { tail -5 "$OUT/pmc_mfma.err"; exit 1; }
 python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_mfma" > "$OUT/pmc_mfma.json"
