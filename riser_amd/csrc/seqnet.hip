@@ -608,7 +608,6 @@ __global__ __launch_bounds__(64 * WAVES) void seq_basic_block_kernel(const Block
         const int bb = tile / a.tiles_per_read;
         const int T_in = a.tin ? as_const_len(a.tin)[bb] : a.T_in, T_out = a.tout ? as_const_len(a.tout)[bb] : a.T_out;
         if (to0 >= T_out) continue;                            // ragged batch: this read ended before the tile
-        const int lim = T_in * a.c_in;
         const bool interior = to0 >= 2 && to0 + TO <= T_out && (to0 + R - 2) * a.stride + 6 <= T_in;
         if (interior)
             do_tile(tile, std::false_type{});
