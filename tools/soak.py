@@ -51,12 +51,13 @@ def main():
             done += period
             if done in (period * 4, ) or done >= args.batches or done % (period * 50) == 0:
                 torch.cuda.synchronize()
+                recent = np.asarray(list(ctl.batch_latencies)[-256:]) * 1e3
                 marks.append((done, torch.cuda.memory_allocated(dev) >> 20, torch.cuda.memory_reserved(dev) >> 20,
-                              resource.getrusage(resource.RUSAGE_SELF).ru_maxrss >> 10))
+                              resource.getrusage(resource.RUSAGE_SELF).ru_maxrss >> 10, float(np.median(recent))))
         ctl.finish()
         lat = np.asarray(ctl.batch_latencies) * 1e3
     for m in marks:
-        print("after %6d batches: device allocated %d MiB, reserved %d MiB, host max RSS %d MiB" % m)
+        print("after %6d batches: device allocated %d MiB, reserved %d MiB, host max RSS %d MiB, p50 of the last 256 batches %.3f ms" % m)
     k = min(1000, lat.size // 3)
     print(f"latency p50 first {k}: {np.median(lat[8:k]):.3f} ms, last {k}: {np.median(lat[-k:]):.3f} ms, max overall {lat[8:].max():.3f} ms over {lat.size} batches")
 
