@@ -341,10 +341,41 @@ class Model:
             # the reference cannot classify ONE read with this head: x.squeeze() (riser/nets/cnn.py:48-49) drops the batch
             # dimension and softmax(dim=1) (riser/model.py:27) raises this; the batched entry points below run it
             raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1)")
-        x = torch.from_numpy(np.ascontiguousarray(signal)).unsqueeze(0)
-        x = x.to(self.device, dtype=torch.float)
-        lens = np.array([x.shape[1]], dtype=np.int32)
-        return self.forward_batch(x, lens)[0]
+        sig = np.ascontiguousarray(signal)
+        if sig.ndim != 1:
+            raise ValueError("classify takes ONE normalised signal [L]; classify_batch takes several")
+        n = int(sig.shape[0])
+        lens = np.array([n], dtype=np.int32)
+        if self.device.type != "cuda" or n == 0:
+            x = torch.from_numpy(sig).unsqueeze(0).to(self.device, dtype=torch.float)
+            return self.forward_batch(x, lens)[0]
+        # the reference's loop calls this once per read (riser/control.py:68-69): the signal and its length go to the device
+        # through pinned staging slots as asynchronous copies on the caller's stream (a pageable .to() is two blocking copies
+        # of ~24 us each that also serialise the host with the previous call's kernels)
+        slot = self._classify_slot(n)
+        slot["free"].synchronize()                                     # the slot's previous copies have left the host buffer
+        slot["x"][:n].copy_(torch.from_numpy(sig))                     # any float dtype / the int64 zeros of mad == 0 -> fp32
+        slot["len"][0] = n
+        x = torch.empty((1, n), dtype=torch.float32, device=self.device)
+        ln = torch.empty((1,), dtype=torch.int32, device=self.device)
+        x.copy_(slot["x"][:n].unsqueeze(0), non_blocking=True)
+        ln.copy_(slot["len"], non_blocking=True)
+        slot["free"].record()
+        return self.forward_batch(x, lens, lens_dev=ln)[0]
+
+    def _classify_slot(self, n: int):
+        """pinned staging for classify(): four slots used in turn, each with an event that says its last copies are done"""
+        slots = self.__dict__.setdefault("_cls_slots", [])
+        k = self.__dict__.get("_cls_next", 0)
+        self._cls_next = (k + 1) & 3
+        if len(slots) <= k:
+            slots.append({"x": torch.empty(max(n, 16384), dtype=torch.float32).pin_memory(),
+                          "len": torch.empty(1, dtype=torch.int32).pin_memory(), "free": torch.cuda.Event()})
+        slot = slots[k]
+        if slot["x"].numel() < n:
+            slot["free"].synchronize()
+            slot["x"] = torch.empty(n, dtype=torch.float32).pin_memory()
+        return slot
 
     def classify_batch(self, signals, lengths=None, return_logits: bool = False):
         """Batched classify of already-normalised signals.
