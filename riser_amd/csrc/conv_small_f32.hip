@@ -10,12 +10,14 @@
 //
 // Here the unit of work is ONE WORKGROUP = one 16 x 16 accumulator tile (16 pooled rows / F(4,3) groups x 16 output
 // channels) over the whole reduction, ONE WAVE per Winograd component:
-//   * no barrier in the loop: every wave streams its own operands from L2 / Infinity Cache in 16-byte units, three chunks
-//     of the reduction ahead, through registers into a wave-private LDS image and reads its MFMA fragments from there (the
-//     weights of a tile are read exactly once; the few activation rows are shared by every wave of the launch and stay in
-//     L2);
+//   * every wave streams its component's weights from L2 / Infinity Cache in 16-byte units, three chunks of the reduction
+//     ahead, through registers into a wave-private LDS image and reads its MFMA fragments from there (the weights of a tile
+//     are read exactly once); the tile's input rows are staged ONCE per workgroup - every wave loads 1 / NC of them into an
+//     image the waves share, three buffers, one barrier per chunk (round 5; round 4 staged them once per WAVE with no barrier
+//     in the loop: RS_SMALL_SHARED=0);
 //   * a launch is (rows / 16) x (C_out / 16) workgroups - 107 for layer 11 at batch 1 - spread over the chip, each wave a
-//     chain of C_in / 4 MFMAs.
+//     chain of C_in / 4 MFMAs; from ~2 workgroups per CU up a wave takes TWO channel sub-tiles (NW = 2: half the workgroups,
+//     two MFMAs per k-step on one transformed input fragment).
 // The MFMA sequence per accumulator (chunk order, k-step order, operand roles, the Winograd input and output transforms
 // and every rounding in them) is that of the tiled kernels, so the results are BIT-IDENTICAL to theirs: a read classified
 // alone equals its row of a 512-read batch (tests/test_gpu_small.py).  The launch planner picks this kernel when the
@@ -67,13 +69,14 @@ struct SmallArgs {
 // them side by side - a single wave issuing everything (fragment reads, transforms, staging and NC MFMAs per k-step, which
 // in fp32 do not overlap: DESIGN.md 5) ran layer 11 in 51 us, 3.4x its MFMA time.
 // Per chunk of KC input channels a wave moves ITS operands in 16-byte units - its component's 16 weight rows x KC floats
-// and the tile's AR = 16 STRIDE + (R - STRIDE) input rows x KC floats (every wave its own copy: 3-6 KB from L2, no barrier
-// to share one) - global -> registers (kDepth chunks ahead, ~8 loads per chunk: the whole look-ahead fits the 6-bit vmcnt
+// and (round 4 form, SH = false) the tile's AR = 16 STRIDE + (R - STRIDE) input rows x KC floats (every wave its own copy:
+// 3-6 KB from L2, no barrier to share one; SH = true: its 1 / NC share of them, into the shared image) - global -> registers (kDepth chunks ahead, ~8 loads per chunk: the whole look-ahead fits the 6-bit vmcnt
 // counter) -> wave-private LDS -> MFMA fragments (ds_read_b32 at the tiled kernels' conflict-free pitch of KC + 2 floats,
 // input rows split into STRIDE planes by row mod STRIDE so that the lanes of a fragment read walk consecutive rows of one
 // plane).  The chunk's byte offset is a SCALAR operand of the buffer loads: no per-lane address arithmetic in the loop.
-// LDS operations of one wave execute in order and no other wave touches its image: no barrier in the loop; ONE at the end,
-// where the component accumulators meet in LDS for the output transform.
+// LDS operations of one wave execute in order and no other wave touches its private image: no barrier in the loop for
+// the weights (SH = false: none at all; SH = true: one per chunk for the shared input rows); ONE at the end, where the
+// component accumulators meet in LDS for the output transform.
 template <int NC, int KC, int NW = 1>
 struct SmallGeom {
     static constexpr int R = NC == 4 ? 4 : 6;             // input rows of a unit
