@@ -403,6 +403,15 @@ def side_variants(args, device, wl, ref):
         pv = torch.empty((B, 2), dtype=torch.float32, device=device)
         dtv = timed(lambda: mv.classify_raw(sig, off, ln, lens, out=pv))
         entry = {"chunks_per_s": round(B / dtv, 1), "ms_per_step": round(dtv * 1e3, 4), "batch": B, **versus_ref(pv.cpu().numpy())}
+        if dt == "bf16x3":                       # thin batches in split precision too (the fp32 figures: thin_batches_f32 below)
+            thin3 = {}
+            for tb in (1, 16, 32, 64):
+                t_lens = np.full(tb, L, dtype=np.int32)
+                t_off = torch.from_numpy(np.arange(tb, dtype=np.int64) * L).to(device)
+                t_len = torch.from_numpy(t_lens).to(device)
+                pt = torch.empty((tb, 2), dtype=torch.float32, device=device)
+                thin3[str(tb)] = round(timed(lambda: mv.classify_raw(sig, t_off, t_len, t_lens, out=pt)) * 1e3, 4)
+            variants["thin_batches_bf16x3"] = {"ms_per_step_by_reads": thin3, "chunk_samples": L}
         if dt in ("f16", "bf16"):                # plain 16-bit: fast, outside the 1e-3 tolerance
             variants.setdefault("approximate", {})[dt] = entry
         else:
@@ -965,6 +974,9 @@ def compact_line(detail, args, model, wl):
     thin = (detail.get("variants") or {}).get("thin_batches_f32")
     if thin:
         roof["thin_batch_ms_f32"] = thin["ms_per_step_by_reads"]      # reads of 16000 samples per call -> ms per call
+    thin3 = (detail.get("variants") or {}).get("thin_batches_bf16x3")
+    if thin3:
+        roof["thin_batch_ms_bf16x3"] = thin3["ms_per_step_by_reads"]
     line["roofline"] = roof
     cb = detail.get("cpu_baseline")
     if cb:
