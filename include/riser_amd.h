@@ -65,7 +65,12 @@ typedef enum rs_dtype {
                                v_mfma_f32_16x16x32_bf16 with fp32 accumulate.  The 16-bit mode that meets the 1e-3
                                probability tolerance of BASELINE configs 3 / 5; RS_BF16 / RS_F16 are the fast,
                                approximate variants */
-    RS_F16X3 = 5            /* the same with f16 pairs (~22 significand bits above 2^-14, less below) */
+    RS_F16X3 = 5,           /* the same with f16 pairs (~22 significand bits above 2^-14, less below) */
+    RS_F16XF8 = 6           /* RS_F16X3 whose wide layers keep hi*hi on v_mfma_f32_16x16x32_f16 and evaluate the two cross
+                               terms hi*lo + lo*hi as ONE K-concatenated product of OCP e4m3 values on the block-scaled
+                               v_mfma_scale_f32_16x16x128_f8f6f4 (an E8M0 scale per activation row and 32 channels): two
+                               instruction times per 64 K where split precision spends three; probabilities within ~3e-4
+                               of fp32 (inside the 1e-3 tolerance), same activation range as RS_F16X3 */
 } rs_dtype;
 
 /* decisions of riser/control.py:75-82, as written into rs_decide's output */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RISER_AMD_LIB") or os.path.join(_HERE, "lib", "libriser_amd.so")
 
 RS_OK = 0
-RS_F32, RS_BF16, RS_F16, RS_F32W, RS_BF16X3, RS_F16X3 = 0, 1, 2, 3, 4, 5
+RS_F32, RS_BF16, RS_F16, RS_F32W, RS_BF16X3, RS_F16X3, RS_F16XF8 = 0, 1, 2, 3, 4, 5, 6
 RS_TRY_AGAIN, RS_ACCEPT, RS_REJECT, RS_NO_DECISION = 0, 1, 2, 3
 RS_ENRICH, RS_DEPLETE = 0, 1
 DECISION_NAMES = ("try_again", "accept", "reject", "no_decision")

@@ -120,7 +120,8 @@ constexpr size_t kAlign = 256;
 inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 // storage type of the activations: the Winograd fp32 path shares every non-conv kernel with RS_F32
-int act_dtype(const rs_model* m) { return m->dtype == RS_F32W ? RS_F32 : m->dtype; }
+// (RS_F16XF8 is RS_F16X3 everywhere but in the wide layers' conv kernel and their rows)
+int act_dtype(const rs_model* m) { return m->dtype == RS_F32W ? RS_F32 : m->dtype == RS_F16XF8 ? RS_F16X3 : m->dtype; }
 int esize(const rs_model* m) { return act_dtype(m) == RS_F32 ? 4 : 2; }
 // 16-bit storage type of a mode (RS_BF16 or RS_F16), also for the split-precision modes
 int base16(int dtype) { return is_f16_family(dtype) ? RS_F16 : RS_BF16; }
@@ -263,9 +264,12 @@ WsLayout ws_layout(const rs_model* m, int B, int Lmax) {
     for (int i = 0; i < m->n_layers; ++i) {                       // layer i's output buffer
         const bool fine = two && i < m->split;
         const size_t rows = fine ? (size_t)w.nb_f_max * (w.Uf >> (i + 1)) : (size_t)w.nb_max * (w.U >> (i + 1));
-        buf = std::max(buf, rows * m->cp[i] * esize(m));
+        // F8 rows carry their scale plane behind them (conv_ring_f8.hip)
+        const bool f8 = i + 1 < m->n_layers && m->layers[i + 1].f8_in;
+        auto bytes_of = [&](size_t r) { return f8 ? f8_scale_offset((int64_t)r, m->cp[i]) + f8_scale_bytes((int64_t)r, m->cp[i]) : r * m->cp[i] * esize(m); };
+        buf = std::max(buf, bytes_of(rows));
         if (two && i == m->split - 1)                             // ... and its re-packed copy in the coarse layout
-            buf = std::max(buf, (size_t)w.nb_max * (w.U >> (i + 1)) * m->cp[i] * esize(m));
+            buf = std::max(buf, bytes_of((size_t)w.nb_max * (w.U >> (i + 1))));
     }
     buf = align_up(buf + kAlign);
     w.rbase_off = 0;
@@ -382,6 +386,31 @@ unsigned short to_h16(float f, int dtype) {
     return (unsigned short)(u >> 16);
 }
 
+// fp32 -> OCP e4m3 (bias 7, largest finite 448, subnormals of 2^-9), round to nearest even, saturating
+unsigned char to_e4m3(float f) {
+    const unsigned char sign = std::signbit(f) ? 0x80 : 0x00;
+    float a = fabsf(f);
+    if (!(a == a)) return (unsigned char)(sign | 0x7f);
+    if (a >= 448.0f) return (unsigned char)(sign | 0x7e);
+    int e = a > 0.0f ? ilogbf(a) : -127;
+    if (e < -6) e = -6;                                       // subnormal quantum 2^-9
+    const float q = ldexpf(1.0f, e - 3);
+    const float n = nearbyintf(a / q);                        // half to even (default rounding mode); n <= 16
+    if (n == 0.0f) return sign;
+    int m = (int)n, ee = e;
+    if (m == 16) {                                            // rounded up into the next binade
+        m = 8;
+        ++ee;
+    }
+    if (m < 8) return (unsigned char)(sign | m);              // subnormal: exponent field 0
+    return (unsigned char)(sign | ((ee + 7) << 3) | (m - 8));
+}
+
+// RS_F16XF8: layer i can take part in a run of F8 rows (conv_ring_f8.hip): a tiled layer with at least one whole 64-channel panel
+bool f8_eligible(int dtype, int i, int n_layers, const int32_t* channels) {
+    return dtype == RS_F16XF8 && i >= 3 && i < n_layers && channels[i - 1] >= 64 && !getenv("RS_NO_F8");
+}
+
 template <class T>
 int upload(T** dptr, const std::vector<T>& h) {
     RS_HIP(hipMalloc(reinterpret_cast<void**>(dptr), std::max<size_t>(h.size(), 1) * sizeof(T)));
@@ -419,7 +448,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         set_error("rs_model_create: n_classes must be 2 (got %d)", n_classes);
         return RS_ERR_ARG;
     }
-    if (dtype != RS_F32 && dtype != RS_BF16 && dtype != RS_F16 && dtype != RS_F32W && !is_x3(dtype)) {
+    if (dtype != RS_F32 && dtype != RS_BF16 && dtype != RS_F16 && dtype != RS_F32W && !is_x3(dtype)) {      // is_x3: RS_F16XF8 too
         set_error("rs_model_create: unknown dtype %d", dtype);
         return RS_ERR_ARG;
     }
@@ -450,6 +479,9 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         // out as [hi x 32 | lo x 32] (conv_ring_h16.hip)
         m->cp[i] = is_x3(dtype) ? 64 * ((channels[i] + 31) / 32)
                                 : round_up(channels[i], (dtype == RS_F32 || dtype == RS_F32W) ? 4 : 8);
+        // RS_F16XF8: the rows between two layers of a run are F8 rows: 128 elements (an H and an F panel) per 64 channels
+        if (f8_eligible(dtype, i, n_layers, channels) && f8_eligible(dtype, i + 1, n_layers, channels))
+            m->cp[i] = 128 * ((channels[i] + 63) / 64);
     }
     int rc = RS_OK;
     {   // layer 0: (w0, w1, w2, bias) per output channel
@@ -470,6 +502,8 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         L.cp_in = m->cp[i - 1];
         L.cp_out = m->cp[i];
         L.x3_terms = x3_terms_of(i);
+        L.f8_in = f8_eligible(dtype, i, n_layers, channels) && f8_eligible(dtype, i - 1, n_layers, channels);
+        L.f8_out = f8_eligible(dtype, i, n_layers, channels) && f8_eligible(dtype, i + 1, n_layers, channels);
         if (dtype == RS_F32) {
             L.plan = plan_static_f32(L.cp_in, L.c_out);
             const ConvPlan& p = L.plan;
@@ -537,7 +571,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             p.nch = (L.c_in + 31) / 32;
             // rows of the packed weight / bias tables: the channels (split precision: all 32 slots of the last panel,
             // every one of which a tile covers) plus zero rows for the widest tile's overhang
-            p.n_alloc = (x3 ? 32 * ((L.c_out + 31) / 32) : round_up(L.c_out, 16)) + conv_ring_max_bn();
+            p.n_alloc = (L.f8_out ? 64 * ((L.c_out + 63) / 64) : x3 ? 32 * ((L.c_out + 31) / 32) : round_up(L.c_out, 16)) + conv_ring_max_bn();
             if (!x3) {
                 p.nch = (L.cp_in + 31) / 32;
                 std::vector<unsigned short> wp((size_t)p.nch * 3 * p.n_alloc * 32, 0);
@@ -555,7 +589,28 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             // ring packing [panel][tap][n_alloc][64] (conv_ring_h16.hip): a panel is 64 input channels, or 32 input
             // channels as [hi x 32 | lo x 32] with lo = round(w - hi) in split precision
             L.ring_panels = x3 ? (L.c_in + 31) / 32 : (L.cp_in + 63) / 64;
-            if (rc == RS_OK) {
+            if (rc == RS_OK && L.f8_in) {
+                // F8 rows (conv_ring_f8.hip): per 64 input channels an H panel (hi16 x 64) and an F panel of e4m3 bytes
+                // [lo8 c0-31 | hi8 c0-31 | lo8 c32-63 | hi8 c32-63], hi8 = e4m3(hi 2^-6), lo8 = e4m3((w - hi) 2^5)
+                L.ring_panels = 2 * ((L.c_in + 63) / 64);
+                std::vector<unsigned short> wr((size_t)L.ring_panels * 3 * p.n_alloc * 64, 0);
+                unsigned char* wb = reinterpret_cast<unsigned char*>(wr.data());
+                for (int n = 0; n < L.c_out; ++n)
+                    for (int ci = 0; ci < L.c_in; ++ci)
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const float wv = conv_w[i][((size_t)n * L.c_in + ci) * 3 + kw] * ws;
+                            const unsigned short hi = to_h16(wv, st16);
+                            const float hf = from_h16(hi, st16);
+                            const int pn = ci / 64, cc = ci - pn * 64;
+                            wr[(((size_t)(2 * pn) * 3 + kw) * p.n_alloc + n) * 64 + cc] = hi;
+                            const size_t fb = ((((size_t)(2 * pn + 1) * 3 + kw) * p.n_alloc + n) * 64) * 2 + (cc >> 5) * 64 + (cc & 31);
+                            wb[fb] = to_e4m3(ldexpf(wv - hf, 5));
+                            wb[fb + 32] = to_e4m3(ldexpf(hf, -6));
+                        }
+                unsigned short* dw2 = nullptr;
+                rc = upload(&dw2, wr);
+                L.d_w2 = dw2;
+            } else if (rc == RS_OK) {
                 std::vector<unsigned short> wr((size_t)L.ring_panels * 3 * p.n_alloc * 64, 0);
                 for (int n = 0; n < L.c_out; ++n)
                     for (int ci = 0; ci < L.c_in; ++ci)
@@ -838,6 +893,13 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
             const size_t row_bytes = (size_t)m->cp[i - 1] * esize(m);
             rc = launch_repack_rows(buf[cur], buf[cur ^ 1], bt.fine, bt.plan, bt.NB, w.Uf >> i, w.U >> i, row_bytes, st);
             if (rc != RS_OK) return rc;
+            if (L.f8_in) {                                            // F8 rows: their scale plane moves with them
+                const int64_t rows_f = (int64_t)bt.NBf * (w.Uf >> i), rows_c = (int64_t)bt.NB * (w.U >> i);
+                rc = launch_repack_scales(static_cast<const char*>(buf[cur]) + f8_scale_offset(rows_f, L.cp_in),
+                                          static_cast<char*>(buf[cur ^ 1]) + f8_scale_offset(rows_c, L.cp_in), bt.fine, bt.plan, bt.NB,
+                                          w.Uf >> i, w.U >> i, L.cp_in / 128, f8_scale_stride(rows_f), f8_scale_stride(rows_c), st);
+                if (rc != RS_OK) return rc;
+            }
             cur ^= 1;
         }
         const bool fine = fine_layer(i);
@@ -878,8 +940,10 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         // every tiled 16-bit layer runs the LDS-DMA ring kernel (the register-staged kernel of round 1, conv_h16.hip, was its
         // bit-for-bit cross-check through round 3 and has been removed)
         const bool ring = !stream16 && (x3 || is16);
+        // RS_F16XF8: the wide layers read and / or write F8 rows (cross terms on the 8-bit MFMA: conv_ring_f8.hip)
+        const bool f8 = ring && (L.f8_in || L.f8_out);
         // ... and narrow layers whose whole weight tensor fits LDS next to two activation slabs on the weights-resident kernel
-        const bool wres = ring && conv_wres_h16_ok(L, x3);
+        const bool wres = ring && !f8 && conv_wres_h16_ok(L, x3);
         // fp32 Winograd layers of a launch with only a handful of rows (Model.classify at batch 1, a thin ReadUntil batch):
         // one wave per 16 x 16 tile instead of 256-row tiles that are mostly padding (conv_small_f32.hip; same bits)
         // (not layer 1 when layer 0 is folded into its staging: nothing has written that layer's input)
@@ -905,7 +969,7 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                             tiled, thin_fit ? "thin fit + launch" : "full-launch model", small32 ? "small" : "tiled");
             }
         }
-        const int kind = (stream32 || stream16 || wres || small32) ? 0 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)
+        const int kind = (stream32 || stream16 || wres || small32) ? 0 : f8 ? 6 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)
                                                                     : m->dtype == RS_F32 ? 3 : 4;
         m->last_ring[i] = ring;
         auto launch_layer = [&]() -> int {
@@ -934,7 +998,10 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                                             f0 ? d_x : nullptr, m->d_w0, m->channels[0], x3);
                 m->last_bm[i] = 16;
                 m->last_bn[i] = round_up(L.c_out, 16);
-            } else if (wres)
+            } else if (f8)
+                rc = launch_conv_ring_f8(L, buf[cur], buf[cur ^ 1], d_blen, NB, P_in, i, m->num_cu, check_dead, st, &m->last_bm[i],
+                                         &m->last_bn[i]);
+            else if (wres)
                 rc = launch_conv_wres_h16(L, buf[cur], buf[cur ^ 1], d_blen, NB, P_in, i, m->num_cu, f16, x3, check_dead, st,
                                           &m->last_bm[i], &m->last_bn[i]);
             else if (ring)
@@ -946,15 +1013,15 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
             }
             return rc;
         };
-        if (m->tuning && (kind == 1 || kind == 2 || kind == 5)) {
+        if (m->tuning && (kind == 1 || kind == 2 || kind == 5 || kind == 6)) {
             // rs_autotune: every feasible entry of the kernel's shape table on THIS layer's real input (the buffers hold the
             // activations of the batch; re-running a layer rewrites the same output), 1 warm + 3 timed launches each;
             // a shape replaces the planner's choice only if it is > 3 % faster
             const int n = kind == 1 ? conv_wino4_num_shapes() : kind == 2 ? conv_wino_num_shapes()
-                        : conv_ring_num_shapes();
+                        : kind == 6 ? conv_ring_f8_num_shapes() : conv_ring_num_shapes();
             auto ok = [&](int k) {
                 return kind == 1 ? conv_wino4_shape_ok(L, k) : kind == 2 ? conv_wino_shape_ok(L, k)
-                     : conv_ring_shape_ok(L, k);
+                     : kind == 6 ? conv_ring_f8_shape_ok(L, k) : conv_ring_shape_ok(L, k);
             };
             hipEvent_t e0, e1;
             RS_HIP(hipEventCreate(&e0));
@@ -996,7 +1063,10 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         if (rc != RS_OK) return rc;
         prof_mark(m, 1 + i, st);
         if (m->dbg_dst && m->dbg_layer == i) {
-            const size_t nb = std::min(m->dbg_bytes, (size_t)NB * (P_in / 2) * L.cp_out * esize(m));
+            const int64_t rows_out = (int64_t)NB * (P_in / 2);          // F8 rows: with the scale plane behind them
+            const size_t all = L.f8_out ? f8_scale_offset(rows_out, L.cp_out) + f8_scale_bytes(rows_out, L.cp_out)
+                                        : (size_t)rows_out * L.cp_out * esize(m);
+            const size_t nb = std::min(m->dbg_bytes, all);
             RS_HIP(hipMemcpyAsync(m->dbg_dst, buf[cur ^ 1], nb, hipMemcpyDeviceToDevice, st));
         }
         cur ^= 1;

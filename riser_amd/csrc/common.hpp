@@ -81,8 +81,8 @@ struct Hooks {
 };
 const Hooks& default_hooks();
 
-inline bool is_x3(int dtype) { return dtype == RS_BF16X3 || dtype == RS_F16X3; }
-inline bool is_f16_family(int dtype) { return dtype == RS_F16 || dtype == RS_F16X3; }
+inline bool is_x3(int dtype) { return dtype == RS_BF16X3 || dtype == RS_F16X3 || dtype == RS_F16XF8; }
+inline bool is_f16_family(int dtype) { return dtype == RS_F16 || dtype == RS_F16X3 || dtype == RS_F16XF8; }
 inline bool is_16bit(int dtype) { return dtype == RS_BF16 || dtype == RS_F16 || is_x3(dtype); }
 
 constexpr int kMaxLayers = 16;
@@ -136,6 +136,8 @@ struct ConvLayerDev {
     void* d_w;                // packed weights [n_alloc][nch][3][kc] (f32 or bf16)
     void* d_w2 = nullptr;     // 16-bit modes: ring packing [panel][tap][n_alloc][64] (conv_ring_h16.hip)
     int ring_panels = 0;      // panels of the ring packing: 64 channels each (plain) or 32 channels as hi | lo (x3)
+    bool f8_in = false;       // RS_F16XF8: the layer reads / writes F8 rows (conv_ring_f8.hip); cp_in / cp_out are their pitches
+    bool f8_out = false;
     int x3_terms = 7;         // split precision, -DRS_X3_MASK measurement builds only (RS_X3_TERMS): 1 hi*hi | 2 x lo*w hi | 4 x hi*w lo
     float* d_bias;            // [n_alloc] fp32, zero padded
     // f16 / f16x3: the packed 16-bit weights are the layer's weights x 2^k (max |w| 2^k in [8192, 16384): the LOW halves of
@@ -202,6 +204,14 @@ bool conv_wres_h16_ok(const ConvLayerDev& L, bool x3);
 int launch_conv_wres_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
                          int layer_index, int num_cu, bool f16, bool x3, int check_dead, hipStream_t st, int* bm_out,
                          int* bn_out);
+// RS_F16XF8 (conv_ring_f8.hip): split precision with the cross terms on the block-scaled 8-bit MFMA; F8 rows carry a scale plane
+int launch_conv_ring_f8(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
+                        int layer_index, int num_cu, int check_dead, hipStream_t st, int* bm_out, int* bn_out);
+int conv_ring_f8_num_shapes();
+bool conv_ring_f8_shape_ok(const ConvLayerDev& L, int k);
+size_t f8_scale_offset(int64_t rows, int cp);     // byte offset of the scale plane behind `rows` F8 rows of cp 16-bit elements
+int f8_scale_stride(int64_t rows);                // rows per 64-channel panel of the plane (4 bytes each)
+size_t f8_scale_bytes(int64_t rows, int cp);
 int conv_ring_max_bn();
 int conv_ring_num_shapes();
 bool conv_ring_shape_ok(const ConvLayerDev& L, int k);
@@ -221,6 +231,10 @@ int launch_head(const void* d_y, int dtype, int cp, int c, int P_last, int n_lay
 // rows of layer `split - 1`'s output from the fine block layout (Pf rows per block) to the coarse one (Pc rows per block)
 int launch_repack_rows(const void* d_src, void* d_dst, const BlockPlan& fine, const BlockPlan& coarse, int NB_coarse, int Pf,
                        int Pc, size_t row_bytes, hipStream_t st);
+
+// the scale plane of F8 rows (conv_ring_f8.hip: [64-channel panel][stride][4 bytes]) across the same re-pack
+int launch_repack_scales(const void* d_src, void* d_dst, const BlockPlan& fine, const BlockPlan& coarse, int NB_coarse, int Pf,
+                         int Pc, int n_planes, int stride_f, int stride_c, hipStream_t st);
 
 // the `fc` classifier (fc_head.hip): weights on the device, first Linear re-ordered to [P][C4][H]
 struct FcHead {

@@ -269,6 +269,34 @@ int launch_repack_rows(const void* d_src, void* d_dst, const BlockPlan& fine, co
     return RS_OK;
 }
 
+// the scale plane of F8 rows across the same re-pack: one dword per row and 64-channel panel; rows behind the read's end get the
+// scale of an all-zero block (any valid E8M0 byte would do: their data are zeros)
+__global__ __launch_bounds__(256) void repack_scales_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst,
+                                                            const int32_t* __restrict__ rbase_f, const int32_t* __restrict__ rbase_c,
+                                                            const int32_t* __restrict__ bread_c, int nb_f_total, int Pf, int Pc,
+                                                            int stride_f, int stride_c) {
+    const int k = blockIdx.x, p = blockIdx.y;
+    const int b = bread_c[k];
+    const int j = k - rbase_c[b];
+    const int blocks_f = min(rbase_f[b + 1], nb_f_total) - rbase_f[b];
+    const int64_t src0 = (int64_t)p * stride_f + (int64_t)rbase_f[b] * Pf, dst0 = (int64_t)p * stride_c + (int64_t)k * Pc;
+    const int limit = max(blocks_f, 0) * Pf;
+    for (int r = threadIdx.x; r < Pc; r += blockDim.x) {
+        const int t = j * Pc + r;
+        dst[dst0 + r] = t < limit ? src[src0 + t] : 0x5f6a5f6au;
+    }
+}
+
+int launch_repack_scales(const void* d_src, void* d_dst, const BlockPlan& fine, const BlockPlan& coarse, int NB_coarse, int Pf,
+                         int Pc, int n_planes, int stride_f, int stride_c, hipStream_t st) {
+    if (NB_coarse <= 0 || n_planes <= 0) return RS_OK;
+    hipLaunchKernelGGL(repack_scales_kernel, dim3((unsigned)NB_coarse, (unsigned)n_planes), dim3(64), 0, st,
+                       static_cast<const unsigned*>(d_src), static_cast<unsigned*>(d_dst), fine.rbase, coarse.rbase, coarse.bread,
+                       fine.nb_total, Pf, Pc, stride_f, stride_c);
+    RS_HIP(hipGetLastError());
+    return RS_OK;
+}
+
 int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, const BlockPlan& plan, int NB, const float* d_w4,
                  int cp_out, void* d_y, int dtype, hipStream_t st) {
     const int P1 = (1 << plan.shift) / 2;

@@ -17,7 +17,7 @@ from . import _native as nv
 _DTYPES = {"f32": nv.RS_F32, "fp32": nv.RS_F32, "float32": nv.RS_F32,
            "bf16": nv.RS_BF16, "bfloat16": nv.RS_BF16, "f16": nv.RS_F16, "fp16": nv.RS_F16,
            "float16": nv.RS_F16, "f32w": nv.RS_F32W, "f32_winograd": nv.RS_F32W,
-           "bf16x3": nv.RS_BF16X3, "f16x3": nv.RS_F16X3}
+           "bf16x3": nv.RS_BF16X3, "f16x3": nv.RS_F16X3, "f16xf8": nv.RS_F16XF8}
 
 
 def _stream_ptr(device) -> int:
@@ -52,13 +52,15 @@ class Model:
     @staticmethod
     def dtypes():
         """Arithmetic modes this build of the library accepts (canonical names)."""
-        return ("f32w", "f32", "bf16", "f16", "bf16x3", "f16x3")
+        return ("f32w", "f32", "bf16", "f16", "bf16x3", "f16x3", "f16xf8")
 
     def __init__(self, state, config, logger, target, dtype: str = "f32w", device=None):
         """dtype: "f32w" (default; fp32 end to end, conv layers as Winograd F(2,3) / F(4,3) on the
         f32-input MFMA), "f32" (fp32, direct lowering: exact fmaf chains), "bf16x3" / "f16x3" (split
         precision on the 16-bit MFMA: hi + lo pairs, three MFMAs per product, fp32 accumulate - the 16-bit mode
-        that stays within 1e-3 of the reference), "f16" / "bf16" (plain 16-bit activations and weights, fp32
+        that stays within 1e-3 of the reference), "f16xf8" (f16x3 whose wide layers evaluate the two cross terms of the
+        split product as one block-scaled e4m3 product on the 8-bit MFMA: two instruction times per product instead of
+        three, within ~3e-4 of the reference), "f16" / "bf16" (plain 16-bit activations and weights, fp32
         accumulate: fast, approximate)."""
         self.target = target
         self.logger = logger
@@ -294,7 +296,7 @@ class Model:
     # from ~1000 reads of 16000 samples on and falls off once a layer's activations outgrow the 256 MB Infinity Cache
     # (profiles/r04_batch_sweep_*.txt: fp32 4096 reads -4 %, split precision 2048 reads -5 %; two bytes more per element there)
     _CALL_SAMPLES = {"f32w": 2048 << 14, "f32": 2048 << 14, "bf16": 2048 << 14, "f16": 2048 << 14,
-                     "bf16x3": 1024 << 14, "f16x3": 1024 << 14}
+                     "bf16x3": 1024 << 14, "f16x3": 1024 << 14, "f16xf8": 1024 << 14}
 
     def call_batch(self, B: int, lmax: int) -> int:
         """Reads per library call for a batch of B reads of up to lmax samples: B itself, or - beyond the 2 GiB buffer
