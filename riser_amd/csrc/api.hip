@@ -406,9 +406,14 @@ unsigned char to_e4m3(float f) {
     return (unsigned char)(sign | ((ee + 7) << 3) | (m - 8));
 }
 
-// RS_F16XF8: layer i can take part in a run of F8 rows (conv_ring_f8.hip): a tiled layer with at least one whole 64-channel panel
+// RS_F16XF8: layer i can take part in a run of F8 rows (conv_ring_f8.hip).  Wide layers only (RS_F8_MIN_CIN input channels,
+// default 200: layers 7-11 of the shipped net): with 2/3 of the matrix-pipe time a tile of this kernel is bound three ways at
+// once - MFMA, L2 -> LDS staging (~24 B/clk/CU) and LDS fragment reads are each ~1 500 cycles per sub-stage at 256 x 192 - and
+// its even-NT tile shapes cover the narrow layers' columns worse than the split-precision kernel's (measured, 512 x 16000:
+// layers 4, 5 +20 ... +30 %, layer 6 +-0, layers 7 / 8 / 9 / 11 -5 / -11 / -10 / -18 %)
 bool f8_eligible(int dtype, int i, int n_layers, const int32_t* channels) {
-    return dtype == RS_F16XF8 && i >= 3 && i < n_layers && channels[i - 1] >= 64 && !getenv("RS_NO_F8");
+    const int min_cin = getenv("RS_F8_MIN_CIN") ? atoi(getenv("RS_F8_MIN_CIN")) : 200;        // model creation only
+    return dtype == RS_F16XF8 && i >= 3 && i < n_layers && channels[i - 1] >= std::max(64, min_cin);
 }
 
 template <class T>

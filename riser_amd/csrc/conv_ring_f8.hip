@@ -79,6 +79,9 @@ struct F8Args {
 };
 
 __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+#ifdef RS_F8_NO_H                // diagnostic build: no 16-bit MFMAs
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 // unit k of A (32 e4m3 values of one row) against unit k of B, k = 0..3, each scaled by its lane's E8M0 byte
@@ -147,6 +150,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr int kX3 = 0;      // [hi x 32 | lo x 32] f16: hi*hi, lo*hi, hi*lo
 constexpr int kH = 1;       // hi16 x 64: (h0, h0), (h1, h1)
 constexpr int kF = 2;       // 8-bit units: one scaled instruction
+constexpr int kNone = 3;    // (as the previous sub-stage's kind: it left nothing pending)
 
 // scale slab: LDS row R' holds the scales of position m0 - 4 + R' (16-byte aligned source for every lane)
 constexpr int scale_pieces_of(int bm) { return ((bm + 11) * 4 + 1023) / 1024; }
@@ -325,7 +329,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
     int keep8_s[MT / 2];
     auto deferred_pass = [&](auto PREV_) __attribute__((always_inline)) {
         constexpr int PREV = decltype(PREV_)::value;
-        if constexpr (PREV == kF) {
+        if constexpr (PREV == kNone) {
+        } else if constexpr (PREV == kF) {
 #pragma unroll
             for (int i = 0; i < MT / 2; ++i)
 #pragma unroll
@@ -342,7 +347,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
         constexpr int KIND = decltype(KIND_)::value;
         constexpr int tap = decltype(TAP)::value;
         constexpr int NDMA = decltype(NDMA_)::value;
-        constexpr int NM = KIND == kX3 ? 2 * MT * NT : KIND == kH ? MT * NT : (MT / 2) * NT;      // MFMAs executed here
+        // tap 2 of an F panel keeps nothing back: the sub-stage behind it may run a tile's epilogue, which needs the registers
+        constexpr bool F_DEFER = KIND == kF && tap != 2;
+        constexpr int NM = KIND == kX3 ? 2 * MT * NT : KIND == kH ? MT * NT : F_DEFER ? (MT / 2) * NT : MT * NT;      // MFMAs executed here
         constexpr int GAP = NM / (NDMA + 1) > 0 ? NM / (NDMA + 1) : 1;
         const unsigned ax0 = a_rd[tap][0] + (unsigned)(xb * XS), ax1 = a_rd[tap][1] + (unsigned)(xb * XS);
         u32x4 a0[MT], b0[NT], a1[MT], b1[NT];
@@ -378,7 +385,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
         // a small tile has fewer MFMAs here than pieces to issue: the rest behind them (the stage-end wait counts every piece)
         constexpr int ISSUED = NM / GAP < NDMA ? NM / GAP : NDMA;
         static_for<NDMA - ISSUED>([&](auto I_) { dma(std::integral_constant<int, ISSUED + decltype(I_)::value>{}); });
-        if constexpr (KIND == kF) {
+        if constexpr (KIND == kF && !F_DEFER) {
+        } else if constexpr (KIND == kF) {
 #pragma unroll
             for (int i = 0; i < MT / 2; ++i) {
                 keep8_a[i][0] = a0[MT / 2 + i];
@@ -605,9 +613,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
     constexpr auto KX3 = std::integral_constant<int, kX3>{};
     constexpr auto KH = std::integral_constant<int, kH>{};
     constexpr auto KF = std::integral_constant<int, kF>{};
+    constexpr auto KN = std::integral_constant<int, kNone>{};
     while (true) {
         if constexpr (IN_F8) {
-            run_panel(KH, KF);               // n_panels is even: a tile never ends on an H panel
+            run_panel(KH, KN);               // n_panels is even: a tile never ends on an H panel
             run_panel(KF, KH);
         } else {
             run_panel(KX3, KX3);
@@ -615,10 +624,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
         if (!more) break;
     }
     // the walk's last sub-stage: its deferred part and the last tile's epilogue (`xb` has moved on: the slab is done_xb)
-    if constexpr (IN_F8)
-        deferred_pass(KF);
-    else
-        deferred_pass(KX3);
+    if constexpr (!IN_F8) deferred_pass(KX3);
     epilogue(done, done_cb, done_xb);
 }
 

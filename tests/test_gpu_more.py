@@ -743,3 +743,57 @@ def test_control_loop_signal_store_and_scale(dev, tmp_path):
     n_rows = open(str(tmp_path / "big.csv")).read().count("\n") - 1
     assert n_rows > 10000 and len(client.finished) == 2
     m.close()
+
+
+def test_f16xf8_cross_terms_on_the_8bit_mfma(dev, golden_dir):
+    """RS_F16XF8 (csrc/conv_ring_f8.hip): split precision whose wide layers keep hi*hi on the f16 MFMA and evaluate the cross
+    terms hi*lo + lo*hi as ONE block-scaled e4m3 product (v_mfma_scale_f32_16x16x128_f8f6f4; rows between those layers carry
+    an E8M0 scale per row and 32 channels).  By default layers 7-11 of the shipped net; RS_F8_MIN_CIN=64 puts EVERY layer from
+    4 on into that form (the run then crosses the fine -> coarse re-pack, whose scale plane moves with the rows).  Both against
+    the reference's golden probabilities and the oracle within the 1e-3 tolerance, labels identical; and the properties that
+    do not depend on size: a read's bits are those of the read alone, whatever the batch, its order, the layout (host lengths
+    or not, one level or two), and thin launches (one read) agree with the batched row."""
+    import os
+    from conftest import hooked_model
+    from riser_amd.preprocess import pack_reads
+    net = np.load(os.path.join(golden_dir, "network.npz"))
+    for env in ({}, {"RS_F8_MIN_CIN": "64"}):
+        models, worst = {}, 0.0
+        for seed, L, B, first in net["cases"]:
+            tag = f"s{seed}_L{L}_B{B}_r{first}"
+            seed = int(seed)
+            if seed not in models:
+                models[seed] = hooked_model(env, synth.make_state_dict(seed), "f16xf8", dev)
+            sigs = synth.make_signals(int(net["sig_seed"][0]), int(B), int(L), first_read=int(first))
+            sig, off, ln, lh = pack_reads(list(sigs), dev)
+            got = models[seed].classify_raw(sig, off, ln, lh).cpu().numpy()
+            want = net[f"{tag}.probs"]
+            err = float(np.abs(got - want).max())
+            worst = max(worst, err)
+            assert np.isfinite(got).all() and err < 1e-3, (env, tag, err)
+            assert np.array_equal(got[:, 1] > 0.9, want[:, 1] > 0.9), (env, tag)
+        print(f"f16xf8 {env}: worst |dp| {worst:.2e} over the golden cases")
+        assert worst < 5e-4, (env, worst)
+        for m in models.values():
+            m.close()
+    # layout and batch invariance with every wide layer in the 8-bit form: lengths at the block edges of both levels
+    sd = synth.make_state_dict(2)
+    m = hooked_model({"RS_F8_MIN_CIN": "64"}, sd, "f16xf8", dev)
+    one = hooked_model({"RS_F8_MIN_CIN": "64", "RS_ONE_LEVEL": "1"}, sd, "f16xf8", dev)
+    info = m.layer_info()
+    assert info[5]["cp_out"] == 128 * ((info[5]["c_out"] + 63) // 64) and info[11]["cp_out"] == 64 * ((info[11]["c_out"] + 31) // 32)
+    lens = np.array([8615, 4096, 4097, 5119, 5120, 5121, 8191, 8192, 8193, 9215, 9216, 12287, 12288, 16000, 6024, 7168, 10240,
+                     16383, 4607, 20000], dtype=np.int32)
+    sigs = [synth.make_signals(SIG_SEED, 1, int(n), first_read=6100 + i)[0] for i, n in enumerate(lens)]
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    got = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+    want = ro.classify_reads(sd, sigs)
+    assert np.abs(got - want).max() < 1e-3, float(np.abs(got - want).max())
+    assert np.array_equal(got[:, 1] > 0.9, want[:, 1] > 0.9)
+    assert np.array_equal(got, m.classify_raw(sig, off, ln, lh, packed=False).cpu().numpy())
+    assert np.array_equal(got, one.classify_raw(sig, off, ln, lh).cpu().numpy())
+    for idx in ([3], list(range(len(lens)))[::-1], [14, 0, 19, 7]):
+        s2, o2, l2, h2 = pack_reads([sigs[i] for i in idx], dev)
+        assert np.array_equal(m.classify_raw(s2, o2, l2, h2).cpu().numpy(), got[idx]), idx
+    m.close()
+    one.close()

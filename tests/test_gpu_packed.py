@@ -54,7 +54,7 @@ def test_uniform_random_lengths_vs_oracle(dev):
     assert m.block_samples(3) == 1024 and m.block_bases(lh, 3)[-1] == int((lh // 1024 + 1).sum())
 
 
-@pytest.mark.parametrize("dtype", ["f32w", "f32", "f16", "bf16", "bf16x3", "f16x3"])
+@pytest.mark.parametrize("dtype", ["f32w", "f32", "f16", "bf16", "bf16x3", "f16x3", "f16xf8"])
 def test_packed_equals_uniform_pitch_bitwise(dev, dtype):
     """the same batch with and without the host's copy of the lengths (packed blocks vs every read in the slot of the
     longest): identical bits, in every mode, through classify_raw and the unfused rs_forward path"""
@@ -77,7 +77,7 @@ def test_packed_equals_uniform_pitch_bitwise(dev, dtype):
         assert np.array_equal(unf, packed), np.abs(unf - packed).max()
 
 
-@pytest.mark.parametrize("dtype", ["f32w", "f32", "f16", "bf16", "bf16x3", "f16x3"])
+@pytest.mark.parametrize("dtype", ["f32w", "f32", "f16", "bf16", "bf16x3", "f16x3", "f16xf8"])
 def test_two_level_layout_equals_one_level_bitwise(dev, dtype):
     """round 4: conv layers 0-8 run on fine blocks of 1024 samples, layers 9-11 and the head on 4096-sample blocks behind a
     re-pack of layer 8's output (a live 8615-sample read occupies 9216 samples of rows in the early layers instead of
