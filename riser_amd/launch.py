@@ -113,9 +113,15 @@ def launch(args, argv) -> dict:
             raise SystemExit(f"riser_amd.launch: --gpus {n} but only {ndev} ROCm device(s) visible (--share-gpus rehearses "
                              "several ranks on one GPU)")
     log = logging.getLogger("riser_amd.launch")
+    # one clock for the whole launch: every rank - a restarted one too - numbers its minutes from the parent's start and
+    # stops at the parent's deadline (a rank restarted at hour 47 of 48 runs for one hour, not for another 48)
+    t_start = time.time()
+    deadline = t_start + args.duration_h * 3600.0
 
     def spawn(r):
         env = supervise.rank_env(r, n)
+        env["RS_LAUNCH_T0"] = repr(t_start)
+        env["RS_LAUNCH_DEADLINE"] = repr(deadline)
         env["PYTHONPATH"] = _ROOT + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
         return subprocess.Popen([sys.executable, "-m", "riser_amd.launch", *argv], env=env, stdout=subprocess.PIPE,
                                 stderr=subprocess.PIPE, text=True, cwd=os.getcwd())
@@ -163,8 +169,8 @@ def launch(args, argv) -> dict:
                 down.add(rank)
                 failures.append({"rank": rank, "returncode": rc, "channels": [first, last], "time": time.time(),
                                  "stderr_tail": tail[-10:]})
-                log.error(f"rank {rank} (channels {first}-{last}) exited with code {rc}: its channels are not under control. "
-                          "Last stderr lines:\n" + "\n".join("    " + ln for ln in tail[-10:]))
+                log.error(f"rank {rank} (channels {first}-{last}) exited with code {rc}: its channels are not under control "
+                          f"(its stderr: the lines tagged [rank {rank}] above; the last of them are kept in the summary)")
                 for m in list(minutes):                        # minutes that were waiting for this rank only
                     merged_line(m)
             elif kind == "restarted":
@@ -199,16 +205,23 @@ def launch(args, argv) -> dict:
 class _MinuteRelay(logging.Handler):
     """turns the control loop's once-a-minute log line into a JSON line for the parent"""
 
-    def __init__(self, rank):
+    def __init__(self, rank, t0=None):
         super().__init__(level=logging.INFO)
-        self.rank, self.minute = rank, 0
+        self.rank, self.last = rank, -1
+        self.t0 = time.time() if t0 is None else float(t0)           # the LAUNCH's start (RS_LAUNCH_T0), not this process's
+
+    def minute_index(self, now=None):
+        """the launch-wide minute a report made `now` closes: minute k covers [60 k, 60 (k + 1)) s after the launch started;
+        strictly increasing per process"""
+        k = max(0, int(((time.time() if now is None else now) - self.t0) / 60.0 + 0.5) - 1)
+        self.last = max(self.last + 1, k)
+        return self.last
 
     def emit(self, record):
         m = _MINUTE_RE.search(record.getMessage())
         if m:
-            print(json.dumps({"kind": "minute", "rank": self.rank, "minute": self.minute, "assessed": int(m.group(1)),
+            print(json.dumps({"kind": "minute", "rank": self.rank, "minute": self.minute_index(), "assessed": int(m.group(1)),
                               "accepted": int(m.group(2)), "rejected": int(m.group(3))}), flush=True)
-            self.minute += 1
 
 
 def _replay_batches(args):
@@ -254,6 +267,16 @@ class _StubControl:
         self.logger.info(f"In the last minute {n} signals were assessed, 0 were accepted and 0 were rejected")
 
 
+def remaining_duration_h(duration_h, now=None, env=None):
+    """hours this rank still has to run: the launch's deadline (RS_LAUNCH_DEADLINE, set once by the parent) caps --duration-h,
+    so a rank that is started again late in a run does not keep the launch alive for a second full duration"""
+    dl = (os.environ if env is None else env).get("RS_LAUNCH_DEADLINE")
+    if not dl:
+        return duration_h
+    left = (float(dl) - (time.time() if now is None else now)) / 3600.0
+    return max(0.0, min(float(duration_h), left))
+
+
 def _arm_test_failure(args, rank):
     """tests only (--fail-rank): this rank dies with exit code 3, at once or from a timer thread mid-run"""
     if args.fail_rank is None or args.fail_rank != rank:
@@ -277,7 +300,7 @@ def run_rank(args) -> int:
     first, last = rank_channel_range(rank, world, args.channels)
     logger = logging.getLogger(f"riser_amd.rank{rank}")
     logger.setLevel(logging.INFO)
-    logger.addHandler(_MinuteRelay(rank))
+    logger.addHandler(_MinuteRelay(rank, os.environ.get("RS_LAUNCH_T0")))
     out = f"{args.out}.rank{rank}"
     if args.client:
         mod, _, fn = args.client.partition(":")
@@ -315,7 +338,7 @@ def run_rank(args) -> int:
         ctl.reserve(max(512, last - first + 1))
     t0 = time.perf_counter()
     ctl.start()
-    ctl.target(args.mode, args.duration_h, args.threshold, args.unblock_duration)
+    ctl.target(args.mode, remaining_duration_h(args.duration_h), args.threshold, args.unblock_duration)
     ctl.finish()
     wall = time.perf_counter() - t0
     with open(out + ".csv") as f:

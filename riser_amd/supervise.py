@@ -27,9 +27,73 @@ import time
 STDERR_TAIL_LINES = 40
 
 
-def cpu_slices(world: int, cpus=None) -> list:
-    """`world` disjoint, contiguous slices of the cores this process may run on, sizes differing by at most one.  With
-    fewer cores than ranks every rank gets the whole set (a rehearsal box)."""
+def _parse_cpulist(text: str) -> list:
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def read_topology(sys_root: str = "/sys"):
+    """(gpu_nodes, node_cpus) from sysfs, or None when the map is not readable: gpu_nodes[k] = NUMA node of the k-th AMD GPU
+    (DRM cards of vendor 0x1002 in PCI-address order: the order HIP enumerates them in on a default install), node_cpus =
+    {node: [cpu, ...]}.  A node of -1 (no affinity reported) makes the caller fall back."""
+    import glob
+    try:
+        cards = []
+        for dev in glob.glob(os.path.join(sys_root, "class/drm/card[0-9]*/device")):
+            if not os.path.basename(os.path.dirname(dev)).replace("card", "").isdigit():
+                continue
+            with open(os.path.join(dev, "vendor")) as f:
+                if f.read().strip().lower() != "0x1002":
+                    continue
+            with open(os.path.join(dev, "numa_node")) as f:
+                node = int(f.read().strip())
+            cards.append((os.path.basename(os.path.realpath(dev)), node))
+        node_cpus = {}
+        for nd in glob.glob(os.path.join(sys_root, "devices/system/node/node[0-9]*")):
+            with open(os.path.join(nd, "cpulist")) as f:
+                node_cpus[int(os.path.basename(nd)[4:])] = _parse_cpulist(f.read())
+        if not cards or not node_cpus:
+            return None
+        return [n for _, n in sorted(cards)], node_cpus
+    except (OSError, ValueError):
+        return None
+
+
+def numa_cpu_slices(world: int, cpus, gpu_nodes, node_cpus):
+    """slices that keep rank r on the cores of GPU r's NUMA node: the ranks whose GPUs share a node split that node's share of
+    `cpus` between them.  None when the map does not cover every rank (fewer GPUs than ranks, a node of -1, a node without
+    usable cores): the caller falls back to contiguous slices."""
+    if gpu_nodes is None or len(gpu_nodes) < world:
+        return None
+    allowed = set(cpus)
+    by_node = {}
+    for r in range(world):
+        by_node.setdefault(gpu_nodes[r], []).append(r)
+    out = [None] * world
+    for node, ranks in by_node.items():
+        mine = [c for c in node_cpus.get(node, []) if c in allowed]
+        if node < 0 or len(mine) < len(ranks):
+            return None
+        base, extra = divmod(len(mine), len(ranks))
+        at = 0
+        for i, r in enumerate(ranks):
+            k = base + (1 if i < extra else 0)
+            out[r] = mine[at: at + k]
+            at += k
+    return out
+
+
+def cpu_slices(world: int, cpus=None, topology="auto") -> list:
+    """`world` disjoint slices of the cores this process may run on.  When the GPU -> NUMA node map is readable
+    (`read_topology`; `topology` = a (gpu_nodes, node_cpus) pair overrides, None disables) rank r gets cores of GPU r's node;
+    otherwise contiguous slices, sizes differing by at most one.  With fewer cores than ranks every rank gets the whole set
+    (a rehearsal box)."""
+    explicit = cpus is not None
     if cpus is None:
         cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     cpus = list(cpus)
@@ -37,6 +101,12 @@ def cpu_slices(world: int, cpus=None) -> list:
         raise ValueError("world must be >= 1")
     if len(cpus) < world:
         return [list(cpus) for _ in range(world)]
+    if topology == "auto":
+        topology = None if (explicit or os.environ.get("RS_NUMA_SLICES") == "0") else read_topology()
+    if topology:
+        sl = numa_cpu_slices(world, cpus, topology[0], topology[1])
+        if sl:
+            return sl
     base, extra = divmod(len(cpus), world)
     out, at = [], 0
     for r in range(world):
@@ -57,7 +127,10 @@ def rank_env(rank: int, world: int, base_env=None, master_port=None, cpus=None) 
     env["RS_CPU_SLICE"] = ",".join(str(c) for c in sl)
     nthr = max(1, min(len(sl), 32))
     for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
-        env[k] = str(nthr)
+        try:                                                   # an operator's own (smaller) setting stands
+            env[k] = str(max(1, min(nthr, int(env[k])))) if env.get(k) else str(nthr)
+        except ValueError:
+            env[k] = str(nthr)
     env["RS_TORCH_THREADS"] = str(nthr)
     env["RS_HOST_THREADS"] = str(max(1, min(8, len(sl))))          # riser_amd/csrc/hostpack.c: copy threads per gather
     return env
@@ -101,7 +174,7 @@ class _Tail(threading.Thread):
             for line in self.pipe:
                 self.lines.append(line.rstrip("\n"))
                 if not self.quiet:
-                    sys.stderr.write(line)
+                    sys.stderr.write(f"[rank {self.rank}] {line}")
         except ValueError:                                         # pipe closed under us
             pass
 
@@ -122,11 +195,14 @@ class _Pump(threading.Thread):
 class RankFailure(SystemExit):
     """a rank exited non-zero: `.rank`, `.returncode`, `.stderr_tail`; str() is the message the parent prints"""
 
-    def __init__(self, who, rank, returncode, stderr_tail, others):
+    def __init__(self, who, rank, returncode, stderr_tail, others, relayed=False):
         self.rank, self.returncode, self.stderr_tail = rank, returncode, list(stderr_tail)
         tail = "\n".join("    " + ln for ln in self.stderr_tail[-STDERR_TAIL_LINES:])
-        msg = (f"{who}: rank {rank} exited with code {returncode}; the other rank(s) {others} were terminated.\n"
-               f"  last stderr lines of rank {rank}:\n{tail if tail else '    (none)'}")
+        msg = f"{who}: rank {rank} exited with code {returncode}; the other rank(s) {others} were terminated."
+        if relayed:                                            # its stderr went to ours line by line, tagged [rank r]
+            msg += f"\n  (stderr of rank {rank}: the lines tagged [rank {rank}] above)"
+        else:
+            msg += f"\n  last stderr lines of rank {rank}:\n{tail if tail else '    (none)'}"
         super().__init__(msg)
 
 
@@ -198,7 +274,7 @@ def supervise(spawn, world: int, on_stdout_line, who: str, poll_s: float = 0.1, 
                     continue
                 others = [q for q in range(world) if q != r and not done[q]]
                 _stop([procs[q] for q in others], grace_s)
-                raise RankFailure(who, r, rc, tail, others)
+                raise RankFailure(who, r, rc, tail, others, relayed=not quiet_stderr)
             if not all(done):
                 time.sleep(poll_s)
         return [p.returncode for p in procs]

@@ -53,6 +53,11 @@ def test_gpus_8_stub_rehearsal():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["steps"] == 3
     assert abs(out["value"] - 8 * 512 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-3
+    # every rank's own figures (what makes a first real 8-GPU run diagnosable): min / max / argmin of the per-rank rates
+    pr = out["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and 0 <= pr["argmin"] < 8 and pr["min"] <= pr["max"]
+    assert abs(pr["min"] - 512 / (max(pr["ms_per_step"]) * 1e-3)) / pr["min"] < 1e-2
+    assert max(pr["ms_per_step"]) <= out["ms_per_step"] * 1.001          # the headline is the slowest rank's time
 
 
 def test_a_rank_that_dies_before_the_rendezvous_ends_the_run_at_once():

@@ -377,3 +377,48 @@ def test_hostpack_store_slice_against_the_numpy_steps(hp):
     with pytest.raises(ValueError):
         hp.store_slice(reads, ids, row_id, rows, lens, fits.astype(np.uint8), row_have, row_tail, T, np.zeros(4, dtype=np.int16), start,
                        cand_c, stats)
+
+
+def test_numa_aware_core_slices_and_launch_wide_clock(tmp_path):
+    """supervise.cpu_slices prefers the cores of each rank's GPU's NUMA node when sysfs has the map and
+    falls back to contiguous slices when it does not; a restarted rank numbers its minutes from the LAUNCH's start and stops
+    at the launch's deadline; an operator's smaller OMP_NUM_THREADS stands."""
+    from riser_amd import launch, supervise
+    # a fake sysfs: 4 GPUs, cards 1 and 3 on node 1; node 0 = cpus 0-7, node 1 = cpus 8-15; card2 is another vendor's
+    root = tmp_path / "sys"
+    for k, (vendor, node, pci) in enumerate([("0x1002", 0, "0000:05:00.0"), ("0x1002", 1, "0000:85:00.0"), ("0x10de", 0, "0000:06:00.0"),
+                                             ("0x1002", 1, "0000:c5:00.0"), ("0x1002", 0, "0000:45:00.0")]):
+        d = root / "devices" / "pci" / pci
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n")
+        (d / "numa_node").write_text(f"{node}\n")
+        c = root / "class" / "drm" / f"card{k}"
+        c.mkdir(parents=True)
+        (c / "device").symlink_to(d)
+    for n, cl in ((0, "0-7"), (1, "8-11,12-15")):
+        nd = root / "devices" / "system" / "node" / f"node{n}"
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cl + "\n")
+    topo = supervise.read_topology(str(root))
+    assert topo == ([0, 0, 1, 1], {0: list(range(8)), 1: list(range(8, 16))})          # PCI order: 05, 45 (node 0), 85, c5 (node 1)
+    sl = supervise.cpu_slices(4, cpus=range(16), topology=topo)
+    assert sl == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
+    sl = supervise.cpu_slices(3, cpus=[0, 1, 2, 8, 9, 10, 11], topology=topo)           # the affinity mask cuts node 0 to three cores
+    assert sl == [[0, 1], [2], [8, 9, 10, 11]]
+    # not every rank has a GPU in the map / a node without cores / no map: contiguous slices as before
+    assert supervise.cpu_slices(8, cpus=range(16), topology=topo) == [[2 * r, 2 * r + 1] for r in range(8)]
+    assert supervise.cpu_slices(2, cpus=range(4), topology=([0, -1], {0: [0, 1, 2, 3]})) == [[0, 1], [2, 3]]
+    assert supervise.read_topology(str(tmp_path / "nothing")) is None
+    assert supervise.cpu_slices(2, cpus=range(4)) == [[0, 1], [2, 3]]
+    # thread caps: an explicit smaller setting stands, a larger one is cut to the slice
+    env = supervise.rank_env(0, 8, base_env={"OMP_NUM_THREADS": "4", "MKL_NUM_THREADS": "999"}, cpus=range(256))
+    assert env["OMP_NUM_THREADS"] == "4" and env["MKL_NUM_THREADS"] == "32" and env["OPENBLAS_NUM_THREADS"] == "32"
+    # minutes: a rank restarted 47.4 minutes into the launch reports minute 47 first, then 48, 49 (never 0 again)
+    relay = launch._MinuteRelay(3, t0=1000.0)
+    assert [relay.minute_index(now=1000.0 + 60.0 * m + 2.0) for m in (1, 2, 3)] == [0, 1, 2]
+    late = launch._MinuteRelay(3, t0=1000.0)
+    assert [late.minute_index(now=1000.0 + 47.4 * 60 + 60.0 * m) for m in (1, 2, 2.01)] == [47, 48, 49]
+    # duration: the launch's deadline caps a restarted rank's run
+    assert launch.remaining_duration_h(48.0, env={}) == 48.0
+    assert abs(launch.remaining_duration_h(48.0, now=1000.0 + 47 * 3600, env={"RS_LAUNCH_DEADLINE": repr(1000.0 + 48 * 3600)}) - 1.0) < 1e-9
+    assert launch.remaining_duration_h(48.0, now=5e9, env={"RS_LAUNCH_DEADLINE": "1000.0"}) == 0.0
