@@ -300,6 +300,9 @@ typedef struct rs_layer_info {
     int32_t gemm_row_div;       /* conv rows per GEMM row: 1 direct lowering, 2 Winograd F(2,3), 4 Winograd F(4,3) */
     int32_t block_samples;      /* ABI 2.1: block size (samples) of the packed layout this layer runs on - its input rows and
                                    its output rows; the output of the last fine layer is then re-packed to coarse blocks */
+    int32_t rows_format;        /* ABI 2.5: layout of the layer's OUTPUT rows: 0 one value per channel (fp32 / 16-bit), 1 split
+                                   precision (panels [hi x 32 | lo x 32]), 2 F8 rows (RS_F16XF8: per 64 channels hi16 x 64, then
+                                   [hi8 | lo8 | hi8 | lo8] x 32 e4m3 bytes; E8M0 scale plane behind the rows) */
 } rs_layer_info;
 RS_API int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out);
 
@@ -352,6 +355,14 @@ RS_API int rs_seqnet_forward_ragged(rs_seqnet* m, const float* d_x /* fp32 [B, l
  * rs_block_samples - fp32 or 16-bit) into d_dst
  * (at most `bytes`).  d_dst = NULL switches it off.  Used by the layer-wise parity tests.
  */
+/* Half precision has a range: RS_F16 / RS_F16X3 / RS_F16XF8 store activations as IEEE half, and a value beyond 65504 leaves the
+ * conversion as +inf - the forward pass goes on, the probabilities of that read are wrong, and the reference's fp32 path
+ * (riser/model.py:22-28) has no such failure.  Every kernel epilogue of those modes checks its conversions and raises a sticky flag
+ * on the model; the launch entry points still return RS_OK.  rs_model_saturated waits for `stream` and returns 1 if any call
+ * since the last reset overflowed, 0 if none did (always 0 for the fp32 and bf16 modes), a negative rs_status on error; `reset`
+ * != 0 clears the flag behind the read.  (ABI 2.5) */
+RS_API int rs_model_saturated(rs_model* m, int reset, void* stream);
+
 RS_API int rs_debug_capture_layer(rs_model* m, int layer, void* d_dst, size_t bytes);
 
 /*

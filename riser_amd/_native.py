@@ -22,7 +22,7 @@ SYMBOLS = (
     "rs_last_error", "rs_version", "rs_device_count", "rs_model_create", "rs_model_destroy", "rs_model_set_fc_classifier",
     "rs_workspace_bytes", "rs_max_batch", "rs_block_samples", "rs_normalise", "rs_normalise_float", "rs_forward", "rs_padded_length", "rs_classify",
     "rs_classify_ensemble", "rs_ensemble_workspace_bytes", "rs_autotune", "rs_decide", "rs_polya_end", "rs_copy_segments", "rs_model_layer_info", "rs_profile_enable", "rs_profile_read",
-    "rs_debug_capture_layer", "rs_polya_end_resume",
+    "rs_debug_capture_layer", "rs_polya_end_resume", "rs_model_saturated",
     "rs_seqnet_create", "rs_seqnet_destroy", "rs_seqnet_workspace_bytes", "rs_seqnet_forward", "rs_seqnet_set_mode", "rs_seqnet_ragged_ok", "rs_seqnet_forward_ragged",
 )
 
@@ -34,7 +34,7 @@ class SeqOp(C.Structure):
 
 class LayerInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("c_in", "c_out", "cp_in", "cp_out", "k_pad", "n_pad", "bm", "bn", "kc", "gemm_row_div", "block_samples")]
+                ("c_in", "c_out", "cp_in", "cp_out", "k_pad", "n_pad", "bm", "bn", "kc", "gemm_row_div", "block_samples", "rows_format")]
 
 
 class NativeError(RuntimeError):
@@ -117,6 +117,8 @@ def lib():
     L.rs_polya_end_resume.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     L.rs_debug_capture_layer.restype = i32
     L.rs_debug_capture_layer.argtypes = [vp, i32, vp, sz]
+    L.rs_model_saturated.restype = i32
+    L.rs_model_saturated.argtypes = [vp, i32, vp]
     L.rs_profile_enable.restype = i32
     L.rs_profile_enable.argtypes = [vp, i32]
     L.rs_profile_read.restype = i32

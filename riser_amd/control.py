@@ -505,6 +505,7 @@ class SequencerControl:
     def __init__(self, client, models, processor, logger, out_file, signal_cache: bool = True):
         """signal_cache=False uploads every read whole with every batch (no device-resident signals)."""
         self.client, self.models, self.proc, self.logger = client, models, processor, logger
+        self.saturated_batches = 0          # batches in which a half-precision model overflowed (warned about, each)
         self.out_filename = out_file
         # host wall time of the most recent assessed batches (seconds): bounded, a run lasts tens of hours.
         # batch_latencies: get_read_batch() -> reject / finish calls sent (what the pore waits for);
@@ -729,6 +730,13 @@ class SequencerControl:
         caller.synchronize()
         if side is not caller:
             side.synchronize()
+        # half-precision models: an activation beyond 65504 leaves the conversion as +inf and the read's probabilities are
+        # wrong - the reference's fp32 call (riser/model.py:22-28) cannot do that, so the loop says so (csrc: rs_model_saturated)
+        for m in self.models:
+            if getattr(m, "dtype", None) in getattr(m, "HALF_MODES", ()) and m.saturated(reset=True):
+                self.saturated_batches += 1
+                self.logger.warning(f"target {m.target!r} ({m.dtype}): an activation overflowed half precision in this batch of "
+                                    f"{n_total} reads - their probabilities are unreliable; load the model as 'bf16x3' or 'f32w'")
         pn, dn = probs_h.numpy(), dec_h.numpy()
         p_on = np.empty((n_total, n_models), dtype=np.float64)                              # [read][model]
         for _, _, at, n in parts:

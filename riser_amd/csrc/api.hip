@@ -94,6 +94,7 @@ struct rs_model {
     float* d_fcb = nullptr;
     FcHead fc;                            // fc.H > 0: the `fc` classifier replaces the gap_fc head (rs_model_set_fc_classifier)
     float* d_zero = nullptr;              // 256 zero bytes: target of masked-off staging loads
+    unsigned* d_sat = nullptr;            // half-precision modes: sticky word, non-zero once an activation overflowed f16 (rs_model_saturated)
     int num_cu = 256;
     int last_bm[kMaxLayers] = {0};
     int last_bn[kMaxLayers] = {0};
@@ -429,7 +430,7 @@ extern "C" {
 
 const char* rs_last_error(void) { return g_err; }
 
-int rs_version(void) { return (2 << 16) | 4; }
+int rs_version(void) { return (2 << 16) | 5; }
 
 int rs_device_count(void) {
     int n = 0;
@@ -489,6 +490,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             m->cp[i] = 128 * ((channels[i] + 63) / 64);
     }
     int rc = RS_OK;
+    if (is_f16_family(dtype)) rc = upload(&m->d_sat, std::vector<unsigned>(1, 0u));
     {   // layer 0: (w0, w1, w2, bias) per output channel
         std::vector<float> w4((size_t)m->cp[0] * 4, 0.0f);
         for (int c = 0; c < channels[0]; ++c) {
@@ -502,6 +504,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
     for (int i = 1; i < n_layers && rc == RS_OK; ++i) {
         ConvLayerDev& L = m->layers[i];
         L.hooks = &m->hooks;
+        L.d_sat = m->d_sat;
         L.c_in = channels[i - 1];
         L.c_out = channels[i];
         L.cp_in = m->cp[i - 1];
@@ -752,6 +755,7 @@ int rs_model_destroy(rs_model* m) {
     if (m->d_fcw) (void)hipFree(m->d_fcw);
     if (m->d_fcb) (void)hipFree(m->d_fcb);
     if (m->d_zero) (void)hipFree(m->d_zero);
+    if (m->d_sat) (void)hipFree(m->d_sat);
     if (m->fc.d_w1p) (void)hipFree(m->fc.d_w1p);
     if (m->fc.d_b1) (void)hipFree(m->fc.d_b1);
     if (m->fc.d_w2) (void)hipFree(m->fc.d_w2);
@@ -884,7 +888,7 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
     int rc = RS_OK;
     // unfused layer 0: ldx < 0 tells the kernel that read b's samples start at block rbase[b] of d_x
     if (!fuse0 && !fuse0h)
-        rc = launch_conv0(d_x, packed_x ? -1 : ldx, d_len, bt.fine, bt.NBf, m->d_w0, m->cp[0], buf[0], act_dtype(m), st);
+        rc = launch_conv0(d_x, packed_x ? -1 : ldx, d_len, bt.fine, bt.NBf, m->d_w0, m->cp[0], buf[0], act_dtype(m), st, m->d_sat);
     if (rc != RS_OK) return rc;
     prof_mark(m, 1, st);
     int cur = 0;
@@ -1315,6 +1319,22 @@ int rs_copy_segments(const int16_t* d_src, int16_t* d_dst, const int64_t* d_src_
     return launch_copy_segments(d_src, d_dst, d_src_off, d_dst_off, d_len, n, static_cast<hipStream_t>(stream));
 }
 
+int rs_model_saturated(rs_model* m, int reset, void* stream) {
+    if (!m) {
+        set_error("rs_model_saturated: null model");
+        return RS_ERR_ARG;
+    }
+    if (!m->d_sat) return 0;                                  // fp32 / bf16 modes carry fp32's exponent range
+    DeviceGuard guard(m->device);
+    RS_HIP(guard.err);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned v = 0;
+    RS_HIP(hipMemcpyAsync(&v, m->d_sat, sizeof(v), hipMemcpyDeviceToHost, st));
+    if (reset) RS_HIP(hipMemsetAsync(m->d_sat, 0, sizeof(v), st));
+    RS_HIP(hipStreamSynchronize(st));
+    return v ? 1 : 0;
+}
+
 int rs_debug_capture_layer(rs_model* m, int layer, void* d_dst, size_t bytes) {
     if (!m) {
         set_error("rs_debug_capture_layer: null model");
@@ -1368,6 +1388,7 @@ int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out) {
     memset(out, 0, sizeof(*out));
     out->c_out = m->channels[layer];
     out->cp_out = m->cp[layer];
+    out->rows_format = (layer + 1 < m->n_layers && m->layers[layer + 1].f8_in) ? 2 : is_x3(m->dtype) ? 1 : 0;
     if (layer == 0) {
         out->c_in = 1;
         out->cp_in = 1;

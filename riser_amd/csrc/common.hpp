@@ -121,7 +121,18 @@ int launch_normalise_float(const void* d_sig, int elem_bytes, const int64_t* d_o
 // layer 0: x fp32 [B, ldx] -> y [NB * U / 2, cp_out] (fp32 or 16-bit rows, packed block layout), fused bias+ReLU+maxpool
 int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, const BlockPlan& plan, int NB,
                  const float* d_w4 /* [cp_out][4] = w0,w1,w2,bias */, int cp_out,
-                 void* d_y, int dtype, hipStream_t st);
+                 void* d_y, int dtype, hipStream_t st, unsigned* d_sat = nullptr);
+
+#ifdef __HIPCC__
+// The half-precision modes (RS_F16 / RS_F16X3 / RS_F16XF8) store activations as IEEE half: a value beyond 65504 comes out of the
+// conversion as +inf and the forward pass goes on with it.  Every epilogue ORs this into a per-lane word and raises the
+// model's sticky flag (rs_model_saturated) when it is non-zero: bit 15 / 31 is set iff a half of `packed` has exponent field
+// 31 (activations are >= 0 behind the ReLU, so a half's top bit is free: adding 0x0400 carries into it from 0x7c00 on).
+__device__ __forceinline__ unsigned f16_overflow_bits(unsigned packed) { return (packed + 0x04000400u) & 0x80008000u; }
+__device__ __forceinline__ void raise_saturated(unsigned* flag, unsigned bits) {
+    if (bits && flag) atomicOr(flag, 1u);
+}
+#endif
 
 struct ConvPlan {
     int kc;           // input channels per K chunk (fp32: multiple of 4; 16-bit: 32 = one MFMA k-step)
@@ -136,6 +147,7 @@ struct ConvLayerDev {
     void* d_w;                // packed weights [n_alloc][nch][3][kc] (f32 or bf16)
     void* d_w2 = nullptr;     // 16-bit modes: ring packing [panel][tap][n_alloc][64] (conv_ring_h16.hip)
     int ring_panels = 0;      // panels of the ring packing: 64 channels each (plain) or 32 channels as hi | lo (x3)
+    unsigned* d_sat = nullptr; // half-precision modes: the model's sticky "an activation overflowed f16" flag (device word)
     bool f8_in = false;       // RS_F16XF8: the layer reads / writes F8 rows (conv_ring_f8.hip); cp_in / cp_out are their pitches
     bool f8_out = false;
     int x3_terms = 7;         // split precision, -DRS_X3_MASK measurement builds only (RS_X3_TERMS): 1 hi*hi | 2 x lo*w hi | 4 x hi*w lo

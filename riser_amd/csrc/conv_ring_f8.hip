@@ -63,6 +63,7 @@ struct F8Args {
     const unsigned char* xs;     // IN_F8: scale plane [panel64][xs_stride][4]
     unsigned char* ys;           // OUT_F8: scale plane [panel64][ys_stride][4]
     const int32_t* len;
+    unsigned* sat;               // the model's overflow flag (common.hpp: f16_overflow_bits)
     unsigned x_bytes, w_bytes, y_bytes, xs_bytes, ys_bytes;
     int xs_stride, ys_stride;    // rows per plane (multiples of 4)
     int rows_in;
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
         const int c0 = q.n0 + wn * NT * 16;
         const bool odd = r & 1;
         const float us = a.unscale;
+        unsigned sat = 0u;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int orow0 = (q.m0 + (wm * MT + i) * 16) >> 1;      // first of the block's 8 pooled rows
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
                 ca[j] = odd ? got : v0;
                 cb_[j] = odd ? v1 : got;
                 hi[j] = pack2(ca[j], cb_[j]) & keep;
+                sat |= f16_overflow_bits(hi[j]);
                 acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             if constexpr (OUT_F8) {
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
                 }
             }
         }
+        raise_saturated(a.sat, sat);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -743,6 +747,7 @@ int launch_conv_ring_f8(const ConvLayerDev& L, const void* d_x, void* d_y, const
     a.unscale = L.w_unscale;
     a.y = static_cast<unsigned short*>(d_y);
     a.len = d_len;
+    a.sat = L.d_sat;
     const int64_t xb = rows64 * L.cp_in * 2, wb = (int64_t)n_panels * 3 * L.plan.n_alloc * 64 * 2;
     const int64_t yb = rows64 / 2 * L.cp_out * 2;
     if (xb >= 0x80000000LL || wb >= 0x80000000LL || yb >= 0x80000000LL) {

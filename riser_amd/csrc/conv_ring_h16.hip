@@ -82,6 +82,7 @@ struct RingArgs {
     int n_alloc;
     int n_reads;
     int shift_out;
+    unsigned* sat;               // half precision: the model's overflow flag (common.hpp: f16_overflow_bits), else null
     int terms;                   // -DRS_X3_MASK builds: which products of split precision run (1 hi*hi | 2 x lo*w hi | 4 x hi*w lo)
     WalkArgs walk;
     unsigned long long* stamps;  // diagnostic builds only
@@ -452,6 +453,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         const int p0 = pr0 - b0 * a.P_out;
         const int c0 = q.n0 + wn * NT * 16;
         const bool odd = r & 1;
+        unsigned sat = 0u;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int orow0 = (q.m0 + (wm * MT + i) * 16) >> 1;      // first of the block's 8 pooled rows
@@ -473,6 +475,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
                 const float got = swap_pair(odd ? v0 : v1);
                 const float ca = odd ? got : v0, cb_ = odd ? v1 : got;          // channels (r & ~1, r | 1) of row 2g + odd
                 const unsigned hi = pack2<F16>(ca, cb_);
+                if constexpr (F16) sat |= f16_overflow_bits(hi);
                 unsigned char* dst = scr + (2 * g + (odd ? 1 : 0)) * PITCH + j * PW * 16 + (r & ~1) * 2;
                 *reinterpret_cast<unsigned*>(dst) = hi & keep;
                 if constexpr (X3)
@@ -506,6 +509,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
                 }
             }
         }
+        if constexpr (F16) raise_saturated(a.sat, sat);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -755,6 +759,7 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     a.n_reads = B;
     a.shift_out = layer_index + 1;
     a.terms = L.x3_terms;
+    a.sat = f16 ? L.d_sat : nullptr;
     a.stamps = nullptr;
 #ifdef RS_RING_STAMPS
     static unsigned long long* d_stamps = nullptr;

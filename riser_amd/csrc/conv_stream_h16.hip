@@ -76,6 +76,7 @@ struct StreamArgs {
     float unscale;            // 2^-k of the packed weights' power-of-two scale (ConvLayerDev::w_unscale; 1 outside half precision)
     void* y;                  // [rows_in / 2][cp_out] 16-bit
     const int32_t* len;
+    unsigned* sat;            // half precision: the model's overflow flag (common.hpp: f16_overflow_bits), else null
     unsigned x_bytes, xs_bytes, y_bytes;
     int rows_in;              // B * P_in
     int P_in;
@@ -126,6 +127,7 @@ __device__ __forceinline__ unsigned pack2_lo(float a, float b, unsigned hi) {
 
 template <bool FUSE0, int NT, bool F16, bool X3>
 __global__ __launch_bounds__(kWaves * 64, X3 ? 2 : NT == 3 ? 3 : RS_STREAM_WGS) void conv_stream_h16_kernel(const StreamArgs a) {
+    unsigned sat = 0u;                                          // half precision: a conversion overflowed (raised at the end)
     constexpr int ROWB = X3 ? 128 : 64;                         // ring row / input row of one panel
     constexpr int NH = X3 ? 2 : 1;                              // 16-byte halves a lane handles per row: hi (and lo)
     // ring row pitch: 16 bytes more than a row, so that the consumer's ds_read_b128 of every SECOND row (rows 2c + d of
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(kWaves * 64, X3 ? 2 : NT == 3 ? 3 : RS_STREAM_WGS) 
         for (int m = 0; m < 2; ++m) {
             w[0][m][0] = pack2<F16>(o[m][0], o[m][1]);
             w[0][m][1] = pack2<F16>(o[m][2], o[m][3]);
+            if constexpr (F16) sat |= f16_overflow_bits(w[0][m][0]) | f16_overflow_bits(w[0][m][1]);
             if constexpr (X3) {
                 w[1][m][0] = pack2_lo<F16>(o[m][0], o[m][1], w[0][m][0]);
                 w[1][m][1] = pack2_lo<F16>(o[m][2], o[m][3], w[0][m][1]);
@@ -402,6 +405,7 @@ __global__ __launch_bounds__(kWaves * 64, X3 ? 2 : NT == 3 ? 3 : RS_STREAM_WGS) 
             const float p0 = fmaxf(fmaxf(e01[0], o01[0]), 0.0f), p1 = fmaxf(fmaxf(e01[1], o01[1]), 0.0f);
             const float p2 = fmaxf(fmaxf(e23[0], o23[0]), 0.0f), p3 = fmaxf(fmaxf(e23[1], o23[1]), 0.0f);
             hi[j] = (u32x2){pack2<F16>(p0, p1), pack2<F16>(p2, p3)};
+            if constexpr (F16) sat |= f16_overflow_bits(hi[j][0]) | f16_overflow_bits(hi[j][1]);
             if constexpr (X3) lo[j] = (u32x2){pack2_lo<F16>(p0, p1, hi[j][0]), pack2_lo<F16>(p2, p3, hi[j][1])};
             if constexpr (masked) {
                 hi[j] &= (u32x2){keep, keep};
@@ -460,6 +464,7 @@ __global__ __launch_bounds__(kWaves * 64, X3 ? 2 : NT == 3 ? 3 : RS_STREAM_WGS) 
             }
         });
     }
+    if constexpr (F16) raise_saturated(a.sat, sat);
 }
 
 // ======================================================================================================
@@ -489,6 +494,7 @@ struct Stream2Args {
     int n_alloc2;
     void* y;                  // layer 2 output [B * P2 / 2][cp_out] 16-bit
     const int32_t* len;
+    unsigned* sat;            // as StreamArgs::sat
     unsigned xs_bytes, y_bytes;
     int P2;                   // layer-2 input rows per read slot (P0 / 4), a multiple of 32
     int n_reads;
@@ -499,6 +505,7 @@ struct Stream2Args {
 
 template <int NT2, bool F16, bool X3>
 __global__ __launch_bounds__((X3 ? 8 : 4) * 64, X3 ? 1 : 3) void conv_stream012_h16_kernel(const Stream2Args a) {
+    unsigned sat = 0u;
     constexpr int NW = X3 ? 8 : 4;                              // waves per workgroup
     constexpr int NT1 = 2;
     constexpr int ROWB = X3 ? 128 : 64;
@@ -594,6 +601,7 @@ __global__ __launch_bounds__((X3 ? 8 : 4) * 64, X3 ? 1 : 3) void conv_stream012_
         for (int m = 0; m < 2; ++m) {
             w[0][m][0] = pack2<F16>(o[m][0], o[m][1]);
             w[0][m][1] = pack2<F16>(o[m][2], o[m][3]);
+            if constexpr (F16) sat |= f16_overflow_bits(w[0][m][0]) | f16_overflow_bits(w[0][m][1]);
             if constexpr (X3) {
                 w[1][m][0] = pack2_lo<F16>(o[m][0], o[m][1], w[0][m][0]);
                 w[1][m][1] = pack2_lo<F16>(o[m][2], o[m][3], w[0][m][1]);
@@ -681,6 +689,7 @@ __global__ __launch_bounds__((X3 ? 8 : 4) * 64, X3 ? 1 : 3) void conv_stream012_
             const float p0 = fmaxf(fmaxf(e01[0], o01[0]), 0.0f), p1 = fmaxf(fmaxf(e01[1], o01[1]), 0.0f);
             const float p2 = fmaxf(fmaxf(e23[0], o23[0]), 0.0f), p3 = fmaxf(fmaxf(e23[1], o23[1]), 0.0f);
             hi[j] = (u32x2){pack2<F16>(p0, p1), pack2<F16>(p2, p3)};
+            if constexpr (F16) sat |= f16_overflow_bits(hi[j][0]) | f16_overflow_bits(hi[j][1]);
             if constexpr (X3) lo[j] = (u32x2){pack2_lo<F16>(p0, p1, hi[j][0]), pack2_lo<F16>(p2, p3, hi[j][1])};
             if constexpr (masked) {
                 hi[j] &= (u32x2){keep, keep};
@@ -825,6 +834,7 @@ __global__ __launch_bounds__((X3 ? 8 : 4) * 64, X3 ? 1 : 3) void conv_stream012_
             }
         });
     }
+    if constexpr (F16) raise_saturated(a.sat, sat);
 }
 
 using KernelFn = void (*)(const StreamArgs);
@@ -855,6 +865,7 @@ int launch_conv_stream_h16(const ConvLayerDev& L, const void* d_x, void* d_y, co
         return RS_ERR_ARG;
     }
     StreamArgs a;
+    a.sat = f16 ? L.d_sat : nullptr;
     a.x = d_x;
     a.xs = fuse_xs;
     a.w0 = fuse_w0;
@@ -910,6 +921,7 @@ int launch_conv_stream012_h16(const ConvLayerDev& L1, const ConvLayerDev& L2, co
         return RS_ERR_ARG;
     }
     Stream2Args a;
+    a.sat = f16 ? L1.d_sat : nullptr;
     a.xs = d_xs;
     a.w0 = d_w0;
     a.c0 = c0;

@@ -45,6 +45,7 @@ struct WresArgs {
     float unscale;               // as RingArgs::unscale
     unsigned short* y;           // [rows_in / 2][cpx_out]
     const int32_t* len;
+    unsigned* sat;               // half precision: the model's overflow flag (common.hpp: f16_overflow_bits), else null
     unsigned x_bytes, w_bytes, y_bytes;
     int rows_in;
     int P_out;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wres_h16_kernel(const WresAr
         const int b0 = pr0 / a.P_out;
         const int p0 = pr0 - b0 * a.P_out;
         const bool odd = r & 1;
+        unsigned sat = 0u;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int orow0 = (mm0 + (wave * MT + i) * 16) >> 1;
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wres_h16_kernel(const WresAr
                 const float got = swap_pair(odd ? v0 : v1);
                 const float ca = odd ? got : v0, cb_ = odd ? v1 : got;
                 const unsigned hi = pack2<F16>(ca, cb_);
+                if constexpr (F16) sat |= f16_overflow_bits(hi);
                 unsigned char* dst = scr + (2 * g + (odd ? 1 : 0)) * PITCH + j * PW * 16 + (r & ~1) * 2;
                 *reinterpret_cast<unsigned*>(dst) = hi & keep;
                 if constexpr (X3)
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wres_h16_kernel(const WresAr
                                                        ok ? (unsigned)(orow * a.cpx_out + elem) * 2u : kOob, 0, 0);
             }
         }
+        if constexpr (F16) raise_saturated(a.sat, sat);        // (one more vector-memory operation: the counted waits only get stricter)
     };
 
     // ---- the stage loop ----------------------------------------------------------------------------------------------
@@ -400,6 +404,7 @@ int launch_conv_wres_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     a.unscale = L.w_unscale;
     a.y = static_cast<unsigned short*>(d_y);
     a.len = d_len;
+    a.sat = f16 ? L.d_sat : nullptr;
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
     a.y_bytes = (unsigned)yb;

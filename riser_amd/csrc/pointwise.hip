@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
                                                     const int32_t* __restrict__ len, const int32_t* __restrict__ rbase,
                                                     const int32_t* __restrict__ bread, const int32_t* __restrict__ blen,
                                                     int P1, int cq, int cp,
-                                                    const float4* __restrict__ w4, void* __restrict__ yv) {
+                                                    const float4* __restrict__ w4, void* __restrict__ yv, unsigned* sat) {
     constexpr int CH = DT == 0 ? 4 : 8;
     const int ppi = 256 / cq;                                     // positions per iteration
     const int tid = threadIdx.x;
@@ -81,6 +81,12 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
             }
         }
         const int64_t piece = ((int64_t)kb * P1 + pl) * cq + q;   // 16-byte piece index
+        if constexpr (DT == RS_F16 || DT == RS_F16X3) {            // beyond half precision's range: the model's sticky flag
+            float mx = o[0];
+#pragma unroll
+            for (int j = 1; j < CH; ++j) mx = fmaxf(mx, o[j]);
+            if (!(mx <= 65504.0f) && sat) atomicOr(sat, 1u);
+        }
         if constexpr (kX3<DT>) {
             // channels 8q .. 8q+7 of panel q >> 2: the hi piece, and the lo piece 64 bytes behind it
             unsigned short hi[8], lo[8];
@@ -298,7 +304,7 @@ int launch_repack_scales(const void* d_src, void* d_dst, const BlockPlan& fine, 
 }
 
 int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, const BlockPlan& plan, int NB, const float* d_w4,
-                 int cp_out, void* d_y, int dtype, hipStream_t st) {
+                 int cp_out, void* d_y, int dtype, hipStream_t st, unsigned* d_sat) {
     const int P1 = (1 << plan.shift) / 2;
     // 16-byte pieces of 4 (fp32) / 8 (16-bit) channels per output row; split precision: per row cp_out / 2 logical
     // channel slots, each 8-channel group stored as a hi piece and a lo piece
@@ -315,7 +321,7 @@ int launch_conv0(const float* d_x, int64_t ldx, const int32_t* d_len, const Bloc
     auto fn = dtype == RS_F16 ? conv0_kernel<2> : dtype == RS_BF16 ? conv0_kernel<1>
             : dtype == RS_BF16X3 ? conv0_kernel<RS_BF16X3> : dtype == RS_F16X3 ? conv0_kernel<RS_F16X3> : conv0_kernel<0>;
     hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, d_x, ldx, d_len, plan.rbase, plan.bread, plan.blen, P1, cq, cp_out,
-                       reinterpret_cast<const float4*>(d_w4), d_y);
+                       reinterpret_cast<const float4*>(d_w4), d_y, d_sat);
     RS_HIP(hipGetLastError());
     return RS_OK;
 }

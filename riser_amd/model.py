@@ -8,6 +8,7 @@ through the C ABI; torch is used only for device memory and the current stream.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -54,14 +55,21 @@ class Model:
         """Arithmetic modes this build of the library accepts (canonical names)."""
         return ("f32w", "f32", "bf16", "f16", "bf16x3", "f16x3", "f16xf8")
 
-    def __init__(self, state, config, logger, target, dtype: str = "f32w", device=None):
+    HALF_MODES = ("f16", "f16x3", "f16xf8")        # activations stored as IEEE half: a range of 65504
+    HALF_MAX = 65504.0
+
+    def __init__(self, state, config, logger, target, dtype: str = "f32w", device=None, range_check: bool = True):
         """dtype: "f32w" (default; fp32 end to end, conv layers as Winograd F(2,3) / F(4,3) on the
         f32-input MFMA), "f32" (fp32, direct lowering: exact fmaf chains), "bf16x3" / "f16x3" (split
         precision on the 16-bit MFMA: hi + lo pairs, three MFMAs per product, fp32 accumulate - the 16-bit mode
         that stays within 1e-3 of the reference), "f16xf8" (f16x3 whose wide layers evaluate the two cross terms of the
         split product as one block-scaled e4m3 product on the 8-bit MFMA: two instruction times per product instead of
         three, within ~3e-4 of the reference), "f16" / "bf16" (plain 16-bit activations and weights, fp32
-        accumulate: fast, approximate)."""
+        accumulate: fast, approximate).
+        range_check (half-precision modes only): run a small synthetic sample through the new model and REFUSE (ValueError)
+        when an activation comes within a factor of 4 of half precision's 65504 - those modes cannot represent larger
+        activations, the reference's fp32 path can (riser/model.py:22-28).  RS_RANGE_CHECK=0 or range_check=False skip it;
+        at run time `saturated()` (and a warning from `classify`) report an overflow on the real data."""
         self.target = target
         self.logger = logger
         self.device = self._get_device(device)
@@ -166,6 +174,79 @@ class Model:
             nv.check(L.rs_model_set_fc_classifier(h, positions, int(w1.shape[0]), w1.ctypes.data, b1.ctypes.data,
                                                   w2.ctypes.data, b2.ctypes.data), "rs_model_set_fc_classifier")
             self._fc_positions, self._fc_hidden = positions, int(w1.shape[0])
+        if dtype in self.HALF_MODES and range_check and os.environ.get("RS_RANGE_CHECK", "1") != "0":
+            try:
+                self._half_range_check()
+            except Exception:
+                self.close()
+                raise
+
+    # ---- half precision's range ----------------------------------------------------------
+    def half_activation_maxima(self, signals=None) -> list:
+        """largest activation (the hi half) of every conv layer i >= 1 of THIS half-precision model on raw int16 `signals`
+        (default: 16 synthetic reads of riser_amd.synth; MAD-normalised input is confined to ~[-3.5, 3.5] whatever the
+        source), through the library's layer-capture hook.  inf = the layer overflowed."""
+        from . import synth
+        from .preprocess import pack_reads
+        self._need_handle("half_activation_maxima")
+        if signals is None:
+            signals = [synth.make_raw_read(4242, rid, 2048 + 8615 + 37 * rid, polya=bool(rid % 5))[2048:] for rid in range(16)]
+        lens = [len(s) for s in signals]
+        sig, off, ln, lh = pack_reads(list(signals), self.device)
+        info, out, L = self.layer_info(), [], nv.lib()
+        try:
+            for i in range(1, self.n_layers):
+                U, bases = self.block_samples(i), self.block_bases(lens, i)
+                rows, cp, fmt = int(bases[-1]) * (U >> (i + 1)), info[i]["cp_out"], info[i]["rows_format"]
+                cap = torch.zeros(rows * cp, dtype=torch.float16, device=self.device)
+                nv.check(L.rs_debug_capture_layer(self._h, i, cap.data_ptr(), cap.numel() * 2), "rs_debug_capture_layer")
+                self.classify_raw(sig, off, ln, lh)
+                v = cap.view(rows, cp)
+                if fmt == 1:
+                    v = v.view(rows, cp // 64, 2, 32)[:, :, 0, :]            # [hi x 32 | lo x 32]
+                elif fmt == 2:
+                    v = v.view(rows, cp // 128, 2, 64)[:, :, 0, :]           # [hi16 x 64 | e4m3 bytes]
+                v = v.float().abs()
+                out.append(float("inf") if not torch.isfinite(v).all() else float(v.max().item()))
+        finally:
+            L.rs_debug_capture_layer(self._h, -1, None, 0)
+            self.saturated(reset=True)
+        return out
+
+    def _half_range_check(self, margin: float = 4.0):
+        mx = self.half_activation_maxima()
+        worst = max(mx)
+        if not worst * margin < self.HALF_MAX:
+            layer = 1 + mx.index(worst)
+            raise ValueError(
+                f"dtype {self.dtype!r} stores activations as IEEE half (largest value 65504): conv layer {layer} of target "
+                f"{self.target!r} reaches {worst:.4g} on the synthetic sample, less than x{margin:g} inside that range. Use "
+                "'bf16x3' (fp32's exponent range, within 1e-3 of the reference) or 'f32w'; python -m riser_amd.rangecheck "
+                "prints every layer's maximum; range_check=False / RS_RANGE_CHECK=0 load the model anyway")
+
+    def saturated(self, reset: bool = True) -> bool:
+        """True if a half-precision conversion overflowed (an activation beyond 65504) in any call on this model since the
+        flag was last reset; waits for the caller's stream.  Always False for the fp32 / bf16 modes and the generic conv
+        programs (fp32's exponent range)."""
+        if self._h is None or self.dtype not in self.HALF_MODES:
+            return False
+        rc = nv.lib().rs_model_saturated(self._h, 1 if reset else 0, _stream_ptr(self.device))
+        if rc < 0:
+            nv.check(rc, "rs_model_saturated")
+        return rc == 1
+
+    def warn_if_saturated(self, what: str = "a call") -> bool:
+        """`saturated()` turned into a RuntimeWarning (and a logger warning): what classify() does after every call in a
+        half-precision mode, and the control loop once per batch"""
+        if not self.saturated(reset=True):
+            return False
+        msg = (f"riser_amd: {what} on target {self.target!r} overflowed half precision (an activation beyond 65504 in dtype "
+               f"{self.dtype!r}): the probabilities of the affected reads are WRONG. Use dtype 'bf16x3' or 'f32w' for these weights.")
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        if self.logger is not None:
+            self.logger.warning(msg)
+        return True
 
     # ------------------------------------------------------------------------------------
     def _get_device(self, device=None):
@@ -363,7 +444,10 @@ class Model:
         x.copy_(slot["x"][:n].unsqueeze(0), non_blocking=True)
         ln.copy_(slot["len"], non_blocking=True)
         slot["free"].record()
-        return self.forward_batch(x, lens, lens_dev=ln)[0]
+        out = self.forward_batch(x, lens, lens_dev=ln)[0]
+        if self.dtype in self.HALF_MODES:          # the reference's fp32 call cannot overflow: say so when this one did
+            self.warn_if_saturated("classify()")
+        return out
 
     def _classify_slot(self, n: int):
         """pinned staging for classify(): four slots used in turn, each with an event that says its last copies are done"""

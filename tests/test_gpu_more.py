@@ -464,15 +464,90 @@ def test_split_precision_and_the_range_of_the_numbers(dev):
         sd["layers.5.0.bias"] = base["layers.5.0.bias"] * np.float32(scale)
         sd["layers.6.0.weight"] = base["layers.6.0.weight"] / np.float32(scale)
         for dt in ("f32w", "bf16x3", "f16x3"):
-            m = Model(sd, synth.Config(), None, "m", dtype=dt, device=dev)
+            m = Model(sd, synth.Config(), None, "m", dtype=dt, device=dev, range_check=False)
             p = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+            over = m.saturated()
             m.close()
             if ref is None:
                 ref = p
             assert np.isfinite(p).all(), (dt, scale)
+            assert over == (dt == "f16x3" and scale == 1e5), (dt, scale, over)        # the sticky flag of rs_model_saturated
             if dt != "f16x3" or scale <= 1e3:
                 assert np.abs(p - ref).max() < (1e-4 if dt == "f16x3" else 1e-3), (dt, scale, float(np.abs(p - ref).max()))
                 assert np.array_equal(p[:, 1] > 0.9, ref[:, 1] > 0.9), (dt, scale)
+
+
+@pytest.mark.parametrize("dtype", ["f16x3", "f16xf8", "f16"])
+def test_half_precision_overflow_fails_loudly(dev, dtype):
+    """VERDICT round 5, item 2.  The half-precision modes cannot represent an activation beyond 65504; the reference's fp32 call
+    (riser/model.py:22-28) can.  (a) Model() runs a synthetic sample through a new half-precision model and REFUSES weights whose
+    activations come within x4 of that limit, naming the layer and the modes that do work; (b) loaded anyway (range_check=False),
+    every epilogue checks its conversions: the launch still returns, `saturated()` is True (sticky, cleared by the read),
+    `classify()` raises a RuntimeWarning and the control loop logs one per batch; (c) on the calibrated weights nothing fires;
+    bf16x3 / fp32 never report (fp32's exponent range).  The scaled network is the SAME function (ReLU nets are positively
+    homogeneous: layer 7 x s, layer 8 / s), so its fp32 result is the reference."""
+    import logging
+    import warnings
+    from riser_amd import Kit, SequencerControl, SignalProcessor
+    from riser_amd.model import Model
+    from riser_amd.preprocess import pack_reads
+    from riser_amd.replay import scripted_batches
+    sigs = list(synth.make_signals(SIG_SEED, 24, 8000, first_read=900))
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    base = synth.make_state_dict(1)
+    ok = Model(base, synth.Config(), None, "m", dtype=dtype, device=dev)            # (c): passes the range check
+    want = ok.classify_raw(sig, off, ln, lh).cpu().numpy()
+    assert not ok.saturated()
+    mx = ok.half_activation_maxima()
+    assert len(mx) == 11 and all(0 < v < 65504 / 4 for v in mx)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ok.classify(ro.mad_normalise(sigs[0]))                                        # no warning on sane weights
+    ok.close()
+    layer = 7                                                                          # a layer of the 8-bit run in f16xf8
+    s = np.float32(2.0 ** 14)
+    sd = dict(base)
+    sd[f"layers.{layer}.0.weight"] = base[f"layers.{layer}.0.weight"] * s
+    sd[f"layers.{layer}.0.bias"] = base[f"layers.{layer}.0.bias"] * s
+    sd[f"layers.{layer + 1}.0.weight"] = base[f"layers.{layer + 1}.0.weight"] / s
+    with pytest.raises(ValueError, match=f"conv layer {layer} .* 'bf16x3'"):           # (a)
+        Model(sd, synth.Config(), None, "big", dtype=dtype, device=dev)
+    m = Model(sd, synth.Config(), None, "big", dtype=dtype, device=dev, range_check=False)          # (b)
+    assert not m.saturated()
+    p = m.classify_raw(sig, off, ln, lh).cpu().numpy()
+    assert p.shape == want.shape                                                      # the call itself returns
+    assert m.saturated() and not m.saturated()                                        # sticky until read, then cleared
+    with pytest.warns(RuntimeWarning, match="overflowed half precision"):
+        m.classify(ro.mad_normalise(sigs[1]))
+    assert not m.saturated()
+    # the control loop: one warning per batch in the log, the batch still goes through
+    records = []
+
+    class Grab(logging.Handler):
+        def emit(self, rec):
+            records.append(rec.getMessage())
+    log = logging.getLogger(f"sat_{dtype}")
+    log.addHandler(Grab())
+    log.setLevel(logging.INFO)
+    proc = SignalProcessor(Kit.create_from_version("RNA004"), device=dev)
+    from riser_amd.fake_client import FakeClient
+    client = FakeClient(scripted_batches(3, 64))
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        ctl = SequencerControl(client, [m], proc, log, os.path.join(d, "out"))
+        ctl.start()
+        ctl.target("enrich", 0.01, 0.9)
+        ctl.finish()
+    assert ctl.saturated_batches >= 1 and any("overflowed half precision" in r for r in records)
+    m.close()
+    f32 = Model(base, synth.Config(), None, "m", dtype="f32w", device=dev)            # fp32 on the unscaled weights
+    ref = f32.classify_raw(sig, off, ln, lh).cpu().numpy()
+    f32.close()
+    for dt in ("bf16x3", "f32w"):                                                      # fp32's exponent range: never reported, right result
+        r = Model(sd, synth.Config(), None, "big", dtype=dt, device=dev)
+        pr = r.classify_raw(sig, off, ln, lh).cpu().numpy()
+        assert not r.saturated() and np.abs(pr - ref).max() < 1e-3
+        r.close()
 
 
 def test_activation_range_check(dev):
