@@ -345,6 +345,11 @@ RS_API int rs_seqnet_set_mode(rs_seqnet* m, int dtype /* rs_dtype */);
  * it alone, bit for bit.  Only for programs whose ops all run inside fused launches (stem + residual blocks: what
  * riser/nets/resnet.py builds): rs_seqnet_ragged_ok(m) == 1; otherwise RS_ERR_ARG (group the reads by length instead).
  */
+/* Preconditions of rs_seqnet_forward_ragged: d_len[b] in [0, ld] (a larger value is read as ld); a read shorter than the network
+ * needs (no output row left behind some op) gets NaN probabilities - a defined result, no out-of-range access; a batch whose
+ * buffers outgrow the kernels' 2 GiB windows returns RS_ERR_ARG ("split the batch") before anything wrong is written:
+ * rs_seqnet_max_batch(m, ld) is the largest B that cannot. */
+RS_API int rs_seqnet_max_batch(const rs_seqnet* m, int L);
 RS_API int rs_seqnet_ragged_ok(const rs_seqnet* m);
 RS_API int rs_seqnet_forward_ragged(rs_seqnet* m, const float* d_x /* fp32 [B, ld] */, const int32_t* d_len, int B, int ld, void* d_ws,
                              size_t ws_bytes, float* d_probs, float* d_logits, void* stream);

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RISER_AMD_LIB") or os.path.join(_HERE, "lib", "libriser_amd.so")
 
 RS_OK = 0
+RS_ERR_ARG, RS_ERR_HIP, RS_ERR_LENGTH, RS_ERR_OOM, RS_ERR_WORKSPACE = -1, -2, -3, -4, -5
 RS_F32, RS_BF16, RS_F16, RS_F32W, RS_BF16X3, RS_F16X3, RS_F16XF8 = 0, 1, 2, 3, 4, 5, 6
 RS_TRY_AGAIN, RS_ACCEPT, RS_REJECT, RS_NO_DECISION = 0, 1, 2, 3
 RS_ENRICH, RS_DEPLETE = 0, 1
@@ -23,7 +24,7 @@ SYMBOLS = (
     "rs_workspace_bytes", "rs_max_batch", "rs_block_samples", "rs_normalise", "rs_normalise_float", "rs_forward", "rs_padded_length", "rs_classify",
     "rs_classify_ensemble", "rs_ensemble_workspace_bytes", "rs_autotune", "rs_decide", "rs_polya_end", "rs_copy_segments", "rs_model_layer_info", "rs_profile_enable", "rs_profile_read",
     "rs_debug_capture_layer", "rs_polya_end_resume", "rs_model_saturated",
-    "rs_seqnet_create", "rs_seqnet_destroy", "rs_seqnet_workspace_bytes", "rs_seqnet_forward", "rs_seqnet_set_mode", "rs_seqnet_ragged_ok", "rs_seqnet_forward_ragged",
+    "rs_seqnet_create", "rs_seqnet_destroy", "rs_seqnet_workspace_bytes", "rs_seqnet_forward", "rs_seqnet_set_mode", "rs_seqnet_ragged_ok", "rs_seqnet_forward_ragged", "rs_seqnet_max_batch",
 )
 
 
@@ -111,6 +112,8 @@ def lib():
     L.rs_seqnet_set_mode.argtypes = [vp, i32]
     L.rs_seqnet_ragged_ok.restype = i32
     L.rs_seqnet_ragged_ok.argtypes = [vp]
+    L.rs_seqnet_max_batch.restype = i32
+    L.rs_seqnet_max_batch.argtypes = [vp, i32]
     L.rs_seqnet_forward_ragged.restype = i32
     L.rs_seqnet_forward_ragged.argtypes = [vp, vp, vp, i32, i32, vp, sz, vp, vp, vp]
     L.rs_polya_end_resume.restype = i32

@@ -1583,11 +1583,11 @@ struct LenRecipe {
     signed char kind[64], pad[64];
     short k[64], stride[64], prod[64];        // prod: the op that wrote this op's input buffer, -1 = the program's input
 };
-__global__ __launch_bounds__(256) void seq_lengths_kernel(const int32_t* __restrict__ len, int B, const LenRecipe rc,
+__global__ __launch_bounds__(256) void seq_lengths_kernel(const int32_t* __restrict__ len, int B, int ld, const LenRecipe rc,
                                                           int32_t* __restrict__ table) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    table[b] = len[b];
+    table[b] = min(max(len[b], 0), ld);                      // a length beyond the row pitch would read the next read's row
     for (int i = 0; i < rc.n_ops; ++i) {
         const int t = table[(size_t)(rc.prod[i] + 1) * B + b];
         int o;
@@ -1636,6 +1636,8 @@ struct OpDev {
 using namespace rs;
 
 struct rs_seqnet {
+    int64_t window = 0x7fffffffLL; // bytes a kernel addresses through one 32-bit-offset buffer window (RS_SEQ_WINDOW_BYTES at create:
+                                   // tests force the size guards of the fused launches with a small one)
     bool fuse = true;              // RS_SEQ_NOFUSE=1 (read at create): one launch per op, as the program is written
     int mode = 0;                  // rs_seqnet_set_mode: 0 fp32 (f32-input MFMA), 1 split precision on the bf16 MFMA
     bool bneck_x3 = false;         // RS_SEQ_BNECK_X3=1 (read at create): bottleneck blocks in split precision too.  Off: measured
@@ -2005,6 +2007,7 @@ int rs_seqnet_create(const rs_seq_op* ops, int n_ops, int n_buffers, const float
     m->n_buffers = n_buffers;
     m->c_last = c_last;
     m->scalar_conv = getenv("RS_SEQ_SCALAR") != nullptr;
+    if (const char* e = getenv("RS_SEQ_WINDOW_BYTES"); e && atoll(e) > 0) m->window = std::min<int64_t>(atoll(e), 0x7fffffffLL);
     m->fuse = getenv("RS_SEQ_NOFUSE") == nullptr && !m->scalar_conv;
     m->bneck_x3 = getenv("RS_SEQ_BNECK_X3") != nullptr;
     std::vector<const float*> hw, hb;
@@ -2144,6 +2147,14 @@ size_t rs_seqnet_workspace_bytes(const rs_seqnet* m, int B, int L) {
 static int seqnet_forward_impl(rs_seqnet* m, const float* d_x, const int32_t* d_len, int B, int L, void* d_ws, size_t ws_bytes,
                                float* d_probs, float* d_logits, void* stream);
 
+int rs_seqnet_max_batch(const rs_seqnet* m, int L) {
+    // every activation buffer of B reads stays inside one buffer window: B x (the largest buffer of one read) bytes
+    if (!m || L < 1) return 0;
+    const size_t per = buffer_bytes(m, 1, L);
+    if (!per) return 0;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(1 << 30, (m->window - 4096) / (int64_t)per));
+}
+
 int rs_seqnet_forward(rs_seqnet* m, const float* d_x, int B, int L, void* d_ws, size_t ws_bytes, float* d_probs,
                       float* d_logits, void* stream) {
     return seqnet_forward_impl(m, d_x, nullptr, B, L, d_ws, ws_bytes, d_probs, d_logits, stream);
@@ -2216,7 +2227,7 @@ static int seqnet_forward_impl(rs_seqnet* m, const float* d_x, const int32_t* d_
             rc.stride[k] = (short)(o.stride > 0 ? o.stride : 1);
             rc.prod[k] = (short)prod[k];
         }
-        hipLaunchKernelGGL(seq_lengths_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_len, B, rc, table);
+        hipLaunchKernelGGL(seq_lengths_kernel, dim3((B + 255) / 256), dim3(256), 0, st, d_len, B, L, rc, table);
         RS_HIP(hipGetLastError());
     }
     auto rows_after = [&](int op) -> const int32_t* { return table ? table + (size_t)(op + 1) * B : nullptr; };   // op = -1: the input
@@ -2224,7 +2235,7 @@ static int seqnet_forward_impl(rs_seqnet* m, const float* d_x, const int32_t* d_
     for (size_t k = 0; k < m->ops.size(); ++k) {
         const OpDev& o = m->ops[k];
         const OpShape& sh = shp[k];
-        if (o.fuse == 1 && (int64_t)B * 2 * shp[k + 1].t_out < 0x7fffffffLL && (int64_t)B * sh.t_in * 4 < 0x7fffffffLL) {
+        if (o.fuse == 1 && (int64_t)B * 2 * shp[k + 1].t_out < m->window && (int64_t)B * sh.t_in * 4 < m->window) {
             // stem conv + ReLU + MaxPool(2, 2, pad 1) in one launch: GEMM rows = 2 * pooled rows
             const OpShape& ps = shp[k + 1];
             const int rows = B * 2 * ps.t_out;
@@ -2261,11 +2272,11 @@ static int seqnet_forward_impl(rs_seqnet* m, const float* d_x, const int32_t* d_
             k += o.fuse_skip;
             continue;
         }
-        if (o.fuse == 2 && (int64_t)B * shp[k + o.fuse_skip].t_in * o.f_cout * 4 < 0x7fffffffLL) {
+        if (o.fuse == 2 && (int64_t)B * shp[k + o.fuse_skip].t_in * o.f_cout * 4 < m->window) {
             // residual basic block in one launch (shapes of its first 3x3 conv: ops[k + fuse_skip - 1])
             const OpShape& s1 = shp[k + o.fuse_skip - 1];
             const int64_t xb = (int64_t)B * s1.t_in * o.f_cin * 4;
-            if (xb < 0x7fffffffLL && m->mode == 1 && o.d_x_w1) {
+            if (xb < m->window && m->mode == 1 && o.d_x_w1) {
                 // the block in split precision on the bf16 MFMA: same tiling rules, its own LDS footprint
                 BlockX3Args a;
                 a.x = buf(o.f_src);
@@ -2324,7 +2335,7 @@ static int seqnet_forward_impl(rs_seqnet* m, const float* d_x, const int32_t* d_
                 k += o.fuse_skip;
                 continue;
             }
-            if (xb < 0x7fffffffLL) {
+            if (xb < m->window) {
                 BlockArgs a;
                 a.x = buf(o.f_src);
                 a.x_bytes = (unsigned)xb;
@@ -2392,7 +2403,7 @@ static int seqnet_forward_impl(rs_seqnet* m, const float* d_x, const int32_t* d_
             const OpShape& s1 = shp[k + o.fuse_skip - 2];
             const OpShape& s2 = shp[k + o.fuse_skip - 1];
             const int64_t xb = (int64_t)B * s1.t_in * o.f_cin * 4;
-            if (xb < 0x7fffffffLL && (int64_t)B * s2.t_out * o.f_cout * 4 < 0x7fffffffLL && m->mode == 1 && m->bneck_x3 && o.d_x_w1) {
+            if (xb < m->window && (int64_t)B * s2.t_out * o.f_cout * 4 < m->window && m->mode == 1 && m->bneck_x3 && o.d_x_w1) {
                 BneckX3Args a;
                 a.x = buf(o.f_src);
                 a.x_bytes = (unsigned)xb;
@@ -2434,7 +2445,7 @@ static int seqnet_forward_impl(rs_seqnet* m, const float* d_x, const int32_t* d_
                 k += o.fuse_skip;
                 continue;
             }
-            if (xb < 0x7fffffffLL && (int64_t)B * s2.t_out * o.f_cout * 4 < 0x7fffffffLL) {
+            if (xb < m->window && (int64_t)B * s2.t_out * o.f_cout * 4 < m->window) {
                 BneckArgs a;
                 a.x = buf(o.f_src);
                 a.x_bytes = (unsigned)xb;
@@ -2475,13 +2486,21 @@ static int seqnet_forward_impl(rs_seqnet* m, const float* d_x, const int32_t* d_
                 continue;
             }
         }
+        if (d_len) {
+            // a ragged batch runs in fused launches only (they mask by every read's own rows; the unfused kernels below treat
+            // every read as `ld` samples long): a fused launch that does not fit its 2 GiB buffer windows is an error, not a
+            // silent fall-through to wrong probabilities
+            set_error("rs_seqnet_forward_ragged: op %zu of the program cannot run as a fused launch on %d reads of pitch %d (a buffer "
+                      "beyond the 2 GiB window): split the batch", k, B, L);
+            return RS_ERR_ARG;
+        }
         if (o.kind == 0 && m->scalar_conv) {
             const int cq = (o.c_out + 3) / 4;
             const int64_t total = (int64_t)B * sh.t_out * cq;
             hipLaunchKernelGGL(seq_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, buf(o.src),
                                o.d_w, o.d_b, o.add >= 0 ? buf(o.add) : nullptr, buf(o.dst), B, sh.t_in, sh.t_out,
                                o.c_in, o.c_out, cq, o.k, o.stride, o.pad, o.relu);
-        } else if (o.kind == 0 && o.d_wq && (int64_t)B * sh.t_in * o.c_in * 4 < 0x7fffffffLL) {
+        } else if (o.kind == 0 && o.d_wq && (int64_t)B * sh.t_in * o.c_in * 4 < m->window) {
             const int64_t rows = (int64_t)B * sh.t_out;
             const int n_tiles = (int)((rows + 127) / 128);
             const int K = o.k * o.c_in, K16 = (K + 15) & ~15;

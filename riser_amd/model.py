@@ -370,7 +370,7 @@ class Model:
         address every activation buffer through a 2 GiB buffer-resource window (32-bit offsets with
         hardware bounds checking).  Bigger batches are split transparently by the methods below."""
         if self._seq is not None:
-            return 1 << 30
+            return self._seq.max_batch(int(lmax))
         return max(1, nv.lib().rs_max_batch(self._h, int(lmax)))
 
     # samples (reads x padded length) per library call beyond which a batch is cut into equal sub-batches: throughput is flat

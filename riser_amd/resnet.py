@@ -198,6 +198,11 @@ class SeqNet:
                                        torch.cuda.current_stream(self.device).cuda_stream), "rs_seqnet_forward")
         return (probs, logits) if return_logits else probs
 
+    def max_batch(self, L: int) -> int:
+        """largest batch of reads of (pitch) L samples one call can address: every activation buffer stays inside the kernels'
+        2 GiB buffer window (rs_seqnet_max_batch); bigger batches are split by the callers below and in riser_amd.Model"""
+        return max(1, int(nv.lib().rs_seqnet_max_batch(self._h, int(L))))
+
     @property
     def ragged_ok(self) -> bool:
         """True when forward_ragged can run this program (all of its ops inside fused launches: a ResNet's stem and blocks)"""
@@ -208,6 +213,18 @@ class SeqNet:
         read's result is that of forward() on it alone."""
         B, ld = x.shape
         lib = nv.lib()
+        mb = self.max_batch(ld)
+        if B > mb:                                  # reads are independent: equal parts, each inside the buffer window
+            probs = out if out is not None else torch.empty((B, 2), dtype=torch.float32, device=self.device)
+            logits = torch.empty((B, 2), dtype=torch.float32, device=self.device) if return_logits else None
+            parts = -(-B // mb)
+            step = -(-B // parts)
+            for s0 in range(0, B, step):
+                s1 = min(B, s0 + step)
+                r = self.forward_ragged(x[s0:s1], lens_dev[s0:s1], return_logits, out=probs[s0:s1])
+                if return_logits:
+                    logits[s0:s1] = r[1]
+            return (probs, logits) if return_logits else probs
         need = lib.rs_seqnet_workspace_bytes(self._h, B, ld)
         if need == 0:
             raise ValueError(f"a row pitch of {ld} samples is too short for this network")

@@ -316,3 +316,57 @@ def test_resnet_ragged_batch_equals_every_read_alone(block, dtype):
     l2 = net.forward_ragged(x2, torch.tensor([lens[i] for i in order], dtype=torch.int32, device=dev), return_logits=True)[1].cpu().numpy()
     assert np.array_equal(l2, logits[order])
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", ["basic", "bottleneck"])
+def test_resnet_ragged_batch_beyond_the_buffer_window_is_split_not_wrong(block):
+    """a ragged forward whose fused launches do not fit their 2 GiB buffer windows used to fall through to the
+    unfused kernels - which treat every read as `ld` samples long - and returned wrong probabilities with RS_OK.  With the
+    window forced small (RS_SEQ_WINDOW_BYTES at create): the library refuses the call (RS_ERR_ARG, "split the batch"),
+    rs_seqnet_max_batch says what fits, and SeqNet.forward_ragged / Model split the batch - every read still gets the bits of
+    a call on it alone.  Lengths outside [0, ld] are clamped, a read below the network's minimum is NaN, nothing is read out
+    of range."""
+    import torch
+    from riser_amd import _native as nv
+    from riser_amd.resnet import ResNetModel
+    dev = torch.device("cuda", 0)
+    cfg = dict(synth.RESNET_BENCH_CFG) if block == "basic" else BOTTLENECK_WIDE_CFG
+    sd = synth.make_resnet_state_dict(7, cfg)
+    config = types.SimpleNamespace(resnet=types.SimpleNamespace(**cfg))
+    ref = ResNetModel(sd, config, None, "x", device=dev)
+    per_read = (0x7fffffff - 4096) // ref._net.max_batch(9000)      # bytes of one 9000-sample read's largest buffer (about)
+    os.environ["RS_SEQ_WINDOW_BYTES"] = str(5 * per_read + 8192)   # a window of five such reads
+    try:
+        small = ResNetModel(sd, config, None, "x", device=dev)
+    finally:
+        os.environ.pop("RS_SEQ_WINDOW_BYTES", None)
+    lens = [4096, 9000, 8615, 300, 6024, 7999, 5000, 4097, 8999, 8000, 4444, 9000, 6000, 7000, 8000, 5555]
+    ld = 9000
+    base = _inputs(ld)
+    x = np.full((len(lens), ld), np.nan, dtype=np.float32)
+    for i, n in enumerate(lens):
+        x[i, :n] = base[i % 3][:n]
+    xd = torch.from_numpy(x).to(dev)
+    ln = torch.tensor(lens, dtype=torch.int32, device=dev)
+    want = ref._net.forward_ragged(xd, ln, return_logits=True)[1].cpu().numpy()
+    mb = small._net.max_batch(ld)
+    assert 1 <= mb < len(lens) and ref._net.max_batch(ld) > 1000
+    # the raw entry point refuses the whole batch instead of answering wrongly ...
+    net = small._net
+    need = nv.lib().rs_seqnet_workspace_bytes(net._h, len(lens), ld)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    probs = torch.empty((len(lens), 2), dtype=torch.float32, device=dev)
+    rc = nv.lib().rs_seqnet_forward_ragged(net._h, xd.data_ptr(), ln.data_ptr(), len(lens), ld, ws.data_ptr(), ws.numel(),
+                                           probs.data_ptr(), None, None)
+    assert rc == nv.RS_ERR_ARG and "split the batch" in nv.lib().rs_last_error().decode()
+    # ... and the wrappers split it: same bits as the unrestricted model
+    got = net.forward_ragged(xd, ln, return_logits=True)[1].cpu().numpy()
+    assert np.array_equal(got, want)
+    # lengths beyond the pitch are clamped to it, a read below the program's minimum is NaN (defined, nothing out of range)
+    odd = torch.tensor([ld + 5000, 3, -7, 9000], dtype=torch.int32, device=dev)
+    xo = torch.from_numpy(np.ascontiguousarray(np.stack([base[0], base[1], base[2], base[0]])[:, :ld])).to(dev)
+    lo = ref._net.forward_ragged(xo, odd, return_logits=True)[1].cpu().numpy()
+    assert np.array_equal(lo[0], lo[3]) and np.isnan(lo[1]).all() and np.isnan(lo[2]).all()
+    ref.close()
+    small.close()
