@@ -426,12 +426,16 @@ def host_fed_object(args, device, model, wl, lib_dtype, headline):
             continue
         m = model if ldt == lib_dtype else Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=ldt, device=device)
         sc = StreamClassifier([m], sub_batch=B, max_len=L)
-        sc.classify(pinned[: 4 * B])                                   # workspaces of the two streams, clocks
-        torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        probs = sc.classify(pinned)
-        dtw = time.perf_counter() - t1
-        e = {"value": round(n_batch * B / dtw, 1), "ms_per_batch": round(dtw / n_batch * 1e3, 4)}
+        sc.classify(pinned)                                            # one untimed pass: a pinned page's FIRST upload is slow (8.9 ms per
+        torch.cuda.synchronize(device)                                 # 16 MB batch on a fresh allocation), the per-stream workspaces
+        times = []
+        for _ in range(3):                                             # median of three passes over the whole population
+            t1 = time.perf_counter()
+            probs = sc.classify(pinned)
+            times.append(time.perf_counter() - t1)
+        dtw = float(np.median(times))
+        e = {"value": round(n_batch * B / dtw, 1), "ms_per_batch": round(dtw / n_batch * 1e3, 4),
+             "passes_ms_per_batch": [round(t / n_batch * 1e3, 4) for t in times]}
         if ldt == lib_dtype:
             e["ratio_to_resident"] = round(e["value"] / headline, 4)
             e["bits_equal_resident"] = bool(np.array_equal(probs[0, :B], wl.probs.cpu().numpy()))
