@@ -651,6 +651,7 @@ constexpr size_t lds_bytes_of(int bm, int bn, bool in_f8) {
 const Shape kShapes[] = {
     RS_SHAPE(8, 1, 2, 2), RS_SHAPE(8, 1, 2, 4), RS_SHAPE(8, 1, 2, 6), RS_SHAPE(4, 2, 4, 4), RS_SHAPE(4, 2, 4, 6),
     RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(2, 4, 4, 4), RS_SHAPE(2, 4, 2, 4),
+    RS_SHAPE(4, 2, 2, 2), RS_SHAPE(2, 4, 2, 2),            // thin launches: 128 x 64, 64 x 128 (conv_ring_h16.hip's reason)
 };
 #undef RS_SHAPE
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);

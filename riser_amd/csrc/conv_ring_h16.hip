@@ -409,6 +409,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
             }
             if constexpr (NDMA > 0 && n % GAP == GAP - 1 && n / GAP < NDMA) dma(std::integral_constant<int, n / GAP>{});
         });
+        // a thin tile has fewer MFMAs here than pieces to issue: the rest behind them (the stage-end wait counts every piece)
+        constexpr int ISSUED = NM / GAP < NDMA ? NM / GAP : NDMA;
+        static_for<NDMA - ISSUED>([&](auto I_) { dma(std::integral_constant<int, ISSUED + decltype(I_)::value>{}); });
 #pragma unroll
         for (int i = 0; i < MT; ++i) keep_a[i] = X3 ? a0[i] : a1[i];   // deferred: hi * lo  (plain: h1 * h1)
 #pragma unroll
@@ -639,6 +642,9 @@ const Shape kShapes[] = {
     RS_SHAPE(8, 1, 4, 3), RS_SHAPE(8, 1, 4, 4), RS_SHAPE(4, 2, 4, 3), RS_SHAPE(4, 2, 4, 4), RS_SHAPE(4, 2, 4, 5),
     RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(2, 4, 4, 4),
     RS_SHAPE(2, 4, 2, 4), RS_SHAPE(2, 4, 4, 3),
+    // thin launches (round 6): a launch of a few rows pays for every staging piece of its tile's slab whether the rows exist
+    // or not (a 256-row slab is 33 pieces per panel: ~650 cycles per sub-stage with 8 live rows): 64- and 32-row tiles
+    RS_SHAPE(4, 2, 1, 1), RS_SHAPE(4, 2, 1, 2), RS_SHAPE(2, 4, 1, 1),
 };
 #undef RS_SHAPE
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
