@@ -37,6 +37,22 @@
 
 #include <algorithm>
 
+// Diagnostic build only (-DRS_RING_STAMPS, tools/ring_stamps.py f16xf8): s_memtime sums of the sub-stage loop per wave:
+// [0] sub-stage bodies, [1] stage-end wait + barrier, [2] epilogues, [3] walk bookkeeping, [4] sub-stages, [5] total
+#ifdef RS_RING_STAMPS
+#define RS_STAMP(k)                                                                  \
+    do {                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        unsigned long long t__;                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");  \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        ph[k] += t__ - tl;                                                           \
+        tl = t__;                                                                    \
+    } while (0)
+#else
+#define RS_STAMP(k) do { } while (0)
+#endif
+
 namespace rs {
 namespace {
 
@@ -77,6 +93,7 @@ struct F8Args {
     int n_reads;
     int shift_out;
     WalkArgs walk;
+    unsigned long long* stamps;  // diagnostic builds only
 };
 
 __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
@@ -548,6 +565,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
     for (int idx = 0; idx < WPW; ++idx) issue_w_piece(cur, true, 1, idx);
     stage_end(std::integral_constant<int, 0>{});
     int xb = 0, cb = 0;
+#ifdef RS_RING_STAMPS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = tl, rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
 
     bool have_prev = false, prev_tile_end = false;
     Panel done = cur;
@@ -568,6 +589,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
         }
         const bool tile_end = cur.p == a.n_panels - 1;
         const bool nxt_scales = IN_F8 && KIND == kH;                 // the next panel is an F panel: its scale slab travels with it
+        RS_STAMP(3);
         // tap 0: this panel's tap-2 weights, first half of the next panel's slab; the previous tile's epilogue, if one is pending
         substage(KIND_, PREV_, std::integral_constant<int, 0>{}, xb, have_prev, std::integral_constant<int, WPW + XPW0>{},
                  [&](auto I_) {
@@ -578,15 +600,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
                          issue_x_first(nxt, nxt_live, xb ^ 1, nxt_scales, idx - WPW);
                  },
                  [&]() {
-                     if (prev_tile_end) epilogue(done, done_cb, done_xb);
+                     if (prev_tile_end) {
+                         RS_STAMP(0);
+                         epilogue(done, done_cb, done_xb);
+                         RS_STAMP(2);
+                     }
                  });
         have_prev = true;
+        RS_STAMP(0);
         if (tile_end) {
             issue_tile_consts(cur, cb);
             stage_end(std::integral_constant<int, WPW + XPW0 + 2>{});
         } else {
             stage_end(std::integral_constant<int, WPW + XPW0>{});
         }
+        RS_STAMP(1);
         // tap 1: the next panel's tap-0 weights, second half of its slab
         substage(KIND_, KIND_, std::integral_constant<int, 1>{}, xb, true, std::integral_constant<int, WPW + XPW1>{},
                  [&](auto I_) {
@@ -597,11 +625,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
                          issue_x_second(nxt, nxt_live, xb ^ 1, idx - WPW);
                  },
                  nothing);
+        RS_STAMP(0);
         stage_end(std::integral_constant<int, WPW + XPW1>{});
+        RS_STAMP(1);
         // tap 2: the next panel's tap-1 weights
         substage(KIND_, KIND_, std::integral_constant<int, 2>{}, xb, true, std::integral_constant<int, WPW>{},
                  [&](auto I_) { issue_w_piece(nxt, nxt_live, 1, decltype(I_)::value); }, nothing);
+        RS_STAMP(0);
         stage_end(std::integral_constant<int, WPW>{});
+        RS_STAMP(1);
+#ifdef RS_RING_STAMPS
+        ph[4] += 3;
+#endif
 
         prev_tile_end = tile_end;
         if (tile_end) {
@@ -630,6 +665,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
     // the walk's last sub-stage: its deferred part and the last tile's epilogue (`xb` has moved on: the slab is done_xb)
     if constexpr (!IN_F8) deferred_pass(KX3);
     epilogue(done, done_cb, done_xb);
+    RS_STAMP(2);
+#ifdef RS_RING_STAMPS
+    if (a.stamps && lane == 0 && blockIdx.x < 4) {
+        unsigned long long* q = a.stamps + (blockIdx.x * 8 + wave) * 8;
+        for (int k = 0; k < 5; ++k) q[k] = ph[k];
+        q[5] = __builtin_amdgcn_s_memtime() - t_begin;
+        q[6] = 0;
+        q[7] = __builtin_amdgcn_s_memrealtime() - rt_begin;        // 100 MHz ticks
+    }
+#endif
 }
 
 using KernelFn = void (*)(const F8Args);
@@ -791,9 +836,30 @@ int launch_conv_ring_f8(const ConvLayerDev& L, const void* d_x, void* d_y, const
     a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, BM, 3.0 * BN, check_dead, !L.hooks->no_rect_order);
     a.walk.m_base = 0;
     KernelFn fn = s->fn[!in_f8 ? 0 : out_f8 ? 1 : 2];
+    a.stamps = nullptr;
+#ifdef RS_RING_STAMPS
+    static unsigned long long* d_stamps = nullptr;
+    if (!d_stamps) RS_HIP(hipMalloc(&d_stamps, 4 * 8 * 8 * 8));
+    a.stamps = d_stamps;
+#endif
     RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes(*s, in_f8), st, a);
     RS_HIP(hipGetLastError());
+#ifdef RS_RING_STAMPS
+    {
+        RS_HIP(hipStreamSynchronize(st));
+        unsigned long long hp[4 * 8 * 8];
+        RS_HIP(hipMemcpy(hp, d_stamps, sizeof(hp), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 8; w += 4) {
+            const unsigned long long* q = &hp[w * 8];
+            const double n = (double)q[4];
+            fprintf(stderr, "[ring-stamps] layer %d f8 %s->%s tile %dx%d panels %d wave %d: %.0f sub-stages, total %.0f cyc; per sub-stage: "
+                    "body %.0f | wait+barrier %.0f | epilogue %.0f | walk %.0f; workgroup loop %.1f us (%.2f GHz)\n",
+                    layer_index, in_f8 ? "f8" : "x3", out_f8 ? "f8" : "x3", BM, BN, n_panels, w, n, (double)q[5], q[0] / n, q[1] / n, q[2] / n,
+                    q[3] / n, q[7] / 100.0, (double)q[5] / (q[7] * 10.0));
+        }
+    }
+#endif
     if (bm_out) *bm_out = BM;
     if (bn_out) *bn_out = BN;
     return RS_OK;
