@@ -69,7 +69,7 @@ READS_PER_GPU = 18000         # BASELINE config 4: 144 k concurrent chunks over 
 LAT_WARMUP, LAT_SAMPLES = 20, 200
 PEAK_F32_MFMA_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md:45
 PEAK_BF16_MFMA_TF = 2500.0    # :46
-PROFILE_ROUND = "r05"         # roofline.traffic comes from profiles/<round>_pmc_fetch_write_<mode>.json of THIS round only
+PROFILE_ROUND = "r06"         # roofline.traffic comes from profiles/<round>_pmc_fetch_write_<mode>.json of THIS round only
 LIB_DTYPE = {"f32": "f32w", "f32_direct": "f32"}
 MFMA_PASSES = {"bf16x3": 3, "f16x3": 3, "f16xf8": 3}   # split-precision modes issue three 16-bit MFMAs per product (f16xf8: two
                                                          # instruction times on its wide layers; counted as three here)
@@ -275,7 +275,7 @@ def traffic_object(args, model, wl):
     (profiles/rNN_pmc_fetch_write_<mode>.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs of this same command,
     KiB per dispatch, FETCH doubled for gfx950 as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside a
     run, so the figure is the profiled run's, valid for the same workload (config, dtype, batch, chunk)."""
-    tag = {"f32": "f32", "bf16x3": "bf16x3"}.get(args.dtype) if args.config == "rna004_b512" else (
+    tag = {"f32": "f32", "bf16x3": "bf16x3", "f16xf8": "f16xf8"}.get(args.dtype) if args.config == "rna004_b512" else (
         "prog" if args.config == "progressive" and args.dtype == "f16x3" else None)
     if tag is None or args.batch != BATCH or args.chunk != CHUNK:
         return None

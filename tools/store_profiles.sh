@@ -1,9 +1,9 @@
 #!/bin/bash
-# copy the outputs of tools/profile_round.sh r05_f32 f32 / r05_bf16x3 bf16x3 (gpurun_out/prof_r05_*) to their names under profiles/
+# copy the outputs of tools/profile_round.sh r06_f32 f32 / r06_bf16x3 bf16x3 / r06_f16xf8 f16xf8 (gpurun_out/prof_r06_*) to their names under profiles/
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-R=${1:-r05}
-for m in f32 bf16x3; do
+R=${1:-r06}
+for m in f32 bf16x3 f16xf8; do
   d=$ROOT/gpurun_out/prof_${R}_$m
   cp "$d/kernel_stats.csv" "$ROOT/profiles/${R}_kernel_stats_$m.csv"
   cp "$d/pmc_mfma.json" "$ROOT/profiles/${R}_pmc_mfma_busy_$m.json"
