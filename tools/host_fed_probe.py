@@ -18,7 +18,7 @@ t=time.perf_counter()
 for k in range(20): d.copy_(pinned[k*B:(k+1)*B].reshape(-1), non_blocking=True)
 torch.cuda.synchronize()
 print("H2D 16.4 MB: %.3f ms each" % ((time.perf_counter()-t)/20*1e3))
-for dt in ("f32w", "bf16x3", "f16xf8", "bf16x3", "f32w"):
+for dt in (sys.argv[1:] or ["f32w", "bf16x3", "f16xf8", "bf16x3", "f32w"]):
     m = Model(synth.make_state_dict(1), synth.Config(), None, "m", dtype=dt, device=dev)
     sc = StreamClassifier([m], sub_batch=B, max_len=L)
     sc.classify(pinned[:4*B])
@@ -31,5 +31,5 @@ for dt in ("f32w", "bf16x3", "f16xf8", "bf16x3", "f32w"):
     torch.cuda.synchronize(); t=time.perf_counter()
     for _ in range(100): m.classify_raw(sig, off, ln, lh)
     torch.cuda.synchronize(); r=(time.perf_counter()-t)/100*1e3
-    print(dt, "host-fed ms/batch", ["%.3f"%x for x in res], "resident %.3f" % r)
+    print(dt, "dev bufs at", [hex(t.data_ptr()) for t in sc._dev], "ws", {k: hex(v.data_ptr()) for k, v in getattr(m._ws, "_bufs", {}).items()} if hasattr(m._ws, "_bufs") else "", "host-fed ms/batch", ["%.3f"%x for x in res], "resident %.3f" % r)
     m.close()
