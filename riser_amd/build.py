@@ -20,7 +20,7 @@ OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(LIBDIR, "libriser_amd.so")
 ARCH = "gfx950"
 
-SOURCES = ["api.hip", "normalise.hip", "normalise_float.hip", "pointwise.hip", "fc_head.hip", "conv_f32.hip", "conv_wino.hip", "conv_wino_thin.hip", "conv_wino4.hip", "conv_stream_f32.hip", "conv_small_f32.hip", "conv_ring_h16.hip", "conv_ring_f8.hip", "conv_wres_h16.hip", "conv_stream_h16.hip", "polya.hip", "seqnet.hip"]
+SOURCES = ["api.hip", "normalise.hip", "normalise_float.hip", "pointwise.hip", "fc_head.hip", "conv_f32.hip", "conv_wino.hip", "conv_wino_thin.hip", "conv_wino4.hip", "conv_stream_f32.hip", "conv_small_f32.hip", "conv_ring_h16.hip", "conv_ring_f8.hip", "conv_thin_h16.hip", "conv_wres_h16.hip", "conv_stream_h16.hip", "polya.hip", "seqnet.hip"]
 # -ffp-contract=off: the normalise kernel must reproduce numpy's separately rounded fp64
 # operations; the conv kernels use explicit fmaf / MFMA so they lose nothing.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fvisibility=hidden",

@@ -58,6 +58,7 @@ Hooks Hooks::from_env() {
     text("RS_EMU_ROWS", h.emu_rows, sizeof(h.emu_rows));
     if (const char* e = getenv("RS_SMALL_F32_WAVES")) h.small_f32_waves = atoi(e);
     if (const char* e = getenv("RS_H16_WRES")) h.h16_wres = atoi(e) != 0;
+    if (const char* e = getenv("RS_THIN_H16_ROWS")) h.thin_h16_rows = atoi(e);
     return h;
 }
 
@@ -952,7 +953,22 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
         // RS_F16XF8: the wide layers read and / or write F8 rows (cross terms on the 8-bit MFMA: conv_ring_f8.hip)
         const bool f8 = ring && (L.f8_in || L.f8_out);
         // ... and narrow layers whose whole weight tensor fits LDS next to two activation slabs on the weights-resident kernel
-        const bool wres = ring && !f8 && conv_wres_h16_ok(L, x3);
+        // split precision on a launch of a few rows (Model.classify at batch 1, a thin ReadUntil batch): 64 x 32 tiles that take a
+        // WHOLE PANEL per barrier instead of the ring's (panel, tap) sub-stages, each as long as a staging round trip whatever
+        // the tile holds (conv_thin_h16.hip; same bits)
+        bool thin16 = ring && x3 && !f8 && !m->tuning && m->hooks.thin_h16_rows != 0 && conv_thin_h16_ok(L);
+        if (thin16) {
+            const int64_t rows_in = (int64_t)NB * P_in;
+            if (m->hooks.thin_h16_rows > 0)
+                thin16 = rows_in <= m->hooks.thin_h16_rows;
+            else
+                thin16 = conv_thin_h16_cost(L, rows_in, m->num_cu) < conv_ring_plan_cost(L, rows_in, m->num_cu, x3);
+            if (m->hooks.tail_debug)
+                fprintf(stderr, "[thin-or-ring] layer %d: rows %lld, thin %.0f (%lld tiles), ring %.0f -> %s\n", i, (long long)rows_in,
+                        conv_thin_h16_cost(L, rows_in, m->num_cu), (long long)conv_thin_h16_tiles(L, rows_in),
+                        conv_ring_plan_cost(L, rows_in, m->num_cu, x3), thin16 ? "thin" : "ring");
+        }
+        const bool wres = ring && !f8 && !thin16 && conv_wres_h16_ok(L, x3);
         // fp32 Winograd layers of a launch with only a handful of rows (Model.classify at batch 1, a thin ReadUntil batch):
         // one wave per 16 x 16 tile instead of 256-row tiles that are mostly padding (conv_small_f32.hip; same bits)
         // (not layer 1 when layer 0 is folded into its staging: nothing has written that layer's input)
@@ -978,7 +994,7 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                             tiled, thin_fit ? "thin fit + launch" : "full-launch model", small32 ? "small" : "tiled");
             }
         }
-        const int kind = (stream32 || stream16 || wres || small32) ? 0 : f8 ? 6 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)
+        const int kind = (stream32 || stream16 || wres || small32 || thin16) ? 0 : f8 ? 6 : ring ? 5 : m->dtype == RS_F32W ? (L.wino_m == 4 ? 1 : 2)
                                                                     : m->dtype == RS_F32 ? 3 : 4;
         m->last_ring[i] = ring;
         auto launch_layer = [&]() -> int {
@@ -1007,7 +1023,9 @@ static int forward_impl(rs_model* m, const float* d_x, int64_t ldx, const int32_
                                             f0 ? d_x : nullptr, m->d_w0, m->channels[0], x3);
                 m->last_bm[i] = 16;
                 m->last_bn[i] = round_up(L.c_out, 16);
-            } else if (f8)
+            } else if (thin16)
+                rc = launch_conv_thin_h16(L, buf[cur], buf[cur ^ 1], d_blen, NB, P_in, i, m->num_cu, f16, st, &m->last_bm[i], &m->last_bn[i]);
+            else if (f8)
                 rc = launch_conv_ring_f8(L, buf[cur], buf[cur ^ 1], d_blen, NB, P_in, i, m->num_cu, check_dead, st, &m->last_bm[i],
                                          &m->last_bn[i]);
             else if (wres)

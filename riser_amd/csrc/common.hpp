@@ -76,6 +76,8 @@ struct Hooks {
     char force_wino4[256] = "";
     char force_ring[256] = "";       // RS_FORCE_SHAPE_RING
     char emu_rows[128] = "";         // RS_EMU_ROWS "layer:permille;...": TIMING ONLY - the layer runs on that share of the batch's blocks
+    int thin_h16_rows = -1;          // RS_THIN_H16_ROWS: split-precision layers of a launch with at most this many input rows run the
+                                     // thin-launch kernel (conv_thin_h16.hip; 0 = never; default -1: by the cost estimates)
     bool h16_wres = true;            // RS_H16_WRES=0: narrow 16-bit layers on the ring kernel instead of the weights-resident one
     static Hooks from_env();
 };
@@ -216,6 +218,13 @@ bool conv_wres_h16_ok(const ConvLayerDev& L, bool x3);
 int launch_conv_wres_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
                          int layer_index, int num_cu, bool f16, bool x3, int check_dead, hipStream_t st, int* bm_out,
                          int* bn_out);
+// split precision on launches of a few rows: 64 x 32 tiles, a whole panel per barrier (conv_thin_h16.hip); the ring kernel's bits
+bool conv_thin_h16_ok(const ConvLayerDev& L);
+int64_t conv_thin_h16_tiles(const ConvLayerDev& L, int64_t rows_in);
+double conv_thin_h16_cost(const ConvLayerDev& L, int64_t rows_in, int num_cu);
+double conv_ring_plan_cost(const ConvLayerDev& L, int64_t rows_in, int num_cu, bool x3);     // the ring kernel's own estimate of the launch
+int launch_conv_thin_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
+                         int layer_index, int num_cu, bool f16, hipStream_t st, int* bm_out, int* bn_out);
 // RS_F16XF8 (conv_ring_f8.hip): split precision with the cross terms on the block-scaled 8-bit MFMA; F8 rows carry a scale plane
 int launch_conv_ring_f8(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
                         int layer_index, int num_cu, int check_dead, hipStream_t st, int* bm_out, int* bn_out);

@@ -689,6 +689,13 @@ const Shape* choose_shape(int64_t rows, int n16, int n_panels, int num_cu, bool 
 
 }  // namespace
 
+// the planner's own estimate (its cycles) of a launch over `rows` input rows with the best shape of the table
+double conv_ring_plan_cost(const ConvLayerDev& L, int64_t rows, int num_cu, bool x3) {
+    double cost = 1e300;
+    choose_shape(rows, round_up(L.c_out, 16) / 16, L.ring_panels, num_cu, x3, &cost);
+    return cost + 2500.0;
+}
+
 int conv_ring_max_bn() { return 256; }
 int conv_ring_num_shapes() { return kNumShapes; }
 bool conv_ring_shape_ok(const ConvLayerDev&, int k) {

@@ -292,3 +292,47 @@ def test_normalise_fuzz_structured_reads(dev):
         else:
             assert np.array_equal(g, ro.mad_normalise(sgn)), (k, len(sgn))
 
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3", "f16xf8"])
+def test_thin_launch_kernel_of_split_precision_keeps_the_bits(dev, dtype):
+    """round 6: the split-precision layers of a THIN launch - Model.classify at batch 1
+    (riser/model.py:22-28), the ~20 reads a chunk client delivers (riser/control.py:63-69) - run 64 x 32 tiles that take a whole
+    32-channel panel (all three taps) per barrier (csrc/conv_thin_h16.hip) instead of the ring kernel's (panel, tap) sub-stages.
+    Same LDS image, same MFMA sequence per accumulator, same epilogue roundings: identical bits to the ring / weights-resident
+    kernels (RS_THIN_H16_ROWS=0) with the kernel chosen by the planner AND forced onto every launch, for 1 ... 130 reads of
+    ragged lengths; a read alone equals its row of a 300-read batch; within the mode's tolerance of the oracle."""
+    from riser_amd.preprocess import pack_reads
+    sd = synth.make_state_dict(1)
+    auto = hooked_model({}, sd, dtype, dev)
+    ring = hooked_model({"RS_THIN_H16_ROWS": "0"}, sd, dtype, dev)
+    forced = hooked_model({"RS_THIN_H16_ROWS": "100000000"}, sd, dtype, dev)
+    for B in (1, 5, 16, 40, 130):
+        rng = np.random.default_rng(200 + B)
+        lens = rng.integers(4096, 16001, size=B)
+        sigs = _reads(lens, first=41000 + B)
+        sig, off, ln, lh = pack_reads(sigs, dev)
+        want = ring.classify_raw(sig, off, ln, lh, return_logits=True)
+        for name, m in (("planner", auto), ("forced", forced)):
+            got = m.classify_raw(sig, off, ln, lh, return_logits=True)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (dtype, B, name)
+        if B == 1 and dtype != "f16xf8":
+            info = auto.layer_info()
+            assert info[11]["bm"] == 64 and info[11]["bn"] == 32 and info[4]["bm"] == 64     # the planner took the thin kernel
+        if B == 5:
+            oracle = ro.classify_reads(sd, sigs)
+            assert np.abs(want[0].cpu().numpy() - oracle).max() < 1e-3
+    info = forced.layer_info()
+    assert all(info[i]["bm"] == 64 and info[i]["bn"] == 32 for i in range(3, 7))   # layers 3-6 are split-precision rows in all three modes
+    # a read alone against its row of a large batch (which stays on the big tiles)
+    rng = np.random.default_rng(3)
+    lens = rng.integers(4096, 16001, size=300)
+    sigs = _reads(lens, first=43000)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    big = auto.classify_raw(sig, off, ln, lh).cpu().numpy()
+    assert auto.layer_info()[7]["bm"] > 64 and auto.layer_info()[11]["bm"] > 64
+    for k in (0, 123, 299):
+        s1, o1, l1, h1 = pack_reads([sigs[k]], dev)
+        assert np.array_equal(auto.classify_raw(s1, o1, l1, h1).cpu().numpy()[0], big[k])
+    for m in (auto, ring, forced):
+        m.close()
