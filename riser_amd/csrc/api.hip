@@ -39,6 +39,7 @@ Hooks Hooks::from_env() {
     h.no_rect_order = flag("RS_NO_RECT_ORDER");
     h.no_tail_split = flag("RS_NO_TAIL_SPLIT");
     h.tail_debug = flag("RS_TAIL_DEBUG");
+    if (const char* e = getenv("RS_TAIL_MARGIN")) h.tail_margin = atof(e);
     h.no_deep_staging = flag("RS_NO_DEEP_STAGING");
     if (const char* e = getenv("RS_SMALL_SHARED")) h.small_shared = atoi(e);
     if (const char* e = getenv("RS_SMALL_NW")) h.small_nw = atoi(e);

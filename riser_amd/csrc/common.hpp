@@ -61,6 +61,7 @@ struct Hooks {
     bool no_deep_staging = false;    // RS_NO_DEEP_STAGING: the thin fp32 Winograd shapes keep the default staging distance (A/B of the one-item-ahead loads)
     bool tail_debug = false;         // RS_TAIL_DEBUG: print every head / tail decision
     bool ring_tail_split = false;    // RS_RING_TAIL_SPLIT: head + tail launches for the 16-bit ring kernel too (measured: a wash)
+    double tail_margin = 0.0;        // RS_TAIL_MARGIN: a head + tail split is taken when priced below this share of ONE launch (0: the kernels' own 0.97 / 0.92; tuning aid)
     bool no_tail_split = false;      // RS_NO_TAIL_SPLIT: tiled conv layers (fp32 Winograd, 16-bit ring) always as ONE launch (tile_walk.hpp: plan_tail_split)
     bool no_fuse0 = false;           // RS_NO_FUSE0: layer 0 as its own launch on the fp32 Winograd path
     bool no_stream_f32 = false;      // RS_NO_STREAM_F32 / _H16: tiled kernels instead of the streaming ones

@@ -828,7 +828,7 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
                 const Shape* t = choose_shape(r, n16, n_panels, num_cu, x3, c);
                 return t ? (int)(t - kShapes) : -1;
             },
-            0.92);      // this kernel's small tiles cost more than the model says (prologue + epilogue per tile): splits the
+            L.hooks->tail_margin > 0 ? L.hooks->tail_margin : 0.92);      // this kernel's small tiles cost more than the model says (prologue + epilogue per tile): splits the
                         // model prices within 8 % of one launch measured at -1 % (357 x 8615), the others at +1 ... +4.5 %
     int BM, BN;
     if (split.head_shape >= 0) {

@@ -713,7 +713,8 @@ int launch_conv_wino4(const ConvLayerDev& L, const float* d_x, float* d_y, const
                 // thin-launch fit picks for its rows (never slower than this one)
                 const Shape* t = choose_shape(g, n16, p.kc, p.nch, num_cu, c, nullptr, false);
                 return t ? (int)(t - kShapes) : -1;
-            });
+            },
+            L.hooks->tail_margin > 0 ? L.hooks->tail_margin : 0.97);
     int BG, BN;
     if (split.head_shape >= 0) {
         const Shape& h = kShapes[split.head_shape];
