@@ -354,12 +354,6 @@ RS_API int rs_seqnet_ragged_ok(const rs_seqnet* m);
 RS_API int rs_seqnet_forward_ragged(rs_seqnet* m, const float* d_x /* fp32 [B, ld] */, const int32_t* d_len, int B, int ld, void* d_ws,
                              size_t ws_bytes, float* d_probs, float* d_logits, void* stream);
 
-/*
- * Test hook: every following forward pass of `m` also copies the output buffer of conv layer `layer`
- * (1 <= layer < n_layers; position-major [NB * (U >> (layer + 1)), cp_out] in the packed block layout - see
- * rs_block_samples - fp32 or 16-bit) into d_dst
- * (at most `bytes`).  d_dst = NULL switches it off.  Used by the layer-wise parity tests.
- */
 /* Half precision has a range: RS_F16 / RS_F16X3 / RS_F16XF8 store activations as IEEE half, and a value beyond 65504 leaves the
  * conversion as +inf - the forward pass goes on, the probabilities of that read are wrong, and the reference's fp32 path
  * (riser/model.py:22-28) has no such failure.  Every kernel epilogue of those modes checks its conversions and raises a sticky flag
@@ -368,6 +362,12 @@ RS_API int rs_seqnet_forward_ragged(rs_seqnet* m, const float* d_x /* fp32 [B, l
  * != 0 clears the flag behind the read.  (ABI 2.5) */
 RS_API int rs_model_saturated(rs_model* m, int reset, void* stream);
 
+/*
+ * Test hook: every following forward pass of `m` also copies the output buffer of conv layer `layer`
+ * (1 <= layer < n_layers; position-major [NB * (U >> (layer + 1)), cp_out] in the packed block layout - see
+ * rs_block_samples - fp32 or 16-bit) into d_dst
+ * (at most `bytes`).  d_dst = NULL switches it off.  Used by the layer-wise parity tests.
+ */
 RS_API int rs_debug_capture_layer(rs_model* m, int layer, void* d_dst, size_t bytes);
 
 /*

@@ -60,6 +60,7 @@ Hooks Hooks::from_env() {
     if (const char* e = getenv("RS_SMALL_F32_WAVES")) h.small_f32_waves = atoi(e);
     if (const char* e = getenv("RS_H16_WRES")) h.h16_wres = atoi(e) != 0;
     if (const char* e = getenv("RS_THIN_H16_ROWS")) h.thin_h16_rows = atoi(e);
+    if (const char* e = getenv("RS_F8_MIN_CIN")) h.f8_min_cin = atoi(e);
     return h;
 }
 
@@ -414,9 +415,8 @@ unsigned char to_e4m3(float f) {
 // once - MFMA, L2 -> LDS staging (~24 B/clk/CU) and LDS fragment reads are each ~1 500 cycles per sub-stage at 256 x 192 - and
 // its even-NT tile shapes cover the narrow layers' columns worse than the split-precision kernel's (measured, 512 x 16000:
 // layers 4, 5 +20 ... +30 %, layer 6 +-0, layers 7 / 8 / 9 / 11 -5 / -11 / -10 / -18 %)
-bool f8_eligible(int dtype, int i, int n_layers, const int32_t* channels) {
-    const int min_cin = getenv("RS_F8_MIN_CIN") ? atoi(getenv("RS_F8_MIN_CIN")) : 200;        // model creation only
-    return dtype == RS_F16XF8 && i >= 3 && i < n_layers && channels[i - 1] >= std::max(64, min_cin);
+bool f8_eligible(const Hooks& h, int dtype, int i, int n_layers, const int32_t* channels) {
+    return dtype == RS_F16XF8 && i >= 3 && i < n_layers && channels[i - 1] >= std::max(64, h.f8_min_cin);
 }
 
 template <class T>
@@ -488,7 +488,7 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         m->cp[i] = is_x3(dtype) ? 64 * ((channels[i] + 31) / 32)
                                 : round_up(channels[i], (dtype == RS_F32 || dtype == RS_F32W) ? 4 : 8);
         // RS_F16XF8: the rows between two layers of a run are F8 rows: 128 elements (an H and an F panel) per 64 channels
-        if (f8_eligible(dtype, i, n_layers, channels) && f8_eligible(dtype, i + 1, n_layers, channels))
+        if (f8_eligible(m->hooks, dtype, i, n_layers, channels) && f8_eligible(m->hooks, dtype, i + 1, n_layers, channels))
             m->cp[i] = 128 * ((channels[i] + 63) / 64);
     }
     int rc = RS_OK;
@@ -512,8 +512,8 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
         L.cp_in = m->cp[i - 1];
         L.cp_out = m->cp[i];
         L.x3_terms = x3_terms_of(i);
-        L.f8_in = f8_eligible(dtype, i, n_layers, channels) && f8_eligible(dtype, i - 1, n_layers, channels);
-        L.f8_out = f8_eligible(dtype, i, n_layers, channels) && f8_eligible(dtype, i + 1, n_layers, channels);
+        L.f8_in = f8_eligible(m->hooks, dtype, i, n_layers, channels) && f8_eligible(m->hooks, dtype, i - 1, n_layers, channels);
+        L.f8_out = f8_eligible(m->hooks, dtype, i, n_layers, channels) && f8_eligible(m->hooks, dtype, i + 1, n_layers, channels);
         if (dtype == RS_F32) {
             L.plan = plan_static_f32(L.cp_in, L.c_out);
             const ConvPlan& p = L.plan;

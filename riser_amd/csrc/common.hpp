@@ -79,6 +79,7 @@ struct Hooks {
     char emu_rows[128] = "";         // RS_EMU_ROWS "layer:permille;...": TIMING ONLY - the layer runs on that share of the batch's blocks
     int thin_h16_rows = -1;          // RS_THIN_H16_ROWS: split-precision layers of a launch with at most this many input rows run the
                                      // thin-launch kernel (conv_thin_h16.hip; 0 = never; default -1: by the cost estimates)
+    int f8_min_cin = 200;            // RS_F8_MIN_CIN: RS_F16XF8 puts a layer on the 8-bit kernel from this many input channels on (api.hip: f8_eligible)
     bool h16_wres = true;            // RS_H16_WRES=0: narrow 16-bit layers on the ring kernel instead of the weights-resident one
     static Hooks from_env();
 };

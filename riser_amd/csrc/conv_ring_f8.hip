@@ -342,12 +342,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
     // One sub-stage = tap TAP of the panel in slab xb.  As in conv_ring_h16.hip the LAST part of its MFMAs is deferred to the
     // head of the next sub-stage, behind that one's first fragment reads: for the 16-bit kinds the last pass, for an F panel
     // the upper half of the row blocks (operands kept in registers either way).
+    // 24 accumulator tiles in SIX column tiles keep nothing of an F sub-stage back: the kept weight fragments (2 x NT x 4
+    // registers) do not fit beside them - with the deferral <4, 2, 4, 6> spilled 120 bytes per lane and ran layer 9 in 94 us, without
+    // it 36 bytes and 80 us; the other shapes gain 1-4 % from it (tools/shape_sweep.py, round 6)
+    constexpr bool kFDefer = !(MT * NT >= 24 && NT >= 6);
     u32x4 keep_a[MT], keep_b[NT];                       // pending 16-bit pass
     u32x4 keep8_a[MT / 2][2], keep8_b[NT][2];           // pending 8-bit half: row blocks MT / 2 .. MT - 1
     int keep8_s[MT / 2];
     auto deferred_pass = [&](auto PREV_) __attribute__((always_inline)) {
         constexpr int PREV = decltype(PREV_)::value;
         if constexpr (PREV == kNone) {
+        } else if constexpr (PREV == kF && !kFDefer) {
         } else if constexpr (PREV == kF) {
 #pragma unroll
             for (int i = 0; i < MT / 2; ++i)
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_f8_kernel(const F8Args 
         constexpr int tap = decltype(TAP)::value;
         constexpr int NDMA = decltype(NDMA_)::value;
         // tap 2 of an F panel keeps nothing back: the sub-stage behind it may run a tile's epilogue, which needs the registers
-        constexpr bool F_DEFER = KIND == kF && tap != 2;
+        constexpr bool F_DEFER = KIND == kF && tap != 2 && kFDefer;
         constexpr int NM = KIND == kX3 ? 2 * MT * NT : KIND == kH ? MT * NT : F_DEFER ? (MT / 2) * NT : MT * NT;      // MFMAs executed here
         constexpr int GAP = NM / (NDMA + 1) > 0 ? NM / (NDMA + 1) : 1;
         const unsigned ax0 = a_rd[tap][0] + (unsigned)(xb * XS), ax1 = a_rd[tap][1] + (unsigned)(xb * XS);
@@ -697,6 +702,7 @@ const Shape kShapes[] = {
     RS_SHAPE(8, 1, 2, 2), RS_SHAPE(8, 1, 2, 4), RS_SHAPE(8, 1, 2, 6), RS_SHAPE(4, 2, 4, 4), RS_SHAPE(4, 2, 4, 6),
     RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(2, 4, 4, 4), RS_SHAPE(2, 4, 2, 4),
     RS_SHAPE(4, 2, 2, 2), RS_SHAPE(2, 4, 2, 2),            // thin launches: 128 x 64, 64 x 128 (conv_ring_h16.hip's reason)
+    RS_SHAPE(4, 2, 6, 4), RS_SHAPE(2, 4, 6, 2), RS_SHAPE(2, 4, 6, 4),      // 384- and 192-row tiles (conv_ring_h16.hip: batches off the multiples of 256 reads)
 };
 #undef RS_SHAPE
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
@@ -712,7 +718,10 @@ double tile_cost(const Shape& s, int n_panels, bool in_f8) {
     const double dma = ((bm + 8) / 3.0 + bnt * 16.0) * 128.0 / 24.0;
     const double ldsr = 2.0 * 8.0 * (s.mt + s.nt) * 1024.0 / 256.0 * 1.2;
     const double sub = std::max(std::max(mfma, dma), ldsr) + 350.0;
-    return 3.0 * n_panels * sub + 1500.0 + 60.0 * s.mt * s.nt * 2.0;
+    // <4, 2, 4, 6> on F8 input still spills 36-40 bytes per lane (its F sub-stages keep nothing back, see the kernel): a
+    // whole-round launch runs 1.09 x the 384 x 128 tile of the same area (tools/shape_sweep.py, layer 10: 107 against 98 us)
+    const double spill = in_f8 && s.mt * s.nt >= 24 && s.nt >= 6 ? 1.08 : 1.0;
+    return spill * (3.0 * n_panels * sub + 1500.0 + 60.0 * s.mt * s.nt * 2.0);
 }
 
 const Shape* choose_shape(int64_t rows, int cols, int n_panels, int num_cu, bool in_f8, double* cost_out = nullptr) {
@@ -768,7 +777,7 @@ int launch_conv_ring_f8(const ConvLayerDev& L, const void* d_x, void* d_y, const
     }
     // logical channel slots of an output row: every one of them is covered by a tile when the rows are F8 rows (the slots
     // behind the last channel are products with zero weight rows: exact zeros, a valid scale)
-    const int cols_out = out_f8 ? L.cp_out / 2 : L.cp_out / 2;      // F8: 128 elements per 64 slots; x3: 64 per 32
+    const int cols_out = L.cp_out / 2;      // channel slots of a row: F8 rows hold 128 halfwords per 64 slots, x3 rows 64 per 32
     const int cols_cover = out_f8 ? cols_out : round_up(L.c_out, 16);
     const int n_panels = L.ring_panels;
     const Shape* s = choose_shape(rows64, cols_cover, n_panels, num_cu, in_f8);

@@ -642,6 +642,10 @@ const Shape kShapes[] = {
     RS_SHAPE(8, 1, 4, 3), RS_SHAPE(8, 1, 4, 4), RS_SHAPE(4, 2, 4, 3), RS_SHAPE(4, 2, 4, 4), RS_SHAPE(4, 2, 4, 5),
     RS_SHAPE(4, 2, 4, 6), RS_SHAPE(4, 2, 2, 4), RS_SHAPE(4, 2, 2, 6), RS_SHAPE(2, 4, 4, 4),
     RS_SHAPE(2, 4, 2, 4), RS_SHAPE(2, 4, 4, 3),
+    // row counts between the powers of two (round 6): a batch that is not a multiple of 256 reads leaves the layers 1.5 or 2.5
+    // rounds of the 256- / 512-row tiles; 192- / 320- / 384-row tiles turn those into whole rounds
+    RS_SHAPE(8, 1, 3, 3), RS_SHAPE(8, 1, 3, 4), RS_SHAPE(4, 2, 3, 4), RS_SHAPE(4, 2, 3, 5), RS_SHAPE(4, 2, 3, 6),
+    RS_SHAPE(4, 2, 5, 4), RS_SHAPE(4, 2, 6, 4),
     // thin launches (round 6): a launch of a few rows pays for every staging piece of its tile's slab whether the rows exist
     // or not (a 256-row slab is 33 pieces per panel: ~650 cycles per sub-stage with 8 live rows): 64- and 32-row tiles
     RS_SHAPE(4, 2, 1, 1), RS_SHAPE(4, 2, 1, 2), RS_SHAPE(2, 4, 1, 1),

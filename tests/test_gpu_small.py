@@ -336,3 +336,41 @@ def test_thin_launch_kernel_of_split_precision_keeps_the_bits(dev, dtype):
         assert np.array_equal(auto.classify_raw(s1, o1, l1, h1).cpu().numpy()[0], big[k])
     for m in (auto, ring, forced):
         m.close()
+
+
+# conv_ring_h16.hip's and conv_ring_f8.hip's shape tables (WM, WN, MT, NT): a forced shape that a kernel does not hold is ignored
+RING_SHAPES = [(8, 1, 2, 2), (8, 1, 2, 3), (8, 1, 2, 5), (8, 1, 2, 7), (8, 1, 4, 2), (8, 1, 4, 3), (8, 1, 4, 4), (4, 2, 4, 3), (4, 2, 4, 4),
+               (4, 2, 4, 5), (4, 2, 4, 6), (4, 2, 2, 4), (4, 2, 2, 6), (2, 4, 4, 4), (2, 4, 2, 4), (2, 4, 4, 3), (8, 1, 3, 3), (8, 1, 3, 4),
+               (4, 2, 3, 4), (4, 2, 3, 5), (4, 2, 3, 6), (4, 2, 5, 4), (4, 2, 6, 4), (4, 2, 1, 1), (4, 2, 1, 2), (2, 4, 1, 1)]
+F8_SHAPES = [(8, 1, 2, 2), (8, 1, 2, 4), (8, 1, 2, 6), (4, 2, 4, 4), (4, 2, 4, 6), (4, 2, 2, 4), (4, 2, 2, 6), (2, 4, 4, 4), (2, 4, 2, 4),
+             (4, 2, 2, 2), (2, 4, 2, 2), (4, 2, 6, 4), (2, 4, 6, 2), (2, 4, 6, 4)]
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3", "f16xf8"])
+def test_every_tile_shape_of_the_16bit_ring_kernels_keeps_the_bits(dev, dtype):
+    """round 6: the ring kernels' tables hold 192- / 320- / 384-row tiles next to the powers of two (a batch that is not a multiple
+    of 256 reads fills whole rounds of the CUs with them) and the 8-bit kernel's widest shape keeps no F sub-stage back.  A tile
+    shape only regroups rows and channels: every accumulator sees the same panel -> tap -> (hi hi, lo hi, hi lo | 8-bit)
+    sequence, so EVERY shape of both tables, forced onto every ring layer, must reproduce the planner's bits on a ragged batch;
+    and the planner's own result is within the mode's tolerance of the oracle."""
+    from riser_amd.preprocess import pack_reads
+    sd = synth.make_state_dict(1)
+    rng = np.random.default_rng(77)
+    lens = np.concatenate([rng.integers(4096, 16001, size=70), [16000] * 26])
+    sigs = _reads(lens, first=47000)
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    auto = hooked_model({"RS_THIN_H16_ROWS": "0"}, sd, dtype, dev)
+    want = auto.classify_raw(sig, off, ln, lh, return_logits=True)
+    oracle = ro.classify_reads(sd, sigs[:12])
+    assert np.abs(want[0][:12].cpu().numpy() - oracle).max() < 1e-3
+    auto.close()
+    taken = 0
+    for sh in sorted(set(RING_SHAPES + (F8_SHAPES if dtype == "f16xf8" else []))):
+        force = ";".join("%d:%d,%d,%d,%d" % ((layer,) + sh) for layer in range(3, 12))
+        m = hooked_model({"RS_THIN_H16_ROWS": "0", "RS_FORCE_SHAPE_RING": force}, sd, dtype, dev)
+        got = m.classify_raw(sig, off, ln, lh, return_logits=True)
+        bm, bn = sh[0] * 16 * sh[2], sh[1] * 16 * sh[3]
+        taken += any(i["bm"] == bm and i["bn"] == bn for i in m.layer_info()[4:12])
+        m.close()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), (dtype, sh)
+    assert taken >= 20, taken                    # the forces were honoured (a shape whose LDS does not fit a layer is skipped)

@@ -1,5 +1,5 @@
 """A/B two builds of the library in one process launch sequence (alternating), per-step time of dtype $RS_DT (default f32) at
-$RS_B x $RS_L (default 512 x 16000)."""
+$RS_B x $RS_L (default 512 x 16000; RS_MIXED=1: lengths L/2, 3L/4, L by read index)."""
 import sys, os, subprocess, json
 libs = sys.argv[1:]
 code = r'''
@@ -13,6 +13,9 @@ B, L = int(os.environ.get("RS_B", 512)), int(os.environ.get("RS_L", 16000))
 sigs = synth.make_signals(20260103, B, L)
 dev = torch.device("cuda", 0)
 sig, off, ln, lens = pack_reads(list(sigs), dev)
+if os.environ.get("RS_MIXED"):                       # 2 s / 3 s / 4 s thirds (BASELINE config 5)
+    lens = np.array([(L // 2, 3 * L // 4, L)[i % 3] for i in range(B)], dtype=np.int32)
+    ln = torch.from_numpy(lens).to(dev)
 m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=os.environ.get("RS_DT", "f32"))
 out = torch.empty((B, 2), device=dev)
 for _ in range(5): m.classify_raw(sig, off, ln, lens, out=out)

@@ -20,10 +20,12 @@ sigs = synth.make_signals(20260103, 64, L); sigs = np.tile(sigs, ((B + 63) // 64
 dev = torch.device("cuda", 0)
 sig, off, ln, lens = pack_reads(list(sigs), dev)
 m = Model(synth.make_state_dict(1), synth.Config(), None, "mRNA", dtype=DT)
-RING = [(8,1,2,2),(8,1,2,3),(8,1,2,5),(8,1,2,7),(8,1,4,2),(8,1,4,3),(8,1,4,4),(4,2,4,3),(4,2,4,4),(4,2,4,5),(4,2,4,6),(4,2,2,4),(4,2,2,6),(2,4,4,4),(2,4,2,4),(2,4,4,3)]
-IS_RING = DT in ("bf16x3", "f16x3", "f16", "bf16")     # every tiled 16-bit layer runs the ring kernel
+RING = [(8,1,2,2),(8,1,2,3),(8,1,2,5),(8,1,2,7),(8,1,4,2),(8,1,4,3),(8,1,4,4),(4,2,4,3),(4,2,4,4),(4,2,4,5),(4,2,4,6),(4,2,2,4),(4,2,2,6),(2,4,4,4),(2,4,2,4),(2,4,4,3),
+        (8,1,3,3),(8,1,3,4),(4,2,3,4),(4,2,3,5),(4,2,3,6),(4,2,5,4),(4,2,6,4)]
+RING_F8 = [(8,1,2,2),(8,1,2,4),(8,1,2,6),(4,2,4,4),(4,2,4,6),(4,2,2,4),(4,2,2,6),(2,4,4,4),(2,4,2,4),(4,2,6,4),(2,4,6,2),(2,4,6,4)]   # conv_ring_f8.hip (layers on F8 rows)
+IS_RING = DT in ("bf16x3", "f16x3", "f16", "bf16", "f16xf8")     # every tiled 16-bit layer runs the ring kernel
 if DT == "f32w": shapes = WINO4 if W4 else WINO
-if IS_RING: shapes = RING
+if IS_RING: shapes = RING_F8 if DT == "f16xf8" else RING
 ROWMUL = 4 if W4 else 2 if DT == "f32w" else 1
 def run():
     global m
