@@ -497,7 +497,10 @@ struct Shape {
 #define RS_SHAPE_4(WM, WN, MT, NT) \
     {WM, WN, MT, NT, {conv_wino4_kernel<WM, WN, MT, NT, 16, true>, conv_wino4_kernel<WM, WN, MT, NT, 20, true>}, {nullptr, nullptr}}
 const Shape kShapes[] = {
-    RS_SHAPE_D(8, 1, 1, 2), RS_SHAPE(8, 1, 1, 3), RS_SHAPE(8, 1, 1, 4), RS_SHAPE(8, 1, 1, 5),
+    // 512 x 96 (round 6): 36 accumulator tiles = 249 / 253 registers, no scratch; its LDS fits with chunks of 16 only (157 KB), so
+    // rs_model_create's chunk choice moves layers 7 and 9 of the shipped net (22 and 48 column groups: 4 and 8 tiles of six) from
+    // chunks of 20 to 16 for it: layer 9 becomes ONE round of 256 tiles at 512 reads (-9 %), the fp32 step -1.3 %
+    RS_SHAPE_D(8, 1, 1, 2), RS_SHAPE(8, 1, 1, 3), RS_SHAPE(8, 1, 1, 4), RS_SHAPE(8, 1, 1, 5), RS_SHAPE(8, 1, 1, 6),
     RS_SHAPE_D(4, 2, 1, 2), RS_SHAPE(4, 2, 1, 3), RS_SHAPE(4, 2, 1, 4), RS_SHAPE(4, 2, 2, 2),
     RS_SHAPE_D(2, 4, 1, 2), RS_SHAPE(2, 4, 1, 3), RS_SHAPE(2, 4, 1, 4), RS_SHAPE(2, 4, 2, 2),
     // small tiles (round 4): a batch of 32 ... 200 reads leaves the late layers a few dozen tiles of the shapes above

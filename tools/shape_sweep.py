@@ -13,7 +13,7 @@ W4 = DT == "f32w4"                       # F(4,3) on the listed layers (RS_WINO4
 if W4:
     os.environ["RS_WINO4"] = ",".join(str(l) for l in layers)
     DT = "f32w"
-WINO4 = [(8,1,1,2),(8,1,1,3),(8,1,1,4),(8,1,1,5),(4,2,1,2),(4,2,1,3),(4,2,1,4),(4,2,2,2),(2,4,1,2),(2,4,1,3),(2,4,1,4),(2,4,2,2),(4,2,1,1),(2,4,1,1),(4,1,1,1),(2,2,1,1),(1,4,1,1),(4,1,1,2),(2,2,1,2),(1,4,1,2),(4,1,1,3),(2,2,1,3)]
+WINO4 = [(8,1,1,2),(8,1,1,3),(8,1,1,4),(8,1,1,5),(8,1,1,6),(4,2,1,2),(4,2,1,3),(4,2,1,4),(4,2,2,2),(2,4,1,2),(2,4,1,3),(2,4,1,4),(2,4,2,2),(4,2,1,1),(2,4,1,1),(4,1,1,1),(2,2,1,1),(1,4,1,1),(4,1,1,2),(2,2,1,2),(1,4,1,2),(4,1,1,3),(2,2,1,3)]
 WINO = [(8,1,2,2),(8,1,2,3),(8,1,2,4),(8,1,1,5),(8,1,1,6),(8,1,1,7),(8,1,1,8),(4,2,2,3),(4,2,2,4),(4,2,1,5),(4,2,1,7),(4,2,1,8),(2,4,2,2),(2,4,2,3),(2,4,1,4),(8,1,1,2),(8,1,1,3),(8,1,1,4),(4,2,1,2),(4,2,1,3),(4,2,1,4),(2,4,1,2),(2,4,1,1),(4,1,1,1),(2,2,1,1),(4,1,1,2),(2,2,1,2),(1,4,1,2),(4,1,1,3),(2,2,1,3)]
 shapes = [(8,1,4,2),(8,1,4,3),(8,1,2,5),(8,1,4,5),(8,1,2,7),(8,1,4,7),(4,2,4,2),(4,2,4,3),(4,2,2,4),(4,2,4,4),(4,2,4,5),(4,2,2,6),(4,2,4,6),(4,2,4,7),(4,2,2,8),(2,4,2,2),(2,4,2,4),(2,4,1,4),(4,2,2,5),(2,4,4,2),(8,1,2,6),(4,2,2,3)]
 sigs = synth.make_signals(20260103, 64, L); sigs = np.tile(sigs, ((B + 63) // 64, 1))[:B]
