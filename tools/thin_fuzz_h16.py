@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random batch shapes (1 ... 235 reads; equal / random / set lengths) through the 16-bit modes' thin-launch forms (the
+"""Random batch shapes (1 ... 235 reads, --big: 250 ... 800; equal / random / set lengths) through the 16-bit modes' thin-launch forms (the
 thin-launch kernel and the ring kernel's 64-row shapes, as the planner picks them) against the ring kernel alone with one big
 shape forced on every layer: the same bits; and against the fp32 path: within 1e-3, labels at 0.9 the same.
     python tools/thin_fuzz_h16.py [--cases 40] [--seed 1] [dtype ...]"""
@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="batches of 250 ... 800 reads (the 192- / 320- / 384-row shapes) instead of 1 ... 235")
     ap.add_argument("dtypes", nargs="*", default=["bf16x3", "f16x3", "f16xf8"])
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -30,7 +31,7 @@ def main():
         rng = np.random.default_rng(args.seed)
         worst = 0.0
         for k in range(args.cases):
-            B = int(rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233]) + rng.integers(0, 3))
+            B = int(rng.integers(250, 801)) if args.big else int(rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233]) + rng.integers(0, 3))
             mode = rng.integers(0, 3)
             lens = (np.full(B, int(rng.integers(4096, 16001))) if mode == 0 else rng.integers(4096, 16001, size=B) if mode == 1
                     else rng.choice([4096, 6024, 8615, 12048, 16000], size=B))
