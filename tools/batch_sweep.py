@@ -16,7 +16,7 @@ for dt in (sys.argv[1:] or ["f32w", "f16"]):
         sig, off, ln, lens = pack_reads(list(sigs), dev)
         out = torch.empty((B, 2), device=dev)
         for _ in range(12): m.classify_raw(sig, off, ln, lens, out=out)
-        torch.cuda.synchronize(); n = max(3, min(50, int(2000 / max(B, 1)) + 3)); t = time.perf_counter()
+        torch.cuda.synchronize(); n = max(int(os.environ.get("RS_SWEEP_MIN_STEPS", 3)), min(50, int(2000 / max(B, 1)) + 3)); t = time.perf_counter()
         for _ in range(n): m.classify_raw(sig, off, ln, lens, out=out)
         torch.cuda.synchronize(); dtm = (time.perf_counter() - t) / n
         print(f"{dt} B={B:5d} L={L:6d}: {dtm*1e3:8.3f} ms/batch  {B/dtm:10.0f} chunks/s")
