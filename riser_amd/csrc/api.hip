@@ -61,6 +61,7 @@ Hooks Hooks::from_env() {
     if (const char* e = getenv("RS_H16_WRES")) h.h16_wres = atoi(e) != 0;
     if (const char* e = getenv("RS_THIN_H16_ROWS")) h.thin_h16_rows = atoi(e);
     if (const char* e = getenv("RS_F8_MIN_CIN")) h.f8_min_cin = atoi(e);
+    if (const char* e = getenv("RS_X3_TAIL")) h.x3_tail = atoi(e) != 0;
     return h;
 }
 
@@ -599,6 +600,11 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
             // ring packing [panel][tap][n_alloc][64] (conv_ring_h16.hip): a panel is 64 input channels, or 32 input
             // channels as [hi x 32 | lo x 32] with lo = round(w - hi) in split precision
             L.ring_panels = x3 ? (L.c_in + 31) / 32 : (L.cp_in + 63) / 64;
+            // split precision, a last panel of at most 8 channels behind 2 ... 4 full ones (67 = 64 + 3, 100 = 96 + 4): its three
+            // taps become one K step (conv_ring_h16.hip: TAIL).  Not where another kernel reads the same packing (the 8-bit
+            // kernel's split-precision input, the weights-resident kernel): a layer's bits must not depend on who runs it.
+            L.ring_tail = x3 && m->hooks.x3_tail && !L.f8_in && !L.f8_out && L.c_in % 32 >= 1 && L.c_in % 32 <= 8 &&
+                          L.ring_panels >= 3 && L.ring_panels <= 5;
             if (rc == RS_OK && L.f8_in) {
                 // F8 rows (conv_ring_f8.hip): per 64 input channels an H panel (hi16 x 64) and an F panel of e4m3 bytes
                 // [lo8 c0-31 | hi8 c0-31 | lo8 c32-63 | hi8 c32-63], hi8 = e4m3(hi 2^-6), lo8 = e4m3((w - hi) 2^5)
@@ -629,7 +635,10 @@ int rs_model_create(int n_layers, const int32_t* channels, int n_classes, const 
                             const unsigned short hi = to_h16(wv, st16);
                             if (x3) {
                                 const int pn = ci / 32, cc = ci - pn * 32;
-                                const size_t at = (((size_t)pn * 3 + kw) * p.n_alloc + n) * 64 + cc;
+                                // the merged tail slab sits in the last panel's tap-0 place: K group kw = tap kw's 8 channel slots
+                                const size_t at = L.ring_tail && pn == L.ring_panels - 1
+                                                      ? (((size_t)pn * 3) * p.n_alloc + n) * 64 + 8 * kw + cc
+                                                      : (((size_t)pn * 3 + kw) * p.n_alloc + n) * 64 + cc;
                                 wr[at] = hi;
                                 wr[at + 32] = to_h16(wv - from_h16(hi, st16), st16);
                             } else {
@@ -1421,6 +1430,7 @@ int rs_model_layer_info(const rs_model* m, int layer, rs_layer_info* out) {
     out->c_in = L.c_in;
     out->cp_in = L.cp_in;
     out->k_pad = (m->dtype == RS_F32W ? (L.wino_m == 4 ? 6 : 4) : 3) * L.plan.kc * L.plan.nch;
+    if (L.ring_tail) out->k_pad = (3 * (L.ring_panels - 1) + 1) * 32;                       // the last panel's taps share one K step
     if (m->last_ring[layer] && !is_x3(m->dtype)) out->k_pad = 3 * 64 * L.ring_panels;      // 64-channel panels
     out->n_pad = m->last_bn[layer] ? round_up(round_up(L.c_out, 16), m->last_bn[layer]) : round_up(L.c_out, 16);
     out->bm = m->last_bm[layer];

@@ -79,6 +79,7 @@ struct Hooks {
     char emu_rows[128] = "";         // RS_EMU_ROWS "layer:permille;...": TIMING ONLY - the layer runs on that share of the batch's blocks
     int thin_h16_rows = -1;          // RS_THIN_H16_ROWS: split-precision layers of a launch with at most this many input rows run the
                                      // thin-launch kernel (conv_thin_h16.hip; 0 = never; default -1: by the cost estimates)
+    bool x3_tail = true;             // RS_X3_TAIL=0: split-precision layers whose last panel holds <= 8 channels keep it as three 32-wide K steps instead of ONE merged step (conv_ring_h16.hip: TAIL)
     int f8_min_cin = 200;            // RS_F8_MIN_CIN: RS_F16XF8 puts a layer on the 8-bit kernel from this many input channels on (api.hip: f8_eligible)
     bool h16_wres = true;            // RS_H16_WRES=0: narrow 16-bit layers on the ring kernel instead of the weights-resident one
     static Hooks from_env();
@@ -151,6 +152,8 @@ struct ConvLayerDev {
     void* d_w;                // packed weights [n_alloc][nch][3][kc] (f32 or bf16)
     void* d_w2 = nullptr;     // 16-bit modes: ring packing [panel][tap][n_alloc][64] (conv_ring_h16.hip)
     int ring_panels = 0;      // panels of the ring packing: 64 channels each (plain) or 32 channels as hi | lo (x3)
+    bool ring_tail = false;   // split precision: the LAST panel holds <= 8 channels and is packed as the merged tail slab
+                              // [hi: tap 0 | tap 1 | tap 2 | 0][lo: ...] in its tap-0 place (conv_ring_h16.hip: TAIL; conv_thin_h16.hip)
     unsigned* d_sat = nullptr; // half-precision modes: the model's sticky "an activation overflowed f16" flag (device word)
     bool f8_in = false;       // RS_F16XF8: the layer reads / writes F8 rows (conv_ring_f8.hip); cp_in / cp_out are their pitches
     bool f8_out = false;

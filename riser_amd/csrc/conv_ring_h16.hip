@@ -160,9 +160,10 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
-template <int WM, int WN, int MT, int NT, bool F16, bool X3>
+template <int WM, int WN, int MT, int NT, bool F16, bool X3, bool TAIL = false>
 __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingArgs a) {
     static_assert(WM * WN == 8, "8 waves per workgroup");
+    static_assert(!TAIL || X3, "the merged tail panel exists in split precision only");
     constexpr int BM = WM * 16 * MT;
     constexpr int BN = WN * 16 * NT;
     constexpr int XROWS = BM + 8;                                   // slab rows: positions m0 - 1 .. m0 + BM + 6
@@ -178,6 +179,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     static_assert(BN % kPieceRows == 0 && XROWS % kPieceRows == 0, "slabs are whole pieces");
     static_assert(BN <= 256, "one piece holds the tile's bias values");
     static_assert(CONST_OFF + 4096 <= 160 * 1024, "LDS capacity");
+    // TAIL (round 6): the layer's LAST panel holds at most 8 channels (67 = 64 + 3, 100 = 96 + 4): instead of three more
+    // sub-stages of 32-wide K steps that are 3/32 full, its three taps are ONE K step - k-group g of a lane's fragment = tap g's
+    // 8 channel slots (group 3: zero weights) - run once per tile between the last sub-stage's deferred pass and the epilogue.
+    // Its operands live in two slabs of their own: [XROWS rows x (hi x 8 | lo x 8) = 32 bytes] of activations and one weight
+    // slab [BN x 128 bytes] = [hi: tap 0 | tap 1 | tap 2 | 0][lo: the same], staged with the tap-2 sub-stage of the tile's
+    // FIRST panel (a tile has at least two full panels, so the pieces have landed long before the tile ends); a.n_panels
+    // counts the full panels only, the tail is panel index a.n_panels of the activation rows and of the weight packing.
+    constexpr int TXP = TAIL ? (XROWS + 31) / 32 : 0;               // DMA pieces of the tail activation slab (32 rows each)
+    constexpr int TAIL_X_OFF = CONST_OFF + 4096;
+    constexpr int TAIL_W_OFF = TAIL_X_OFF + TXP * 1024;
+    constexpr int GARB_OFF = TAIL_W_OFF + (TAIL ? WP : 0) * 1024;   // 1 KiB nobody reads: where a tile's other panels aim the tail's piece slots
+    constexpr int TPW = TAIL ? (TXP + WP + 7) / 8 : 0;              // tail pieces per wave (tap-2 sub-stage)
+    static_assert(!TAIL || GARB_OFF + 1024 <= 160 * 1024, "LDS capacity with the tail slabs");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
 #ifdef RS_RING_STAMPS
@@ -238,6 +252,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     auto issue_w = [&](const Panel& q, int tap) {
 #pragma unroll
         for (int idx = 0; idx < WPW; ++idx) issue_w_piece(q, true, tap, idx);
+    };
+    // the tail slabs of tile q (TAIL): piece k = wave + 8 idx; k < TXP: activation rows 32 k .. 32 k + 31 (lane l: row l >> 1,
+    // hi (l & 1 = 0) or lo half of the tail panel's first eight slots); then the WP pieces of the merged weight slab; the slots
+    // left over, and every slot when `live` is false (the tile's other panels), read out of range into the garbage piece
+    auto issue_tail_piece = [&](const Panel& q, bool live, int idx) {
+        const int k = wave + 8 * idx;
+        if (live && k < TXP) {
+            const unsigned off = (unsigned)(((q.m0 - 1 + 32 * k + (lane >> 1)) * a.cpx_in + a.n_panels * 64 + (lane & 1) * 32) * 2);
+            dma_piece(off, rs_x, (unsigned)(TAIL_X_OFF + k * 1024));
+        } else if (live && k - TXP < WP) {
+            const unsigned off = (unsigned)((((a.n_panels * 3) * a.n_alloc + q.n0 + (k - TXP) * kPieceRows) * 64) * 2) + w_lane;
+            dma_piece(off, rs_w, (unsigned)(TAIL_W_OFF + (k - TXP) * 1024));
+        } else {
+            dma_piece(kOob, rs_w, (unsigned)GARB_OFF);
+        }
     };
     // End of a sub-stage: wait until at most KEEP vector-memory operations of this wave are outstanding - the KEEP
     // pieces it issued during THIS sub-stage stay in flight across the barrier, everything older (the previous
@@ -345,6 +374,40 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
 #endif
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<F16>(keep_a[i], keep_b[j], acc[i][j]);
+        }
+    };
+    // the tail K step of the tile that has just run its last sub-stage (TAIL): fragments from the tail slabs - lane (r, g) reads
+    // slab row r + min(g, 2) (tap g of its output row; group 3 meets zero weights, any finite row serves) - and the three
+    // products in the order of every other K step
+    auto tail_pass = [&]() {
+        if constexpr (TAIL) {
+            u32x4 th[MT], tl_[MT];
+            const unsigned ta = (unsigned)(TAIL_X_OFF + (wm * 16 * MT + r + (g < 2 ? g : 2)) * 32);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                th[i] = *reinterpret_cast<const u32x4*>(lds + ta + i * 16 * 32);
+                tl_[i] = *reinterpret_cast<const u32x4*>(lds + ta + i * 16 * 32 + 16);
+            }
+            // column by column (the next column's weight fragments are read while this one's MFMAs run): 2 x MT + 4 fragment
+            // registers live instead of 2 x (MT + NT) - the widest shapes sit at the register limit here
+            const unsigned tb0 = b_rd[0] - W_OFF + TAIL_W_OFF, tb1 = b_rd[1] - W_OFF + TAIL_W_OFF;
+            u32x4 uh = *reinterpret_cast<const u32x4*>(lds + tb0), ul = *reinterpret_cast<const u32x4*>(lds + tb1);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                u32x4 nh = uh, nl = ul;
+                if (j + 1 < NT) {
+                    nh = *reinterpret_cast<const u32x4*>(lds + tb0 + (j + 1) * 16 * kRowB);
+                    nl = *reinterpret_cast<const u32x4*>(lds + tb1 + (j + 1) * 16 * kRowB);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = mfma16<F16>(th[i], uh, acc[i][j]);       // hi * hi
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = mfma16<F16>(tl_[i], uh, acc[i][j]);      // lo * hi
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = mfma16<F16>(th[i], ul, acc[i][j]);       // hi * lo
+                uh = nh;
+                ul = nl;
+            }
         }
     };
     auto substage = [&](auto TAP, int xb, bool have_prev, auto NDMA_, auto&& dma, auto&& between) {
@@ -560,6 +623,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
                  [&]() {
                      if (prev_tile_end) {
                          RS_STAMP(0);
+                         tail_pass();
                          epilogue(done, done_cb, done_xb);
                          RS_STAMP(2);
                      }
@@ -586,11 +650,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         RS_STAMP(0);
         stage_end(std::integral_constant<int, WPW + XPW1>{});
         RS_STAMP(1);
-        // tap 2: the next panel's tap-1 weights
-        substage(std::integral_constant<int, 2>{}, xb, true, std::integral_constant<int, WPW>{},
-                 [&](auto I_) { issue_w_piece(nxt, nxt_live, 1, decltype(I_)::value); }, nothing);
+        // tap 2: the next panel's tap-1 weights (TAIL: and the tile's tail slabs - real pieces in the tile's first panel, the
+        // same number of piece slots aimed at the garbage piece in the others: the stage-end wait counts them at compile time,
+        // and a second instance of the sub-stage behind a run-time branch costs 150-300 bytes of spills per lane: measured)
+        substage(std::integral_constant<int, 2>{}, xb, true, std::integral_constant<int, WPW + TPW>{},
+                 [&](auto I_) {
+                     constexpr int idx = decltype(I_)::value;
+                     if constexpr (idx < WPW)
+                         issue_w_piece(nxt, nxt_live, 1, idx);
+                     else
+                         issue_tail_piece(cur, cur.p == 0, idx - WPW);
+                 },
+                 nothing);
         RS_STAMP(0);
-        stage_end(std::integral_constant<int, WPW>{});
+        stage_end(std::integral_constant<int, WPW + TPW>{});
         RS_STAMP(1);
 #ifdef RS_RING_STAMPS
         ph[4] += 3;
@@ -611,6 +684,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
 #if !defined(RS_EMU_MFMA_FRAC) || RS_EMU_MFMA_FRAC != 3
     deferred_pass();
 #endif
+    tail_pass();
     epilogue(done, done_cb, done_xb);
     RS_STAMP(2);
 #ifdef RS_RING_STAMPS
@@ -629,14 +703,25 @@ using KernelFn = void (*)(const RingArgs);
 struct Shape {
     int wm, wn, mt, nt;
     KernelFn fn[2][2];     // [plain, x3][bf16, f16]
+    KernelFn tail[2];      // x3 with the merged tail panel [bf16, f16]; null where the tail slabs do not fit the LDS
 };
 
 constexpr size_t lds_bytes_of(int bm, int bn) { return (size_t)(2 * (bm + 8) + 3 * bn) * kRowB + 4096; }
+// ... with the tail slabs (kernel: TAIL_X_OFF ...): 32-row pieces of the activation tail, the merged weight slab, the garbage piece
+constexpr size_t lds_tail_bytes_of(int bm, int bn) { return lds_bytes_of(bm, bn) + (size_t)((bm + 8 + 31) / 32) * 1024 + (size_t)bn * kRowB + 1024; }
+template <int WM, int WN, int MT, int NT, bool F16>
+constexpr KernelFn tail_fn() {
+    if constexpr (lds_tail_bytes_of(WM * 16 * MT, WN * 16 * NT) <= 160 * 1024)
+        return conv_ring_h16_kernel<WM, WN, MT, NT, F16, true, true>;
+    else
+        return nullptr;
+}
 
 #define RS_SHAPE(WM, WN, MT, NT)                                                                                  \
     {WM, WN, MT, NT,                                                                                              \
      {{conv_ring_h16_kernel<WM, WN, MT, NT, false, false>, conv_ring_h16_kernel<WM, WN, MT, NT, true, false>},   \
-      {conv_ring_h16_kernel<WM, WN, MT, NT, false, true>, conv_ring_h16_kernel<WM, WN, MT, NT, true, true>}}}
+      {conv_ring_h16_kernel<WM, WN, MT, NT, false, true>, conv_ring_h16_kernel<WM, WN, MT, NT, true, true>}},     \
+     {tail_fn<WM, WN, MT, NT, false>(), tail_fn<WM, WN, MT, NT, true>()}}
 const Shape kShapes[] = {
     RS_SHAPE(8, 1, 2, 2), RS_SHAPE(8, 1, 2, 3), RS_SHAPE(8, 1, 2, 5), RS_SHAPE(8, 1, 2, 7), RS_SHAPE(8, 1, 4, 2),
     RS_SHAPE(8, 1, 4, 3), RS_SHAPE(8, 1, 4, 4), RS_SHAPE(4, 2, 4, 3), RS_SHAPE(4, 2, 4, 4), RS_SHAPE(4, 2, 4, 5),
@@ -653,28 +738,32 @@ const Shape kShapes[] = {
 #undef RS_SHAPE
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
-size_t lds_bytes(const Shape& s) { return lds_bytes_of(s.wm * 16 * s.mt, s.wn * 16 * s.nt); }
+size_t lds_bytes(const Shape& s, bool tail = false) {
+    return tail ? lds_tail_bytes_of(s.wm * 16 * s.mt, s.wn * 16 * s.nt) : lds_bytes_of(s.wm * 16 * s.mt, s.wn * 16 * s.nt);
+}
 
 // cost model in SIMD cycles per tile: a sub-stage is bound by its MFMAs (two waves share a SIMD, 16 cycles per
 // 16x16x32) or by its DMA (~24 B/clk/CU from L2), plus a fixed barrier / first-fragment bubble; the epilogue is paid
 // per tile.  Rounds over the CUs quantise the whole.  (Constants refitted in round 4 on tools/shape_sweep.py at 357 x 8615,
 // 300 x 7000, 128 x 16000 and 512 x 16000: the picks are within 1 % of the measured best of the table at all four.)
-double tile_cost(const Shape& s, int n_panels, bool x3) {
-    if (lds_bytes(s) > 160 * 1024) return -1.0;
+// tail: the layer's last panel is the merged tail (n_panels counts it): one more pass of MFMAs per tile instead of three sub-stages
+double tile_cost(const Shape& s, int n_panels, bool x3, bool tail = false) {
+    if (lds_bytes(s, tail) > 160 * 1024 || (tail && !s.tail[0])) return -1.0;
     const int bm = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
     const double mfma = (x3 ? 3.0 : 2.0) * s.mt * s.nt * 16.0 * 2.0;
     const double dma = ((bm + 8) / 3.0 + bnt * 16.0) * 128.0 / 24.0;
     const double ldsr = 2.0 * 8.0 * (s.mt + s.nt) * 1024.0 / 256.0 * 1.2;
     const double sub = std::max(std::max(mfma, dma), ldsr) + 350.0;
+    if (tail) return 3.0 * (n_panels - 1) * sub + mfma + 200.0 + 1500.0 + 60.0 * s.mt * s.nt * 1.5;
     return 3.0 * n_panels * sub + 1500.0 + 60.0 * s.mt * s.nt * (x3 ? 1.5 : 1.0);
 }
 
-const Shape* choose_shape(int64_t rows, int n16, int n_panels, int num_cu, bool x3, double* cost_out = nullptr) {
+const Shape* choose_shape(int64_t rows, int n16, int n_panels, int num_cu, bool x3, double* cost_out = nullptr, bool tail = false) {
     const Shape* best = nullptr;
     double best_cost = 1e300;
     for (int k = 0; k < kNumShapes; ++k) {
         const Shape& s = kShapes[k];
-        const double tile = tile_cost(s, n_panels, x3);
+        const double tile = tile_cost(s, n_panels, x3, tail);
         if (tile < 0) continue;
         const int bm = s.wm * 16 * s.mt, bnt = s.wn * s.nt;
         const int64_t mtiles = (rows + bm - 1) / bm;
@@ -696,14 +785,14 @@ const Shape* choose_shape(int64_t rows, int n16, int n_panels, int num_cu, bool 
 // the planner's own estimate (its cycles) of a launch over `rows` input rows with the best shape of the table
 double conv_ring_plan_cost(const ConvLayerDev& L, int64_t rows, int num_cu, bool x3) {
     double cost = 1e300;
-    choose_shape(rows, round_up(L.c_out, 16) / 16, L.ring_panels, num_cu, x3, &cost);
+    choose_shape(rows, round_up(L.c_out, 16) / 16, L.ring_panels, num_cu, x3, &cost, x3 && L.ring_tail);
     return cost + 2500.0;
 }
 
 int conv_ring_max_bn() { return 256; }
 int conv_ring_num_shapes() { return kNumShapes; }
-bool conv_ring_shape_ok(const ConvLayerDev&, int k) {
-    return k >= 0 && k < kNumShapes && lds_bytes(kShapes[k]) <= 160 * 1024;
+bool conv_ring_shape_ok(const ConvLayerDev& L, int k) {
+    return k >= 0 && k < kNumShapes && lds_bytes(kShapes[k], L.ring_tail) <= 160 * 1024 && (!L.ring_tail || kShapes[k].tail[0]);
 }
 
 int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
@@ -723,8 +812,9 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     // that hold channels, the last tile of a row of tiles stores zeros into what is left of the last panel
     const int n16 = round_up(L.c_out, 16) / 16;
     const int n_panels = L.ring_panels;
+    const bool tail = x3 && L.ring_tail;                              // the last of them is the merged tail panel
     double single_cost = 0.0;
-    const Shape* s = choose_shape(rows64, n16, n_panels, num_cu, x3, &single_cost);
+    const Shape* s = choose_shape(rows64, n16, n_panels, num_cu, x3, &single_cost, tail);
     bool pinned = false;                                            // a forced or tuned shape runs as one launch
     if (const char* force = L.hooks->force_ring; *force) {          // tuning aid: "layer:wm,wn,mt,nt;..."
         int l, wm, wn, mt, nt;
@@ -732,7 +822,7 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
             if (sscanf(q, "%d:%d,%d,%d,%d", &l, &wm, &wn, &mt, &nt) == 5 && l == layer_index)
                 for (int k = 0; k < kNumShapes; ++k)
                     if (kShapes[k].wm == wm && kShapes[k].wn == wn && kShapes[k].mt == mt && kShapes[k].nt == nt &&
-                        lds_bytes(kShapes[k]) <= 160 * 1024) {
+                        conv_ring_shape_ok(L, k)) {
                         s = &kShapes[k];
                         pinned = true;
                     }
@@ -771,7 +861,7 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     a.cpx_in = L.cp_in;
     a.cpx_out = L.cp_out;
     a.cols_out = x3 ? L.cp_out / 2 : L.cp_out;
-    a.n_panels = n_panels;
+    a.n_panels = tail ? n_panels - 1 : n_panels;                      // the kernel's loop runs over the full panels
     a.n_alloc = L.plan.n_alloc;
     a.n_reads = B;
     a.shift_out = layer_index + 1;
@@ -796,10 +886,10 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
         const unsigned grid = (unsigned)std::min<int64_t>(tiles, num_cu);
         a.walk = plan_walk(n_mtiles, n_ntiles, grid, num_cu, BM, 3.0 * BN, check_dead, !L.hooks->no_rect_order);
         a.walk.m_base = m_base;
-        KernelFn fn = sh.fn[x3 ? 1 : 0][f16 ? 1 : 0];
+        KernelFn fn = tail ? sh.tail[f16 ? 1 : 0] : sh.fn[x3 ? 1 : 0][f16 ? 1 : 0];
         RS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes(sh), st, a);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(kThreads), lds_bytes(sh, tail), st, a);
         RS_HIP(hipGetLastError());
 #ifdef RS_RING_STAMPS
         {
@@ -825,11 +915,11 @@ int launch_conv_ring_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     TailSplit split;
     if (!pinned && !L.hooks->no_tail_split && L.hooks->ring_tail_split)
         split = plan_tail_split(
-            kNumShapes, rows64, num_cu, single_cost, [&](int k) { return tile_cost(kShapes[k], n_panels, x3); },
+            kNumShapes, rows64, num_cu, single_cost, [&](int k) { return tile_cost(kShapes[k], n_panels, x3, tail); },
             [&](int k) { return kShapes[k].wm * 16 * kShapes[k].mt; },
             [&](int k) { return (n16 + kShapes[k].wn * kShapes[k].nt - 1) / (kShapes[k].wn * kShapes[k].nt); },
             [&](int64_t r, double* c) {
-                const Shape* t = choose_shape(r, n16, n_panels, num_cu, x3, c);
+                const Shape* t = choose_shape(r, n16, n_panels, num_cu, x3, c, tail);
                 return t ? (int)(t - kShapes) : -1;
             },
             L.hooks->tail_margin > 0 ? L.hooks->tail_margin : 0.92);      // this kernel's small tiles cost more than the model says (prologue + epilogue per tile): splits the

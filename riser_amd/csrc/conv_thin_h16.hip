@@ -57,6 +57,7 @@ struct ThinArgs {
     int cpx_in, cpx_out;
     int n_panels, n_alloc, n_blocks, shift_out;
     int n_ntiles;
+    int tail;                    // the last panel is the merged tail: its three taps are one K step (conv_ring_h16.hip: TAIL)
 };
 
 template <bool F16>
@@ -157,19 +158,33 @@ __global__ __launch_bounds__(kThreads) void conv_thin_h16_kernel(const ThinArgs 
         const int nxt = stage == 0 ? 2 : stage - 1;                 // (stage + 2) % 3
         issue_panel(p + 2, nxt);
         const unsigned so = (unsigned)(stage * kStage);
-        u32x4 fa[3][2], fb[3][2];
+        if (a.tail && p == a.n_panels - 1) {
+            // the merged tail panel (its stage holds the panel's activation slab as usual and the merged weight slab in the
+            // tap-0 rows): K group g of the fragment = tap g's first eight channel slots, i.e. slab row r + g, 16-byte slot 0
+            // of the hi / lo half (group 3: zero weights, any row); one K step, the three products in the usual order
+            const int R = wm * 16 + r + (g < 2 ? g : 2);
+            const u32x4 th = *reinterpret_cast<const u32x4*>(lds + so + R * 128 + ((0 ^ (R & 7)) << 4));
+            const u32x4 tl = *reinterpret_cast<const u32x4*>(lds + so + R * 128 + ((4 ^ (R & 7)) << 4));
+            const u32x4 uh = *reinterpret_cast<const u32x4*>(lds + so + b_rd[0][0]);
+            const u32x4 ul = *reinterpret_cast<const u32x4*>(lds + so + b_rd[0][1]);
+            acc = mfma16<F16>(th, uh, acc);
+            acc = mfma16<F16>(tl, uh, acc);
+            acc = mfma16<F16>(th, ul, acc);
+        } else {
+            u32x4 fa[3][2], fb[3][2];
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
+            for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                fa[tap][h] = *reinterpret_cast<const u32x4*>(lds + so + a_rd[tap][h]);
-                fb[tap][h] = *reinterpret_cast<const u32x4*>(lds + so + b_rd[tap][h]);
+                for (int h = 0; h < 2; ++h) {
+                    fa[tap][h] = *reinterpret_cast<const u32x4*>(lds + so + a_rd[tap][h]);
+                    fb[tap][h] = *reinterpret_cast<const u32x4*>(lds + so + b_rd[tap][h]);
+                }
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                acc = mfma16<F16>(fa[tap][0], fb[tap][0], acc);          // hi * hi
+                acc = mfma16<F16>(fa[tap][1], fb[tap][0], acc);          // lo * hi
+                acc = mfma16<F16>(fa[tap][0], fb[tap][1], acc);          // hi * lo
             }
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-            acc = mfma16<F16>(fa[tap][0], fb[tap][0], acc);          // hi * hi
-            acc = mfma16<F16>(fa[tap][1], fb[tap][0], acc);          // lo * hi
-            acc = mfma16<F16>(fa[tap][0], fb[tap][1], acc);          // hi * lo
         }
         stage = stage == 2 ? 0 : stage + 1;
     }
@@ -258,6 +273,7 @@ int launch_conv_thin_h16(const ConvLayerDev& L, const void* d_x, void* d_y, cons
     a.n_alloc = L.plan.n_alloc;
     a.n_blocks = B;
     a.shift_out = layer_index + 1;
+    a.tail = L.ring_tail ? 1 : 0;
     a.n_ntiles = L.cp_out / 2 / kBN;                                 // 32 slots per output panel: every one is written
     if (a.n_ntiles * kBN > L.plan.n_alloc) {
         set_error("conv_thin_h16: layer %d: %d columns overhang the weight table", layer_index, a.n_ntiles * kBN);

@@ -378,7 +378,7 @@ const Shape* pick_shape(const ConvLayerDev& L, bool x3) {
 }  // namespace
 
 bool conv_wres_h16_ok(const ConvLayerDev& L, bool x3) {
-    return L.d_w2 && L.ring_panels >= 1 && L.hooks->h16_wres && pick_shape(L, x3) != nullptr;
+    return L.d_w2 && L.ring_panels >= 1 && !L.ring_tail && L.hooks->h16_wres && pick_shape(L, x3) != nullptr;   // (a merged tail panel is the ring and thin kernels' packing)
 }
 
 int launch_conv_wres_h16(const ConvLayerDev& L, const void* d_x, void* d_y, const int32_t* d_len, int B, int P_in,
