@@ -183,15 +183,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
     // sub-stages of 32-wide K steps that are 3/32 full, its three taps are ONE K step - k-group g of a lane's fragment = tap g's
     // 8 channel slots (group 3: zero weights) - run once per tile between the last sub-stage's deferred pass and the epilogue.
     // Its operands live in two slabs of their own: [XROWS rows x (hi x 8 | lo x 8) = 32 bytes] of activations and one weight
-    // slab [BN x 128 bytes] = [hi: tap 0 | tap 1 | tap 2 | 0][lo: the same], staged with the tap-2 sub-stage of the tile's
+    // slab [BN x 128 bytes] = [hi: tap 0 | tap 1 | tap 2 | 0][lo: the same], staged behind the tap-2 sub-stage of the tile's
     // FIRST panel (a tile has at least two full panels, so the pieces have landed long before the tile ends); a.n_panels
     // counts the full panels only, the tail is panel index a.n_panels of the activation rows and of the weight packing.
     constexpr int TXP = TAIL ? (XROWS + 31) / 32 : 0;               // DMA pieces of the tail activation slab (32 rows each)
     constexpr int TAIL_X_OFF = CONST_OFF + 4096;
     constexpr int TAIL_W_OFF = TAIL_X_OFF + TXP * 1024;
-    constexpr int GARB_OFF = TAIL_W_OFF + (TAIL ? WP : 0) * 1024;   // 1 KiB nobody reads: where a tile's other panels aim the tail's piece slots
-    constexpr int TPW = TAIL ? (TXP + WP + 7) / 8 : 0;              // tail pieces per wave (tap-2 sub-stage)
-    static_assert(!TAIL || GARB_OFF + 1024 <= 160 * 1024, "LDS capacity with the tail slabs");
+    constexpr int TPW = TAIL ? (TXP + WP + 7) / 8 : 0;              // tail pieces per wave (behind the first panel's tap-2 sub-stage)
+    static_assert(!TAIL || TAIL_W_OFF + WP * 1024 <= 160 * 1024, "LDS capacity with the tail slabs");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
 #ifdef RS_RING_STAMPS
@@ -254,18 +253,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         for (int idx = 0; idx < WPW; ++idx) issue_w_piece(q, true, tap, idx);
     };
     // the tail slabs of tile q (TAIL): piece k = wave + 8 idx; k < TXP: activation rows 32 k .. 32 k + 31 (lane l: row l >> 1,
-    // hi (l & 1 = 0) or lo half of the tail panel's first eight slots); then the WP pieces of the merged weight slab; the slots
-    // left over, and every slot when `live` is false (the tile's other panels), read out of range into the garbage piece
-    auto issue_tail_piece = [&](const Panel& q, bool live, int idx) {
-        const int k = wave + 8 * idx;
-        if (live && k < TXP) {
+    // hi (l & 1 = 0) or lo half of the tail panel's first eight slots); then the WP pieces of the merged weight slab; a wave
+    // whose share has run out re-issues the last piece (same bytes, same place: the count per wave is static)
+    auto issue_tail_piece = [&](const Panel& q, int idx) {
+        const int k = min(wave + 8 * idx, TXP + WP - 1);
+        if (k < TXP) {
             const unsigned off = (unsigned)(((q.m0 - 1 + 32 * k + (lane >> 1)) * a.cpx_in + a.n_panels * 64 + (lane & 1) * 32) * 2);
             dma_piece(off, rs_x, (unsigned)(TAIL_X_OFF + k * 1024));
-        } else if (live && k - TXP < WP) {
+        } else {
             const unsigned off = (unsigned)((((a.n_panels * 3) * a.n_alloc + q.n0 + (k - TXP) * kPieceRows) * 64) * 2) + w_lane;
             dma_piece(off, rs_w, (unsigned)(TAIL_W_OFF + (k - TXP) * 1024));
-        } else {
-            dma_piece(kOob, rs_w, (unsigned)GARB_OFF);
         }
     };
     // End of a sub-stage: wait until at most KEEP vector-memory operations of this wave are outstanding - the KEEP
@@ -650,20 +647,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_ring_h16_kernel(const RingAr
         RS_STAMP(0);
         stage_end(std::integral_constant<int, WPW + XPW1>{});
         RS_STAMP(1);
-        // tap 2: the next panel's tap-1 weights (TAIL: and the tile's tail slabs - real pieces in the tile's first panel, the
-        // same number of piece slots aimed at the garbage piece in the others: the stage-end wait counts them at compile time,
-        // and a second instance of the sub-stage behind a run-time branch costs 150-300 bytes of spills per lane: measured)
-        substage(std::integral_constant<int, 2>{}, xb, true, std::integral_constant<int, WPW + TPW>{},
-                 [&](auto I_) {
-                     constexpr int idx = decltype(I_)::value;
-                     if constexpr (idx < WPW)
-                         issue_w_piece(nxt, nxt_live, 1, idx);
-                     else
-                         issue_tail_piece(cur, cur.p == 0, idx - WPW);
-                 },
-                 nothing);
+        // tap 2: the next panel's tap-1 weights
+        substage(std::integral_constant<int, 2>{}, xb, true, std::integral_constant<int, WPW>{},
+                 [&](auto I_) { issue_w_piece(nxt, nxt_live, 1, decltype(I_)::value); }, nothing);
         RS_STAMP(0);
-        stage_end(std::integral_constant<int, WPW + TPW>{});
+        if (TAIL && cur.p == 0) {
+            // the tile's tail slabs, behind its first panel (like the tile constants: a burst at the end of the sub-stage that
+            // stays in flight across the barrier; the tile has at least two full panels, so it has landed long before the tile ends)
+#pragma unroll
+            for (int idx = 0; idx < TPW; ++idx) issue_tail_piece(cur, idx);
+            stage_end(std::integral_constant<int, WPW + TPW>{});
+        } else {
+            stage_end(std::integral_constant<int, WPW>{});
+        }
         RS_STAMP(1);
 #ifdef RS_RING_STAMPS
         ph[4] += 3;
@@ -707,8 +703,8 @@ struct Shape {
 };
 
 constexpr size_t lds_bytes_of(int bm, int bn) { return (size_t)(2 * (bm + 8) + 3 * bn) * kRowB + 4096; }
-// ... with the tail slabs (kernel: TAIL_X_OFF ...): 32-row pieces of the activation tail, the merged weight slab, the garbage piece
-constexpr size_t lds_tail_bytes_of(int bm, int bn) { return lds_bytes_of(bm, bn) + (size_t)((bm + 8 + 31) / 32) * 1024 + (size_t)bn * kRowB + 1024; }
+// ... with the tail slabs (kernel: TAIL_X_OFF ...): 32-row pieces of the activation tail and the merged weight slab
+constexpr size_t lds_tail_bytes_of(int bm, int bn) { return lds_bytes_of(bm, bn) + (size_t)((bm + 8 + 31) / 32) * 1024 + (size_t)bn * kRowB; }
 template <int WM, int WN, int MT, int NT, bool F16>
 constexpr KernelFn tail_fn() {
     if constexpr (lds_tail_bytes_of(WM * 16 * MT, WN * 16 * NT) <= 160 * 1024)
