@@ -872,3 +872,42 @@ def test_f16xf8_cross_terms_on_the_8bit_mfma(dev, golden_dir):
         assert np.array_equal(m.classify_raw(s2, o2, l2, h2).cpu().numpy(), got[idx]), idx
     m.close()
     one.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3"])
+def test_merged_tail_panel_of_split_precision(dev, dtype):
+    """round 6: a split-precision layer whose input ends in a panel of 1-8 channels behind 2-4 full ones runs that panel's three
+    taps as ONE K step (conv_ring_h16.hip: TAIL; conv_thin_h16.hip).  A net whose layers sit on both sides of every
+    eligibility bound - inputs of 65 (3 panels, 1 channel in the last), 72 (8), 104 (4 panels), 136 (5 panels), 73 (9: not
+    merged), 40 (2 panels: not merged) - against the oracle; the thin-launch kernel, the ring kernel and every forced ring shape
+    give the same bits; RS_X3_TAIL=0 (the un-merged order) stays within round-off of it; a sub-batch reproduces its rows."""
+    from riser_amd.preprocess import pack_reads
+    from conftest import hooked_model
+    channels = (20, 30, 65, 72, 104, 136, 73, 40, 48)
+    cfg = synth.Config(synth.CnnConfig(channels=list(channels), kernels=[3] * len(channels)))
+    sd = synth.make_state_dict(11, channels=channels)
+    rng = np.random.default_rng(5)
+    lens = [int(n) for n in rng.integers(4096, 16001, size=37)] + [16000] * 3
+    sigs = [synth.make_signals(SIG_SEED, 1, n, first_read=5200 + i)[0] for i, n in enumerate(lens)]
+    sig, off, ln, lh = pack_reads(sigs, dev)
+    want = ro.classify_reads(sd, sigs[:10])
+    ring = hooked_model({"RS_THIN_H16_ROWS": "0"}, sd, dtype, dev, config=cfg)
+    got = ring.classify_raw(sig, off, ln, lh, return_logits=True)
+    assert np.abs(got[0][:10].cpu().numpy() - want).max() < 1e-3
+    info = ring.layer_info()
+    assert [info[i]["k_pad"] for i in (3, 4, 5, 6, 7, 8)] == [7 * 32, 7 * 32, 10 * 32, 13 * 32, 9 * 32, 6 * 32]   # merged: 3 (panels - 1) + 1 K steps
+    for env in ({"RS_THIN_H16_ROWS": "100000000"}, {}, {"RS_THIN_H16_ROWS": "0", "RS_FORCE_SHAPE_RING": ";".join("%d:4,2,2,4" % i for i in range(3, 9))},
+                {"RS_THIN_H16_ROWS": "0", "RS_FORCE_SHAPE_RING": ";".join("%d:8,1,2,7" % i for i in range(3, 9))}):
+        m = hooked_model(env, sd, dtype, dev, config=cfg)
+        g2 = m.classify_raw(sig, off, ln, lh, return_logits=True)
+        assert torch.equal(g2[0], got[0]) and torch.equal(g2[1], got[1]), (dtype, env)
+        m.close()
+    plain = hooked_model({"RS_X3_TAIL": "0"}, sd, dtype, dev, config=cfg)
+    assert [plain.layer_info()[i]["k_pad"] for i in (3, 4, 5, 6)] == [9 * 32, 9 * 32, 12 * 32, 15 * 32]
+    p2 = plain.classify_raw(sig, off, ln, lh)
+    assert 0 < float((p2 - got[0]).abs().max()) < 5e-4            # another summation order, the same arithmetic
+    plain.close()
+    idx = torch.tensor([7, 0, 39], device=dev)
+    part = ring.classify_raw(sig, off[idx].contiguous(), ln[idx].contiguous(), lh[[7, 0, 39]])
+    assert torch.equal(part, got[0][idx])
+    ring.close()
